@@ -1,0 +1,101 @@
+"""ctypes binding of fade_amd/libfadehip.so (include/fadehip.h).
+
+The library is the product path; there is no fallback.  Loading fails loudly when the shared
+object is missing, and fadehip_create fails when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfadehip.so")
+
+MAX_OPS = 16
+NUM_SLOTS = 2
+
+# every symbol include/fadehip.h declares
+EXPORTS = [
+    "fadehip_params_default", "fadehip_abi_version", "fadehip_create", "fadehip_destroy", "fadehip_last_error",
+    "fadehip_host_alloc", "fadehip_host_free", "fadehip_sw_batch", "fadehip_genome_upload",
+    "fadehip_annotate_upload", "fadehip_annotate_run", "fadehip_annotate_submit", "fadehip_annotate_collect",
+    "fadehip_sync", "fadehip_last_run_profile", "fadehip_stats_allreduce",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("open", C.c_int32), ("ext", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
+                ("max_ref_len", C.c_int32), ("max_batch_reads", C.c_int32), ("trace_bytes", C.c_int64)]
+
+
+class SwResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("end_query", C.c_int32), ("end_ref", C.c_int32), ("beg_query", C.c_int32),
+                ("beg_ref", C.c_int32), ("n_ops", C.c_int32), ("ops", C.c_uint32 * MAX_OPS)]
+
+
+class Aln(C.Structure):
+    _fields_ = [("read_idx", C.c_int32), ("art", C.c_int32), ("win_start", C.c_int64), ("win_len", C.c_int32),
+                ("clip_left", C.c_int32), ("clip_right", C.c_int32), ("aligned_len", C.c_int32), ("sw", SwResult)]
+
+
+SW_DTYPE = np.dtype([("score", "<i4"), ("end_query", "<i4"), ("end_ref", "<i4"), ("beg_query", "<i4"),
+                     ("beg_ref", "<i4"), ("n_ops", "<i4"), ("ops", "<u4", (MAX_OPS,))])
+ALN_DTYPE = np.dtype([("read_idx", "<i4"), ("art", "<i4"), ("win_start", "<i8"), ("win_len", "<i4"),
+                      ("clip_left", "<i4"), ("clip_right", "<i4"), ("aligned_len", "<i4"), ("sw", SW_DTYPE)])
+assert SW_DTYPE.itemsize == C.sizeof(SwResult)
+assert ALN_DTYPE.itemsize == C.sizeof(Aln)
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p),
+                ("has_sa", C.c_void_p), ("l_seq", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar_ops", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq_packed", C.c_void_p)]
+
+
+class AnnoOut(C.Structure):
+    _fields_ = [("rs", C.c_void_p), ("aln", C.c_void_p), ("aln_cap", C.c_int32), ("n_aln", C.c_int32),
+                ("stats", C.c_int64 * 8)]
+
+
+class FadeHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fadehip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libfadehip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); fade_amd has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.fadehip_params_default.argtypes = [C.POINTER(Params)]
+    L.fadehip_params_default.restype = None
+    L.fadehip_abi_version.restype = C.c_int
+    L.fadehip_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Params)]
+    L.fadehip_destroy.argtypes = [vp]
+    L.fadehip_destroy.restype = None
+    L.fadehip_last_error.argtypes = [vp]
+    L.fadehip_last_error.restype = C.c_char_p
+    L.fadehip_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.fadehip_host_free.argtypes = [vp, vp]
+    L.fadehip_sw_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.fadehip_genome_upload.argtypes = [vp, i32, vp, vp]
+    L.fadehip_annotate_upload.argtypes = [vp, C.c_int, C.POINTER(ReadBatch)]
+    L.fadehip_annotate_run.argtypes = [vp, C.c_int, i32, i32]
+    L.fadehip_annotate_submit.argtypes = [vp, C.c_int, C.POINTER(ReadBatch), i32, i32]
+    L.fadehip_annotate_collect.argtypes = [vp, C.c_int, C.POINTER(AnnoOut)]
+    L.fadehip_sync.argtypes = [vp]
+    L.fadehip_last_run_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_float * 4), C.POINTER(i64 * 4)]
+    L.fadehip_stats_allreduce.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here means the .so is stale against include/fadehip.h
+    _lib = L
+    return L

@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference interface for the annotate hot path, over the C ABI.
+
+Reference seam (D):
+    auto p = Parasail("ACTGN", 10, 2, 2, -3);           source/anno.d:36
+    auto res = p.sw_striped(q_seq, ref_seq);            source/analysis.d:67
+    res.score / res.position / res.cigar                source/analysis.d:69-113
+    annotateTask(rec, &p, fai, mfai, floor, window)     source/anno.d:55-110
+
+Everything that computes runs in libfadehip.so on the GPU; this module only marshals numpy
+arrays and formats the am/as/ar/ab strings exactly as analysis.d:84-92,108-118 and
+anno.d:94-107 do.  There is no CPU implementation of the alignment here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALN_DTYPE, SW_DTYPE, FadeHipError
+
+CIGAR_OPS = "MIDNSHP=X"
+NT16 = "=ACMGRSVTWYHKDBN"
+_NT16_ARR = np.frombuffer(NT16.encode(), dtype=np.uint8)
+# util.d:18-20
+_COMP = np.array([0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15], dtype=np.uint8)
+
+
+def cigar_str(ops):
+    return "".join("%d%s" % (int(o) >> 4, CIGAR_OPS[int(o) & 0xF]) for o in ops)
+
+
+class Context:
+    """One fadehip_ctx (one GPU)."""
+
+    def __init__(self, device=-1, open=10, ext=2, match=2, mismatch=-3, max_ref_len=0, max_batch_reads=0,
+                 trace_bytes=0):
+        self._L = _lib.load()
+        p = _lib.Params()
+        self._L.fadehip_params_default(C.byref(p))
+        p.open, p.ext, p.match, p.mismatch = open, ext, match, mismatch
+        if max_ref_len:
+            p.max_ref_len = max_ref_len
+        if max_batch_reads:
+            p.max_batch_reads = max_batch_reads
+        p.trace_bytes = trace_bytes
+        h = C.c_void_p()
+        rc = self._L.fadehip_create(C.byref(h), device, C.byref(p))
+        if rc != 0:
+            raise FadeHipError(rc, self._L.fadehip_last_error(None).decode())
+        self._h = h
+        self._keep = {}
+        self.contig_names = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fadehip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FadeHipError(rc, self._L.fadehip_last_error(self._h).decode())
+
+    # ---- level 1: the SW seam (analysis.d:67)
+    def sw_batch_packed(self, q_concat, q_off, r_concat, r_off):
+        q_concat = np.ascontiguousarray(q_concat, dtype=np.uint8)
+        r_concat = np.ascontiguousarray(r_concat, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        r_off = np.ascontiguousarray(r_off, dtype=np.int64)
+        n = len(q_off) - 1
+        out = np.zeros(n, dtype=SW_DTYPE)
+        self._chk(self._L.fadehip_sw_batch(self._h, n, q_concat.ctypes.data, q_off.ctypes.data, r_concat.ctypes.data,
+                                           r_off.ctypes.data, out.ctypes.data))
+        return out
+
+    def sw_batch(self, queries, refs):
+        qs = [q.encode() if isinstance(q, str) else bytes(q) for q in queries]
+        rs = [r.encode() if isinstance(r, str) else bytes(r) for r in refs]
+        q_off = np.zeros(len(qs) + 1, dtype=np.int64)
+        r_off = np.zeros(len(rs) + 1, dtype=np.int64)
+        np.cumsum([len(q) for q in qs], out=q_off[1:])
+        np.cumsum([len(r) for r in rs], out=r_off[1:])
+        qc = np.frombuffer(b"".join(qs), dtype=np.uint8) if q_off[-1] else np.zeros(0, np.uint8)
+        rc = np.frombuffer(b"".join(rs), dtype=np.uint8) if r_off[-1] else np.zeros(0, np.uint8)
+        return self.sw_batch_packed(qc, q_off, rc, r_off)
+
+    # ---- level 2: annotateTask over a batch (anno.d:55-110)
+    def genome_upload(self, names, seqs):
+        """seqs: list of bytes / uint8 arrays (raw FASTA residues)."""
+        arrs = [np.frombuffer(s.encode() if isinstance(s, str) else s, dtype=np.uint8) if not isinstance(s, np.ndarray)
+                else np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        n = len(arrs)
+        lens = (C.c_int64 * n)(*[len(a) for a in arrs])
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        self._chk(self._L.fadehip_genome_upload(self._h, n, C.cast(lens, C.c_void_p), C.cast(ptrs, C.c_void_p)))
+        self.contig_names = [x.decode() if isinstance(x, bytes) else x for x in names]
+
+    def _c_batch(self, batch):
+        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in
+                (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("has_sa", np.uint8), ("l_seq", np.int32),
+                 ("cigar_off", np.uint32), ("cigar_ops", np.uint32), ("seq_off", np.uint32), ("seq_packed", np.uint8))}
+        n = len(keep["pos"])
+        b = _lib.ReadBatch(n, *[keep[k].ctypes.data for k in
+                                ("tid", "pos", "flag", "has_sa", "l_seq", "cigar_off", "cigar_ops", "seq_off",
+                                 "seq_packed")])
+        return b, keep, n
+
+    def annotate_upload(self, slot, batch):
+        b, keep, n = self._c_batch(batch)
+        self._keep[slot] = (keep, n)
+        self._chk(self._L.fadehip_annotate_upload(self._h, slot, C.byref(b)))
+
+    def annotate_run(self, slot, floor_len=5, window=300):
+        self._chk(self._L.fadehip_annotate_run(self._h, slot, floor_len, window))
+
+    def annotate_collect(self, slot):
+        n = self._keep[slot][1]
+        rs = np.zeros(max(n, 1), dtype=np.uint8)
+        aln = np.zeros(max(n, 1), dtype=ALN_DTYPE)
+        out = _lib.AnnoOut(rs.ctypes.data, aln.ctypes.data, n, 0)
+        self._chk(self._L.fadehip_annotate_collect(self._h, slot, C.byref(out)))
+        return rs[:n], aln[:out.n_aln].copy(), np.array(list(out.stats), dtype=np.int64)
+
+    def annotate(self, batch, floor_len=5, window=300, slot=0):
+        self.annotate_upload(slot, batch)
+        self.annotate_run(slot, floor_len, window)
+        return self.annotate_collect(slot)
+
+    def sync(self):
+        self._chk(self._L.fadehip_sync(self._h))
+
+    def last_profile(self, slot=0):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int64 * 4)()
+        self._chk(self._L.fadehip_last_run_profile(self._h, slot, C.byref(ms), C.byref(cnt)))
+        return dict(gate_ms=ms[0], forward_ms=ms[1], traceback_ms=ms[2], total_ms=ms[3], alignments=cnt[0],
+                    cells=cnt[1], trace_bytes=cnt[2], algorithmic_bytes=cnt[3])
+
+
+class SwResult:
+    """What FADE reads from a dparasail result (analysis.d:69-113)."""
+
+    __slots__ = ("score", "position", "cigar", "end_query", "end_ref", "beg_query", "n_ops")
+
+    def __init__(self, rec):
+        self.score = int(rec["score"])
+        self.position = int(rec["beg_ref"])
+        self.n_ops = int(rec["n_ops"])
+        self.cigar = [int(o) for o in rec["ops"][:min(self.n_ops, _lib.MAX_OPS)]]
+        self.end_query = int(rec["end_query"])
+        self.end_ref = int(rec["end_ref"])
+        self.beg_query = int(rec["beg_query"])
+
+    def cigar_string(self):
+        return cigar_str(self.cigar)
+
+
+class Parasail:
+    """Parasail("ACTGN", 10, 2, 2, -3) — anno.d:36 — with the alignment done on the GPU."""
+
+    def __init__(self, alphabet="ACTGN", open=10, ext=2, match=2, mismatch=-3, device=-1, ctx=None):
+        if sorted(alphabet.upper()) != sorted("ACTGN"):
+            raise ValueError("the gfx950 kernels carry the ACTGN+wildcard matrix of anno.d:36 only")
+        self.ctx = ctx or Context(device=device, open=open, ext=ext, match=match, mismatch=mismatch)
+
+    def sw_striped(self, q_seq, ref_seq):
+        return SwResult(self.ctx.sw_batch([q_seq], [ref_seq])[0])
+
+    def sw_striped_batch(self, q_seqs, ref_seqs):
+        return [SwResult(r) for r in self.ctx.sw_batch(q_seqs, ref_seqs)]
+
+
+# ---------------------------------------------------------------- tag formatting (host, as in the reference)
+def unpack_seq(seq_packed, off, l_seq):
+    """BAM 4-bit -> nt16 codes (uint8 array of l_seq)."""
+    b = np.asarray(seq_packed[off:off + (l_seq + 1) // 2], dtype=np.uint8)
+    codes = np.empty(2 * len(b), dtype=np.uint8)
+    codes[0::2] = b >> 4
+    codes[1::2] = b & 15
+    return codes[:l_seq]
+
+
+def format_tags(batch, contig_names, rs, aln):
+    """am/as/ar/ab for every artifact read: analysis.d:84-92,108-118 + anno.d:98-107.
+    Returns {read_idx: dict(rs=, am=, as_=, ar=, ab=)} for reads with art_left|art_right."""
+    out = {}
+    for a in aln:
+        art = int(a["art"])
+        if not art:
+            continue
+        i = int(a["read_idx"])
+        lq = int(batch["l_seq"][i])
+        codes = unpack_seq(batch["seq_packed"], int(batch["seq_off"][i]), lq)
+        seq = _NT16_ARR[codes].tobytes().decode()
+        q_seq = _NT16_ARR[_COMP[codes][::-1]].tobytes().decode()  # util.d:23-34
+        qo = int(batch["qual_off"][i])
+        bq = (np.asarray(batch["qual"][qo:qo + lq], dtype=np.uint8) + 33).astype(np.uint8).tobytes().decode("latin-1")
+        sw = a["sw"]
+        n_ops = int(sw["n_ops"])
+        ops = [int(o) for o in sw["ops"][:n_ops]]
+        name = contig_names[int(batch["tid"][i])]
+        apos = int(a["win_start"]) + int(sw["beg_ref"])
+        pos = int(batch["pos"][i])
+        left = ["", "", "", ""]
+        right = ["", "", "", ""]
+        if art & 1:  # analysis.d:84-92
+            clip = int(a["clip_left"])
+            overlap = apos - (pos - clip) if apos >= pos - clip else 0
+            lead_s = ops[0] >> 4 if (ops[0] & 15) == 4 else 0
+            plen = min(lq, (lq - lead_s) + overlap)
+            left = ["%s,%d,%s" % (name, apos, cigar_str(ops)), seq[:plen], q_seq[lq - plen:], bq[:plen]]
+        if art & 2:  # analysis.d:108-118
+            clip = int(a["clip_right"])
+            res_aligned = sum(o >> 4 for o in ops if (o & 15) in (0, 2, 3, 7, 8))
+            lhs = pos + int(a["aligned_len"]) + clip
+            rhs = apos + res_aligned
+            overlap = lhs - rhs if lhs >= rhs else 0
+            trail_s = ops[-1] >> 4 if (ops[-1] & 15) == 4 else 0
+            plen = min(lq, (lq - trail_s) + overlap)
+            right = ["%s,%d,%s" % (name, apos, cigar_str(ops)), seq[lq - plen:], q_seq[:plen], bq[lq - plen:]]
+        out[i] = dict(rs=int(rs[i]), am=left[0] + ";" + right[0], as_=left[1] + ";" + right[1],
+                      ar=left[2] + ";" + right[2], ab=left[3] + ";" + right[3])
+    return out
+
+
+def annotate_records(ctx, batch, floor_len=5, window=300):
+    """annotateTask over a batch: returns (rs uint8[n], {read_idx: tags}) — anno.d:55-110."""
+    rs, aln, _ = ctx.annotate(batch, floor_len, window)
+    return rs, format_tags(batch, ctx.contig_names, rs, aln)

@@ -1,0 +1,532 @@
+// fadehip_kernels.hpp — gfx950 device code of the `fade annotate` hot path.
+//
+// Replaces, on the device:
+//   source/anno.d:61-74        gate, parse_clips (util.d:37-62), SA -> rs base bits      gate_kernel
+//   source/analysis.d:34-64    floor, reverse complement (util.d:23-34), window, fetch   gate_kernel + loaders
+//   source/analysis.d:67       p.sw_striped(q_seq, ref_seq)  (libparasail, un-vendored)  sw_forward_kernel + traceback_kernel
+//   source/analysis.d:69-83,98-107  artifact gates, ReadStatus bits (readstatus.d:5-26) traceback_kernel
+//
+// Execution model: integer DP, no MFMA.  One wavefront = 4 alignments ("quad"),
+// 16 lanes each; a lane owns R consecutive query rows (16*R >= Lq) and the 16 lanes sweep the
+// reference window as an anti-diagonal wave.  Neighbour exchange is DPP row_shr:1, whose zero
+// fill at each 16-lane row boundary IS the DP boundary condition.  The reference window is staged
+// once into LDS as pre-shifted class codes; the 4-bit/cell trace leaves the wave as fully coalesced
+// 256-byte stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fadehip.h"
+
+namespace fadehip {
+
+// ---------------------------------------------------------------- encodings
+// nt16 codes as htslib's seq_nt16_str "=ACMGRSVTWYHKDBN" (util.d:31).
+// Scoring class: A0 C1 G2 T3 N4, everything else 5 = parasail's '*' wildcard (score 0); 6 = pad column.
+__host__ __device__ constexpr uint64_t make_class_lut() {
+    uint64_t v = 0;
+    for (int k = 0; k < 16; k++) {
+        uint64_t c = 5;
+        if (k == 1) c = 0;
+        if (k == 2) c = 1;
+        if (k == 4) c = 2;
+        if (k == 8) c = 3;
+        if (k == 15) c = 4;
+        v |= c << (4 * k);
+    }
+    return v;
+}
+// util.d:18-20 seq_comp_table
+__host__ __device__ constexpr uint64_t make_comp_lut() {
+    const int t[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+    uint64_t v = 0;
+    for (int k = 0; k < 16; k++) v |= (uint64_t)t[k] << (4 * k);
+    return v;
+}
+constexpr uint64_t CLASS_LUT = make_class_lut();
+constexpr uint64_t COMP_LUT = make_comp_lut();
+constexpr int PAD_CLASS = 6;
+
+__device__ __forceinline__ uint32_t lut4(uint64_t lut, uint32_t code) { return (uint32_t)(lut >> (4 * code)) & 15u; }
+// base b of a packed array: byte b>>1, even base in the high nibble (BAM convention).
+__device__ __forceinline__ uint32_t nib_at(const uint8_t *p, uint64_t b) {
+    const uint32_t v = p[b >> 1];
+    return (b & 1) ? (v & 15u) : (v >> 4);
+}
+
+// ---------------------------------------------------------------- work descriptors
+struct Work {           // 32 bytes
+    uint64_t r_base;    // first base of the reference window in the packed reference
+    uint32_t q_base;    // first base of the query in the packed query array
+    uint32_t lq, lr;
+    uint32_t idx;       // level 1: pair index; level 2: read index
+    uint32_t flags;     // bit0: reverse-complement the query while loading (analysis.d:40)
+    uint32_t pad;
+};
+struct Meta {           // level-2 side data per work item, 32 bytes
+    int64_t win_start;
+    int32_t clip_left, clip_right, aligned_len;
+    int32_t pad[3];
+};
+struct Fwd {            // forward pass result per work item
+    int32_t score, end_q, end_r, pad;
+};
+
+constexpr int NUM_CLASSES = 10;
+__host__ __device__ constexpr int class_rows(int c) {
+    constexpr int t[NUM_CLASSES] = {4, 6, 8, 10, 12, 14, 16, 20, 24, 32};
+    return t[c];
+}
+__host__ __device__ inline int class_of_len(int lq) {
+    for (int c = 0; c < NUM_CLASSES; c++)
+        if (16 * class_rows(c) >= lq) return c;
+    return -1;
+}
+
+struct ScoreTab {
+    uint32_t prof[8];  // prof[q class] : 8 x 4-bit entries (W + open) indexed by ref class*4
+    int32_t open, ext, match, mismatch;
+};
+
+// ---------------------------------------------------------------- ASCII -> packed 4-bit
+__constant__ uint8_t c_ascii_code[256];
+
+// Two residues per thread -> one output byte.  `bad` is set when a byte is '=' (FADEHIP_E_RESIDUE).
+__global__ void pack_ascii_kernel(const uint8_t *__restrict__ in, uint64_t n_bases, uint64_t out_base,
+                                  uint8_t *__restrict__ out, int reject_eq, int *bad) {
+    // out_base must be even; thread k writes out[(out_base>>1) + k]
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t b = 2 * k;
+    if (b >= n_bases) return;
+    const uint8_t a0 = in[b];
+    const uint8_t a1 = (b + 1 < n_bases) ? in[b + 1] : 0;
+    if (reject_eq && (a0 == '=' || a1 == '=')) *bad = 1;
+    out[(out_base >> 1) + k] = (uint8_t)((c_ascii_code[a0] << 4) | c_ascii_code[a1]);
+}
+
+// ---------------------------------------------------------------- gate (anno.d:61-74, analysis.d:34-59)
+struct GateArgs {
+    int32_t n_reads;
+    const int32_t *tid, *pos, *l_seq;
+    const uint16_t *flag;
+    const uint8_t *has_sa;
+    const uint32_t *cigar_off, *cigar_ops, *seq_off;
+    int32_t floor_len, window;
+    int32_t n_contigs;
+    const int64_t *contig_len;
+    const uint64_t *contig_base;  // first base of each contig in the packed genome
+    int32_t max_ref_len;
+    uint8_t *rs;
+    Work *work[NUM_CLASSES];
+    Meta *meta[NUM_CLASSES];
+    uint32_t *counters;  // [0..NC) item counts, [NC..2NC) max lr, [2NC] error bits
+    unsigned long long *counters64;  // [0] DP cells, [1] packed sequence bytes read (query + window)
+};
+
+__global__ void gate_kernel(GateArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_reads) return;
+    const uint32_t c0 = a.cigar_off[i], c1 = a.cigar_off[i + 1];
+    // anno.d:61: count S ops; util.d:37-62 parse_clips; dhtslib alignedLength (M,D,N,=,X)
+    int n_soft = 0;
+    uint32_t clipL = 0, clipR = 0;
+    int64_t aligned = 0;
+    bool first = true;
+    for (uint32_t k = c0; k < c1; k++) {
+        const uint32_t op = a.cigar_ops[k] & 15u, len = a.cigar_ops[k] >> 4;
+        if (op == 4) n_soft++;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) aligned += len;
+        if (op == 5) continue;
+        const bool is_sc = (op == 4);
+        if (first && !is_sc) first = false;
+        else if (first && is_sc) clipL = len;
+        else if (is_sc) clipR = len;
+    }
+    const uint32_t flag = a.flag[i];
+    uint8_t rs = 0;
+    if ((flag & 4u) || n_soft == 0) {  // anno.d:61-65
+        a.rs[i] = 0;
+        return;
+    }
+    if (clipL != 0 || clipR != 0) rs |= 1;  // anno.d:69-70
+    if (a.has_sa[i]) rs |= 32;               // anno.d:73-74
+    a.rs[i] = rs;
+    // analysis.d:34: only clips strictly longer than the floor are re-aligned
+    const bool want = ((int64_t)clipL > a.floor_len && clipL != 0) || ((int64_t)clipR > a.floor_len && clipR != 0);
+    if (!want) return;
+    const int32_t tid = a.tid[i];
+    const int32_t lq = a.l_seq[i];
+    if (tid < 0 || tid >= a.n_contigs) {
+        atomicOr(&a.counters[2 * NUM_CLASSES], 1u);  // mapped record without a valid contig
+        return;
+    }
+    if (lq <= 0) return;
+    // analysis.d:45-59
+    const int64_t pos = a.pos[i];
+    int64_t start = pos - a.window;
+    if (start < 0) start = 0;
+    int64_t end = pos + aligned + a.window;
+    if (end > a.contig_len[tid]) end = a.contig_len[tid];
+    const int64_t lr = end - start;
+    if (lr <= 0) return;
+    const int cls = class_of_len(lq);
+    if (cls < 0) {
+        atomicOr(&a.counters[2 * NUM_CLASSES], 2u);  // read longer than FADEHIP_MAX_QUERY
+        return;
+    }
+    if (lr > a.max_ref_len) {
+        atomicOr(&a.counters[2 * NUM_CLASSES], 4u);  // window longer than max_ref_len
+        return;
+    }
+    const uint32_t slot = atomicAdd(&a.counters[cls], 1u);
+    atomicMax(&a.counters[NUM_CLASSES + cls], (uint32_t)lr);
+    atomicAdd(&a.counters64[0], (unsigned long long)lq * (unsigned long long)lr);
+    atomicAdd(&a.counters64[1], (unsigned long long)((lq + 1) / 2 + (lr + 1) / 2));
+    Work w;
+    w.r_base = a.contig_base[tid] + (uint64_t)start;
+    w.q_base = a.seq_off[i] * 2u;
+    w.lq = (uint32_t)lq;
+    w.lr = (uint32_t)lr;
+    w.idx = (uint32_t)i;
+    w.flags = 1u;
+    w.pad = 0;
+    a.work[cls][slot] = w;
+    Meta m;
+    m.win_start = start;
+    m.clip_left = (int32_t)clipL;
+    m.clip_right = (int32_t)clipR;
+    m.aligned_len = (int32_t)aligned;
+    m.pad[0] = m.pad[1] = m.pad[2] = 0;
+    a.meta[cls][slot] = m;
+}
+
+// ---------------------------------------------------------------- forward SW with trace
+struct SwArgs {
+    const Work *work;
+    int32_t n_items;        // items in this launch (quads = ceil(n/4))
+    const uint8_t *q_nib;   // packed queries
+    const uint8_t *r_nib;   // packed reference
+    uint32_t *trace;        // quad-major trace storage
+    uint64_t quad_stride;   // dwords per quad
+    int32_t ref_stride;     // LDS bytes per group (multiple of 16)
+    Fwd *fwd;
+    ScoreTab sc;
+};
+
+#define DPP_ROW_SHR1 0x111
+
+// One DP cell in the "hat" domain: Eh = E + open, Fh = F + open, Dp = D + open,
+// T = max(Dp, Eh, Fh), H = max(T - open, 0) as one saturating subtract.
+// Trace flags pushed MSB-first: nd (H!=D), nf (H!=F), eo (E opened), fo (F opened).
+template <int R>
+__global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, lig = lane & 15;
+    const int quad = blockIdx.x;
+    const int item = quad * 4 + g;
+    const bool have = item < a.n_items;
+    Work w;
+    if (have) w = a.work[item];
+    else { w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.pad = 0; }
+    const int lq = (int)w.lq, lr = (int)w.lr;
+
+    // steps this wave needs: longest window of its 4 groups + 15 lanes of skew, in blocks of 4
+    int maxlr = __builtin_amdgcn_readlane(lr, 0);
+    maxlr = max(maxlr, __builtin_amdgcn_readlane(lr, 16));
+    maxlr = max(maxlr, __builtin_amdgcn_readlane(lr, 32));
+    maxlr = max(maxlr, __builtin_amdgcn_readlane(lr, 48));
+    const int n_blocks = (maxlr + 15 + 3) >> 2;
+
+    // ---- stage the reference window into LDS as class*4 bytes; pad columns get PAD_CLASS*4
+    uint8_t *lref = lds + g * a.ref_stride;
+    const int n_cols = n_blocks * 4;
+    for (int k = lig; k < n_cols; k += 16) {
+        uint32_t c4 = PAD_CLASS * 4;
+        if (k < lr) c4 = lut4(CLASS_LUT, nib_at(a.r_nib, w.r_base + (uint64_t)k)) * 4u;
+        lref[k] = (uint8_t)c4;
+    }
+
+    // ---- per-row score profiles from the (reverse-complemented) query
+    uint32_t prof[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = lig * R + r;
+        uint32_t p = a.sc.prof[PAD_CLASS];
+        if (row < lq) {
+            uint32_t code;
+            if (w.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)(lq - 1 - row)));
+            else code = nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)row);
+            p = a.sc.prof[lut4(CLASS_LUT, code)];
+        }
+        prof[r] = p;
+    }
+    __syncthreads();
+
+    int32_t Hl[R], Eh[R];
+    uint32_t best[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; best[r] = 0; }
+    int32_t hu_out = 0, fu_out = 0, hu_prev = 0;
+    uint32_t rc = PAD_CLASS * 4;
+    const int32_t open = a.sc.open, ext = a.sc.ext;
+    uint32_t *tq = a.trace + (uint64_t)quad * a.quad_stride + lane;
+    constexpr int ND = R / 2;  // trace dwords per lane per 4-step block
+
+    for (int blk = 0; blk < n_blocks; blk++) {
+        const uint32_t rw = *reinterpret_cast<const uint32_t *>(lref + blk * 4);
+        uint32_t acc[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) acc[k] = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int t = blk * 4 + s;
+            const uint32_t fresh = (rw >> (8 * s)) & 0xffu;
+            // shift the column state one lane to the right; lane 0 of each 16-lane row takes the
+            // next reference column / the DP boundary zeros.
+            rc = (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)rc, DPP_ROW_SHR1, 0xf, 0xf, false);
+            int32_t hu = __builtin_amdgcn_update_dpp(0, hu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
+            int32_t fu = __builtin_amdgcn_update_dpp(0, fu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
+            const bool valid = (uint32_t)(t - lig) < (uint32_t)lr;
+            const uint32_t vmul = valid ? 65536u : 0u;
+            const uint32_t ctv = valid ? (uint32_t)(0xffff - t) : 0u;
+            int32_t hd = hu_prev;
+            hu_prev = hu;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int32_t wq = (int32_t)__builtin_amdgcn_ubfe(prof[r], rc, 4);
+                const int32_t Dp = hd + wq;
+                const int32_t hl = Hl[r];
+                const int32_t Ee = Eh[r] - ext;
+                const int32_t En = max(hl, Ee);
+                const int32_t Fe = fu - ext;
+                const int32_t Fn = max(hu, Fe);
+                const int32_t T = max(max(Dp, En), Fn);
+                const int32_t H = (int32_t)__builtin_elementwise_sub_sat((uint32_t)T, (uint32_t)open);
+                // each flag is the sign bit of a difference, shifted into the accumulator by one
+                // v_alignbit: nd (D < H), nf (F < H), eo (E opened), fo (F opened)
+                const int k0 = (s * R + r) * 4;  // flag index of `nd`; nf, eo, fo follow
+                uint32_t &ac = acc[k0 >> 5];
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Dp - T), 31);
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Fn - T), 31);
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Ee - hl), 31);
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Fe - hu), 31);
+                const uint32_t key = __umul24((uint32_t)H, vmul) + ctv;
+                best[r] = max(best[r], key);
+                hd = hl;
+                Hl[r] = H;
+                Eh[r] = En;
+                hu = H;
+                fu = Fn;
+            }
+            hu_out = hu;
+            fu_out = fu;
+        }
+        uint32_t *tp = tq + (uint64_t)blk * (ND * 64);
+#pragma unroll
+        for (int k = 0; k < ND; k++) tp[k * 64] = acc[k];
+    }
+
+    // ---- end cell: max H, then smallest ref index, then smallest query index (Appendix A.3)
+    uint32_t bk = 0;
+    int brow = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = lig * R + r;
+        if (row < lq && best[r] > bk) { bk = best[r]; brow = row; }
+    }
+    // low half holds 0xffff - t; column j = t - lig
+    uint64_t comp = bk ? ((((uint64_t)(bk + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - brow)) : 0ull;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const uint64_t o = __shfl_xor(comp, m, 64);
+        comp = o > comp ? o : comp;
+    }
+    if (have && lig == 0) {
+        Fwd f;
+        f.score = (int32_t)(comp >> 32);
+        f.end_r = comp ? (int32_t)(0xffff - ((comp >> 16) & 0xffff)) : 0;
+        f.end_q = comp ? (int32_t)(0xffff - (comp & 0xffff)) : 0;
+        f.pad = 0;
+        a.fwd[item] = f;
+    }
+}
+
+// ---------------------------------------------------------------- traceback + artifact gates
+struct TbArgs {
+    const Work *work;
+    const Meta *meta;       // nullptr for level 1
+    const Fwd *fwd;
+    int32_t n_items;
+    int32_t R;
+    const uint8_t *q_nib, *r_nib;
+    const uint32_t *trace;
+    uint64_t quad_stride;
+    ScoreTab sc;
+    fadehip_aln *out;       // [n_items] at this launch's base
+    uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
+    int32_t floor_len;
+    int32_t gate;           // 1: apply analysis.d:69-83,98-107
+};
+
+__device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int g, int i, int j) {
+    const int lig = i / R, r = i - lig * R;
+    const int t = j + lig;
+    const int k0 = ((t & 3) * R + r) * 4;
+    const uint32_t wv = tq[((uint64_t)(t >> 2) * (R >> 1) + (k0 >> 5)) * 64 + (g * 16 + lig)];
+    return (wv >> (28 - (k0 & 31))) & 15u;
+}
+
+__global__ void traceback_kernel(TbArgs a) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= a.n_items) return;
+    const Work w = a.work[item];
+    const Fwd f = a.fwd[item];
+    const int R = a.R, g = item & 3;
+    const uint32_t *tq = a.trace + (uint64_t)(item >> 2) * a.quad_stride;
+    const int lq = (int)w.lq;
+    const bool rcq = w.flags & 1u;
+    const int32_t open = a.sc.open, ext = a.sc.ext;
+
+    // Appendix A.4 traceback.  The value of the current cell is carried along (h), so the
+    // ZERO stop needs no stored flag.
+    uint32_t ring[FADEHIP_MAX_OPS];
+    uint32_t first_gen = 0;  // first generated run == last run of the CIGAR
+    int n_runs = 0;
+    int cur_op = -1;
+    uint32_t cur_len = 0;
+    int i = f.end_q, j = f.end_r, state = 0;
+    int32_t h = f.score;
+    while (i >= 0 && j >= 0) {
+        const uint32_t nb = trace_nibble(tq, R, g, i, j);
+        int op;
+        if (state == 0) {
+            if (h == 0) break;
+            if (!(nb & 8u)) {  // H == D
+                uint32_t qc = rcq ? lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)(lq - 1 - i)))
+                                  : nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)i);
+                const uint32_t rcode = nib_at(a.r_nib, w.r_base + (uint64_t)j);
+                const uint32_t cq = lut4(CLASS_LUT, qc), cr = lut4(CLASS_LUT, rcode);
+                const int32_t wsc = (cq == 5 || cr == 5) ? 0 : (cq == cr ? a.sc.match : a.sc.mismatch);
+                op = (qc == rcode && qc != 0) ? 7 : 8;  // '=' : 'X' by residue equality
+                h -= wsc;
+                i--; j--;
+            } else {
+                state = (nb & 4u) ? 1 : 2;  // H == F (query-only) has priority over E
+                continue;
+            }
+        } else if (state == 1) {  // E: consumes reference only -> 'D'
+            op = 2;
+            if (nb & 2u) { h += open; state = 0; } else h += ext;
+            j--;
+        } else {                  // F: consumes query only -> 'I'
+            op = 1;
+            if (nb & 1u) { h += open; state = 0; } else h += ext;
+            i--;
+        }
+        if (op == cur_op) cur_len++;
+        else {
+            if (cur_op >= 0) {
+                const uint32_t v = (cur_len << 4) | (uint32_t)cur_op;
+                if (n_runs == 0) first_gen = v;
+                ring[n_runs & (FADEHIP_MAX_OPS - 1)] = v;
+                n_runs++;
+            }
+            cur_op = op; cur_len = 1;
+        }
+    }
+    if (cur_op >= 0) {
+        const uint32_t v = (cur_len << 4) | (uint32_t)cur_op;
+        if (n_runs == 0) first_gen = v;
+        ring[n_runs & (FADEHIP_MAX_OPS - 1)] = v;
+        n_runs++;
+    }
+
+    fadehip_aln o;
+    o.read_idx = (int32_t)w.idx;
+    o.art = 0;
+    o.sw.score = f.score;
+    o.sw.end_query = f.end_q;
+    o.sw.end_ref = f.end_r;
+    o.sw.beg_query = i + 1;
+    o.sw.beg_ref = j + 1;
+    // Appendix A.6: [beg_query S] + runs (front = last generated) + [(lq-1-end_query) S]
+    int n = 0;
+    uint32_t first_op = 0, last_op = 0;
+#pragma unroll
+    for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+    if (o.sw.beg_query > 0) {
+        first_op = ((uint32_t)o.sw.beg_query << 4) | 4u;
+        o.sw.ops[0] = first_op;
+        n = 1;
+    }
+    for (int k = 0; k < n_runs; k++) {  // k-th run of the CIGAR = generated run n_runs-1-k
+        if (k < FADEHIP_MAX_OPS) {
+            const uint32_t v = ring[(n_runs - 1 - k) & (FADEHIP_MAX_OPS - 1)];
+            if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = v;
+            if (n == 0) first_op = v;
+        }
+        n++;
+    }
+    if (n_runs > 0) last_op = first_gen;
+    const int tail = lq - 1 - f.end_q;
+    if (tail > 0) {
+        last_op = ((uint32_t)tail << 4) | 4u;
+        if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = last_op;
+        n++;
+    }
+    o.sw.n_ops = n;
+
+    if (a.meta) {
+        const Meta m = a.meta[item];
+        o.win_start = m.win_start;
+        o.win_len = (int32_t)w.lr;
+        o.clip_left = m.clip_left;
+        o.clip_right = m.clip_right;
+        o.aligned_len = m.aligned_len;
+        if (a.gate && n >= 1 && n <= 10) {  // analysis.d:69-70
+            const uint32_t lead_s = (first_op & 15u) == 4u ? (first_op >> 4) : 0u;
+            const uint32_t trail_s = (n > 1 && (last_op & 15u) == 4u) ? (last_op >> 4) : 0u;
+            // analysis.d:34,74-80: left clip longer than the floor, last op '=', score > 1.8*clip
+            // (float cutoff == integer 5*score > 9*clip), result has leading S only
+            if (m.clip_left != 0 && m.clip_left > a.floor_len && (last_op & 15u) == 7u &&
+                5 * (int64_t)f.score > 9 * (int64_t)m.clip_left && trail_s == 0 && lead_s != 0)
+                o.art |= 1;
+            // analysis.d:34,98-104
+            if (m.clip_right != 0 && m.clip_right > a.floor_len && (first_op & 15u) == 7u &&
+                5 * (int64_t)f.score > 9 * (int64_t)m.clip_right && lead_s == 0 && trail_s != 0)
+                o.art |= 2;
+            if (o.art) a.rs[w.idx] |= (uint8_t)(o.art << 1);  // readstatus.d: bit1 art_left, bit2 art_right
+        }
+    } else {
+        o.win_start = 0;
+        o.win_len = (int32_t)w.lr;
+        o.clip_left = o.clip_right = o.aligned_len = 0;
+    }
+    a.out[item] = o;
+}
+
+// ---------------------------------------------------------------- stats.d:45-54 over rs
+__global__ void stats_kernel(const uint8_t *rs, int n, unsigned long long *counters) {
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = rs[i];
+        const uint32_t sc = v & 1, al = (v >> 1) & 1, ar = (v >> 2) & 1, ml = (v >> 3) & 1, mr = (v >> 4) & 1,
+                       sup = (v >> 5) & 1;
+        c[0] += 1;
+        c[1] += sc;
+        c[2] += sup;
+        c[3] += (al | ar) & sup;
+        c[4] += (al | ar);
+        c[5] += ((al & ml) | (ar & mr));
+        c[6] += al;
+        c[7] += ar;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        unsigned long long v = c[k];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[k], v);
+    }
+}
+
+}  // namespace fadehip

@@ -1,0 +1,161 @@
+/*
+ * fadehip.h — C ABI of the MI355X (gfx950) `fade annotate` hot path.
+ *
+ * Drop-in boundary.  The reference (blachlylab/fade) has no plugin API; its hot path is a
+ * synchronous per-record FFI seam:
+ *     auto p   = Parasail("ACTGN", 10, 2, 2, -3);          source/anno.d:36
+ *     auto res = p.sw_striped(q_seq, ref_seq);             source/analysis.d:67
+ * inside  annotateTask (source/anno.d:55-110)  <-  foreach(rec; parallel(bam.allRecords))
+ * (source/anno.d:44-50).  One call per clip cannot feed a GPU, so this ABI exposes the same
+ * contract in two batched forms:
+ *
+ *   Level 1  fadehip_sw_*        — a batch of (query, reference) strings -> {score, position, cigar}
+ *                                   replaces analysis.d:67 (the dparasail/libparasail call).
+ *   Level 2  fadehip_annotate_*  — a batch of BAM-native read records against a genome resident
+ *                                   in HBM -> rs byte per read + the alignment of every read
+ *                                   that was re-aligned.  Replaces the body of annotateTask:
+ *                                   anno.d:61-74 (gate, parse_clips, SA), analysis.d:34-64
+ *                                   (floor, reverse complement util.d:23-34, window, FASTA fetch),
+ *                                   analysis.d:67 (SW), analysis.d:69-83,98-107 (artifact gates),
+ *                                   readstatus.d:5-26 (rs).  The caller keeps I/O and formats the
+ *                                   am/as/ar/ab strings (analysis.d:84-92,108-118, anno.d:94-107).
+ *
+ * Plain C: pointers and sizes only.  Every function returns 0 on success or a negative
+ * FADEHIP_E_* code and never throws or aborts across the boundary; fadehip_last_error(ctx) returns
+ * a sticky message.  A ctx is bound to one device and must be driven by one thread at a time.
+ * There is no CPU fallback: without a usable HIP device fadehip_create fails.
+ */
+#ifndef FADEHIP_H
+#define FADEHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FADEHIP_ABI_VERSION 1
+#define FADEHIP_MAX_OPS 16   /* ops reported per alignment (FADE rejects > 10, analysis.d:69) */
+#define FADEHIP_MAX_QUERY 512 /* longest read the wave-quad kernel handles */
+#define FADEHIP_NUM_SLOTS 2   /* double-buffered batches per ctx */
+
+enum {
+    FADEHIP_OK = 0,
+    FADEHIP_E_INVALID = -1,     /* bad argument */
+    FADEHIP_E_NODEVICE = -2,    /* no HIP device / wrong architecture */
+    FADEHIP_E_HIP = -3,         /* a HIP runtime call failed (message has the HIP error) */
+    FADEHIP_E_NOMEM = -4,       /* host or device allocation failed */
+    FADEHIP_E_UNSUPPORTED = -5, /* scoring parameters, read or window length outside kernel limits */
+    FADEHIP_E_STATE = -6,       /* call out of order (e.g. wait on an idle slot) */
+    FADEHIP_E_RESIDUE = -7,     /* FASTA contains a byte this encoding cannot represent ('=') */
+    FADEHIP_E_RCCL = -8         /* an RCCL call failed */
+};
+
+typedef struct fadehip_ctx fadehip_ctx;
+
+/* Parasail("ACTGN", open, ext, match, mismatch) — anno.d:36.  The alphabet is fixed to
+ * A,C,T,G,N + wildcard (every other residue scores 0), as parasail_matrix_create builds it. */
+typedef struct {
+    int32_t open;      /* 10: cost of the first gap base */
+    int32_t ext;       /* 2 : cost of each further gap base */
+    int32_t match;     /* 2 */
+    int32_t mismatch;  /* -3 */
+    int32_t max_ref_len;   /* longest reference window accepted; 0 -> 8192 */
+    int32_t max_batch_reads; /* capacity of one annotate batch; 0 -> 1<<20 */
+    int64_t trace_bytes;   /* device bytes reserved for trace tables; 0 -> sized on demand */
+} fadehip_params;
+
+void fadehip_params_default(fadehip_params *p);
+int fadehip_abi_version(void);
+
+/* device < 0 -> current device.  Fails with FADEHIP_E_NODEVICE when no gfx950 device exists. */
+int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params);
+void fadehip_destroy(fadehip_ctx *ctx);
+const char *fadehip_last_error(const fadehip_ctx *ctx); /* never NULL; ctx may be NULL */
+
+/* Pinned host memory so that submit can use hipMemcpyAsync. */
+int fadehip_host_alloc(fadehip_ctx *ctx, size_t bytes, void **out);
+int fadehip_host_free(fadehip_ctx *ctx, void *p);
+
+/* ------------------------------------------------------------------ Level 1: the SW seam -- */
+/* What FADE reads from a parasail result (analysis.d:69-113): res.score, res.position
+ * (= beg_ref), res.cigar (BAM-encoded len<<4|op with "MIDNSHP=X", soft-clip padded). */
+typedef struct {
+    int32_t score;
+    int32_t end_query, end_ref; /* 0-based inclusive end cell */
+    int32_t beg_query, beg_ref; /* 0-based; beg_ref is dparasail's `position` */
+    int32_t n_ops;              /* true op count; only min(n_ops, FADEHIP_MAX_OPS) stored */
+    uint32_t ops[FADEHIP_MAX_OPS];
+} fadehip_sw_result;
+
+/* n alignments; strings are ASCII, concatenated, q_off/r_off hold n+1 offsets.  Synchronous. */
+int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_t *q_off,
+                     const uint8_t *r, const int64_t *r_off, fadehip_sw_result *out);
+
+/* ------------------------------------------------------ Level 2: annotateTask over a batch -- */
+/* Upload the indexed FASTA once (what IndexedFastaFile + fetchSequence serve, analysis.d:63).
+ * seqs[c] holds lengths[c] ASCII residues (any case; upper-cased on device as analysis.d:63 does).
+ * Stored in HBM as 4-bit codes, two bases per byte. */
+int fadehip_genome_upload(fadehip_ctx *ctx, int32_t n_contigs, const int64_t *lengths,
+                          const uint8_t *const *seqs);
+
+/* BAM-native structure-of-arrays view of n records (what annotateTask reads from a bam1_t). */
+typedef struct {
+    int32_t n_reads;
+    const int32_t *tid;        /* [n] core.tid */
+    const int32_t *pos;        /* [n] core.pos, 0-based */
+    const uint16_t *flag;      /* [n] core.flag */
+    const uint8_t *has_sa;     /* [n] 1 iff the record carries an SA aux tag (anno.d:73) */
+    const int32_t *l_seq;      /* [n] core.l_qseq */
+    const uint32_t *cigar_off; /* [n+1] index of the record's first op in cigar_ops */
+    const uint32_t *cigar_ops; /* BAM-encoded ops, all records concatenated */
+    const uint32_t *seq_off;   /* [n+1] byte offset of the record's packed sequence */
+    const uint8_t *seq_packed; /* BAM 4-bit sequence bytes, each record byte-aligned */
+} fadehip_read_batch;
+
+/* One entry per read that was re-aligned (clip longer than min-length), in no particular order. */
+typedef struct {
+    int32_t read_idx;
+    int32_t art;         /* bit0 art_left, bit1 art_right (analysis.d:82,106) */
+    int64_t win_start;   /* `start` of analysis.d:45-51 */
+    int32_t win_len;     /* ref_seq.length */
+    int32_t clip_left, clip_right; /* parse_clips(rec.cigar) lengths (anno.d:68) */
+    int32_t aligned_len; /* rec.cigar.alignedLength (analysis.d:53) */
+    fadehip_sw_result sw;
+} fadehip_aln;
+
+typedef struct {
+    uint8_t *rs;          /* [n_reads] out: ReadStatus.raw per read (anno.d:63,94) */
+    fadehip_aln *aln;     /* [aln_cap] out */
+    int32_t aln_cap;      /* in: capacity of aln (n_reads is always enough) */
+    int32_t n_aln;        /* out */
+    int64_t stats[8];     /* out: stats.d:45-54 over this batch: read_count, clipped, sup, art_sup,
+                             art, art_mate, aln_l, aln_r */
+} fadehip_anno_out;
+
+/* Asynchronous pipeline, slot in [0, FADEHIP_NUM_SLOTS):
+ *   upload  : H2D copies of the batch arrays (hipMemcpyAsync on the slot's stream)
+ *   run     : gate -> forward SW with trace -> traceback + artifact gates, all on device
+ *   collect : D2H of rs / aln / stats; blocks until the slot is done
+ * submit = upload + run.  Results stay valid until the slot is uploaded again.
+ * floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
+int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch);
+int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t window);
+int fadehip_annotate_submit(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch,
+                            int32_t floor_len, int32_t window);
+int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out);
+int fadehip_sync(fadehip_ctx *ctx);
+
+/* Measurement: device time of the last run on `slot`, from hipEvents recorded on the slot's
+ * stream around each kernel.  ms[0] gate, ms[1] forward SW (dominant), ms[2] traceback+gates,
+ * ms[3] whole run.  counts[0] alignments, counts[1] DP cells, counts[2] trace bytes written,
+ * counts[3] algorithmic bytes of the forward kernel. */
+int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[4]);
+
+/* Sum counters over the ranks' devices with one ncclAllReduce (RCCL) — single process, one ctx
+ * per device.  counters is [n_ctx][count] in, every row holds the sum on return. */
+int fadehip_stats_allreduce(fadehip_ctx *const *ctxs, int n_ctx, int64_t *counters, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,40 @@
+"""Level-2 parity: the device annotate path vs the oracle's annotateTask restatement (anno.d:55-110)."""
+import numpy as np
+import pytest
+
+from fade_amd import format_tags, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_tags(oracle, g, b, cfg, floor_len=None, window=None):
+    G = oracle.GenomeHolder(g.names, [a.tobytes() for a in g.ascii_contigs()])
+    reads, keep = oracle.make_reads(b)
+    n = len(b["pos"])
+    rs = np.zeros(n, dtype=np.uint8)
+    tags = {}
+    for i in range(n):
+        a = oracle.annotate_one(G, reads[i], floor_len=cfg["floor_len"] if floor_len is None else floor_len,
+                                window=cfg["window"] if window is None else window)
+        rs[i] = a["rs"]
+        if a["has_tags"]:
+            tags[i] = dict(rs=a["rs"], am=a["am"], as_=a["as_"], ar=a["ar"], ab=a["ab"])
+    return rs, tags
+
+
+@pytest.mark.parametrize("name,n", [("C1", 6000), ("C2", 6000), ("C3", 3000), ("C5", 4000)])
+def test_annotate_matches_oracle(ctx, oracle, name, n):
+    cfg, g, b = synth.make_config(name, n, contig_len=300_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    rs, aln, stats = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+    tags = format_tags(b, ctx.contig_names, rs, aln)
+    ors, otags = _oracle_tags(oracle, g, b, cfg)
+    assert np.array_equal(rs, ors), "rs differs at %r" % np.nonzero(rs != ors)[0][:10]
+    assert tags == otags
+    # stats.d:45-54 over the batch
+    c = np.zeros(8, dtype=np.int64)
+    for v in ors:
+        c += [1, v & 1, (v >> 5) & 1, ((v >> 1 | v >> 2) & 1) & (v >> 5) & 1, (v >> 1 | v >> 2) & 1,
+              ((v >> 1) & (v >> 3) | (v >> 2) & (v >> 4)) & 1, (v >> 1) & 1, (v >> 2) & 1]
+    assert list(stats) == list(c)
+    assert len(tags) > 0

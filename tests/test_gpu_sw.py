@@ -1,0 +1,68 @@
+"""Level-1 parity: fadehip_sw_batch (analysis.d:67 replacement) vs the scalar oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import concat, make_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ctx, oracle, qs, rs):
+    qc, qo = concat(qs)
+    rc, ro = concat(rs)
+    got = ctx.sw_batch_packed(qc, qo, rc, ro)
+    exp, exp_ops = oracle.sw_batch(qc, qo, rc, ro, threads=8, max_ops=16)
+    bad = []
+    for k in range(len(qs)):
+        g = got[k]
+        e = exp[k]
+        tup_g = (int(g["score"]), int(g["end_query"]), int(g["end_ref"]), int(g["beg_query"]), int(g["beg_ref"]),
+                 int(g["n_ops"]))
+        tup_e = tuple(int(x) for x in e)
+        n = min(tup_e[5], 16)
+        if tup_g != tup_e or list(g["ops"][:n]) != list(exp_ops[k][:n]):
+            bad.append((k, tup_g, tup_e, oracle.cigar_str(g["ops"][:n]), oracle.cigar_str(exp_ops[k][:n])))
+    assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(qs), bad[:3])
+
+
+def test_sw_small_known(ctx, oracle):
+    q = np.frombuffer(b"GGGGGGGGGGACGTACGGTCAGGC", dtype=np.uint8)
+    r = np.frombuffer(b"TTTTTTTTTTACGTACGGTCAGGCTTTTTTTTTT", dtype=np.uint8)
+    got = ctx.sw_batch([q.tobytes()], [r.tobytes()])[0]
+    assert int(got["score"]) == 28 and int(got["beg_ref"]) == 10
+    assert oracle.cigar_str(got["ops"][:got["n_ops"]]) == "10S14="
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sw_random_families(ctx, oracle, seed):
+    rng = np.random.default_rng(seed)
+    qs, rs = make_pairs(rng, 1400)
+    _compare(ctx, oracle, qs, rs)
+
+
+def test_sw_all_row_classes(ctx, oracle):
+    """Every R class of the kernel (Lq 1..512) and ragged window lengths."""
+    rng = np.random.default_rng(11)
+    qs, rs = [], []
+    for lq in list(range(1, 40)) + [63, 64, 65, 95, 96, 97, 127, 128, 129, 150, 159, 160, 161, 191, 192, 193, 223,
+                                     224, 225, 250, 255, 256, 257, 300, 319, 320, 321, 383, 384, 385, 500, 511, 512]:
+        for kind in ("planted", "related", "random"):
+            q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(1, 1200), kinds=(kind,))
+            qs += q
+            rs += r
+    _compare(ctx, oracle, qs, rs)
+
+
+def test_sw_empty_inputs(ctx):
+    out = ctx.sw_batch([b"", b"ACGT", b""], [b"ACGT", b"", b""])
+    assert [int(x) for x in out["n_ops"]] == [0, 1, 0]
+    assert int(out["ops"][1][0]) == (4 << 4 | 4)
+    assert len(ctx.sw_batch([], [])) == 0
+
+
+def test_sw_limits_fail_loudly(ctx):
+    import fade_amd
+    with pytest.raises(fade_amd.FadeHipError):
+        ctx.sw_batch([b"A" * 513], [b"ACGT"])
+    with pytest.raises(fade_amd.FadeHipError):
+        ctx.sw_batch([b"ACGT"], [b"A" * 9000])
