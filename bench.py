@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — annotate reads/s of the MI355X hot path on BASELINE.json's config 2
+(10M x 150 bp PE reads, --window-size 100, default --min-length), synthetic data.
+
+One process per GPU (torch.distributed / RCCL when --gpus > 1); reads shard per rank with no
+data-path collective; the only collective is the final all-reduce of the stats.d counters.
+A step = one pass of the device annotate path (gate -> forward SW with trace -> traceback + artifact
+gates -> stats) over one batch of reads already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(genome, cfg, n_sample, seed):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on this host's cores
+    over a bounded sample of the same workload.  Checker code: never on the product path."""
+    from fade_amd import synth
+    from oracle import pyoracle as O
+    cores = len(os.sched_getaffinity(0))
+    b = synth.make_reads(genome, n_sample, seed, **cfg)
+    G = O.GenomeHolder(genome.names, [a.tobytes() for a in genome.ascii_contigs()])
+    t0 = time.perf_counter()
+    rs, _ = O.annotate_batch_soa(G, b, cfg["floor_len"], cfg["window"], threads=cores, want_am=False)
+    dt = time.perf_counter() - t0
+    return dict(value=n_sample / dt, unit="reads/s", cores=cores, kind="port",
+                sample="%d reads of the same synthetic workload (%.2f s wall = %.0f core-seconds, scalar "
+                       "oracle on %d threads)" % (n_sample, dt, dt * cores, cores)), b, rs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--batch-reads", type=int, default=1_000_000, help="reads per step per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU-baseline sample (0: scale with cores)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import fade_amd
+    from fade_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    dev = torch.device("cuda", local)
+
+    cfg = synth.config(args.config)
+    genome = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    # per-GPU record range: each rank owns its own shard of the reads (seed 100 + rank)
+    batch = synth.make_reads(genome, args.batch_reads, 100 + rank, **cfg)
+    ctx = fade_amd.Context(device=local, max_batch_reads=max(args.batch_reads, 1 << 20))
+    ctx.genome_upload(genome.names, genome.ascii_contigs())
+    ctx.annotate_upload(0, batch)  # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.annotate_run(0, cfg["floor_len"], cfg["window"])
+    barrier()
+    fwd_ms, tb_ms, gate_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.annotate_run(0, cfg["floor_len"], cfg["window"])
+        if len(fwd_ms) < 4:  # HIP-event times of a few steps; reading them waits for the step anyway
+            p = ctx.last_profile(0)
+            fwd_ms.append(p["forward_ms"])
+            tb_ms.append(p["traceback_ms"])
+            gate_ms.append(p["gate_ms"])
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.last_profile(0)
+    rs, aln, stats = ctx.annotate_collect(0)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    st = torch.tensor(stats, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)  # RCCL: the final stats reduction
+    dt_max = float(t.item())
+    total_reads = args.batch_reads * world * args.steps
+
+    if rank == 0:
+        fwd = float(np.mean(fwd_ms))
+        achieved = prof["algorithmic_bytes"] / (fwd * 1e-3) / 1e9
+        out = {
+            "metric": "annotate reads/sec at 1/2/4/8 MI355X; rs/am tag bit-exact vs ref",
+            "value": total_reads / dt_max,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d x %d bp PE reads per GPU per step, -w %d, --min-length %d, p_softclip %.2f"
+                                   % (args.config, args.batch_reads, cfg["read_len"], cfg["window"], cfg["floor_len"],
+                                      cfg["p_sc"]),
+                       "alignments_per_step": int(prof["alignments"]), "dp_cells_per_step": int(prof["cells"])},
+            "roofline": {"bound": "hbm", "kernel": "sw_forward_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": int(prof["algorithmic_bytes"]),
+                         "kernel_ms": fwd, "gcups": prof["cells"] / (fwd * 1e-3) / 1e9},
+            "kernels_ms": {"gate": float(np.mean(gate_ms)), "sw_forward": fwd, "traceback": float(np.mean(tb_ms))},
+            "stats": {k: int(v) for k, v in zip(
+                ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"], st.tolist())},
+        }
+        if not args.no_cpu and world == 1:
+            cores = len(os.sched_getaffinity(0))
+            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(600_000, 2500 * cores)
+            cb, sb, srs = cpu_baseline(genome, cfg, n_sample, 1000 + rank)
+            cb["gpu_over_cpu"] = out["value"] / cb["value"]
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

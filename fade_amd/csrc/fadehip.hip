@@ -364,7 +364,6 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
     if (n == 0) return 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Slot &s = ctx->slots[0];
-    if (s.state == 2) return set_err(ctx, FADEHIP_E_STATE, "slot 0 holds uncollected annotate results");
     const int64_t q_total = q_off[n], r_total = r_off[n];
     // class-partitioned work lists, built on the host from the offsets (no sequence is touched here)
     std::vector<Work> lists[NUM_CLASSES];
@@ -640,7 +639,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         base += cnt;
     }
     s.n_aln = base;
-    hipLaunchKernelGGL(stats_kernel, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)s.rs.p, n,
+    hipLaunchKernelGGL(stats_kernel, dim3(std::min(128, (n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)s.rs.p, n,
                        (unsigned long long *)s.stats.p);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_end))) return rc;

@@ -124,79 +124,111 @@ struct GateArgs {
 
 __global__ void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_reads) return;
-    const uint32_t c0 = a.cigar_off[i], c1 = a.cigar_off[i + 1];
-    // anno.d:61: count S ops; util.d:37-62 parse_clips; dhtslib alignedLength (M,D,N,=,X)
-    int n_soft = 0;
-    uint32_t clipL = 0, clipR = 0;
-    int64_t aligned = 0;
-    bool first = true;
-    for (uint32_t k = c0; k < c1; k++) {
-        const uint32_t op = a.cigar_ops[k] & 15u, len = a.cigar_ops[k] >> 4;
-        if (op == 4) n_soft++;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) aligned += len;
-        if (op == 5) continue;
-        const bool is_sc = (op == 4);
-        if (first && !is_sc) first = false;
-        else if (first && is_sc) clipL = len;
-        else if (is_sc) clipR = len;
-    }
-    const uint32_t flag = a.flag[i];
-    uint8_t rs = 0;
-    if ((flag & 4u) || n_soft == 0) {  // anno.d:61-65
-        a.rs[i] = 0;
-        return;
-    }
-    if (clipL != 0 || clipR != 0) rs |= 1;  // anno.d:69-70
-    if (a.has_sa[i]) rs |= 32;               // anno.d:73-74
-    a.rs[i] = rs;
-    // analysis.d:34: only clips strictly longer than the floor are re-aligned
-    const bool want = ((int64_t)clipL > a.floor_len && clipL != 0) || ((int64_t)clipR > a.floor_len && clipR != 0);
-    if (!want) return;
-    const int32_t tid = a.tid[i];
-    const int32_t lq = a.l_seq[i];
-    if (tid < 0 || tid >= a.n_contigs) {
-        atomicOr(&a.counters[2 * NUM_CLASSES], 1u);  // mapped record without a valid contig
-        return;
-    }
-    if (lq <= 0) return;
-    // analysis.d:45-59
-    const int64_t pos = a.pos[i];
-    int64_t start = pos - a.window;
-    if (start < 0) start = 0;
-    int64_t end = pos + aligned + a.window;
-    if (end > a.contig_len[tid]) end = a.contig_len[tid];
-    const int64_t lr = end - start;
-    if (lr <= 0) return;
-    const int cls = class_of_len(lq);
-    if (cls < 0) {
-        atomicOr(&a.counters[2 * NUM_CLASSES], 2u);  // read longer than FADEHIP_MAX_QUERY
-        return;
-    }
-    if (lr > a.max_ref_len) {
-        atomicOr(&a.counters[2 * NUM_CLASSES], 4u);  // window longer than max_ref_len
-        return;
-    }
-    const uint32_t slot = atomicAdd(&a.counters[cls], 1u);
-    atomicMax(&a.counters[NUM_CLASSES + cls], (uint32_t)lr);
-    atomicAdd(&a.counters64[0], (unsigned long long)lq * (unsigned long long)lr);
-    atomicAdd(&a.counters64[1], (unsigned long long)((lq + 1) / 2 + (lr + 1) / 2));
+    // per-thread contribution to the batch counters; reduced per wave before touching memory
+    unsigned long long cells = 0, seq_bytes = 0;
+    uint32_t lr_for_max = 0, errbits = 0;
+    int cls = -1;
     Work w;
-    w.r_base = a.contig_base[tid] + (uint64_t)start;
-    w.q_base = a.seq_off[i] * 2u;
-    w.lq = (uint32_t)lq;
-    w.lr = (uint32_t)lr;
-    w.idx = (uint32_t)i;
-    w.flags = 1u;
-    w.pad = 0;
-    a.work[cls][slot] = w;
     Meta m;
-    m.win_start = start;
-    m.clip_left = (int32_t)clipL;
-    m.clip_right = (int32_t)clipR;
-    m.aligned_len = (int32_t)aligned;
-    m.pad[0] = m.pad[1] = m.pad[2] = 0;
-    a.meta[cls][slot] = m;
+    if (i < a.n_reads) {
+        const uint32_t c0 = a.cigar_off[i], c1 = a.cigar_off[i + 1];
+        // anno.d:61: count S ops; util.d:37-62 parse_clips; dhtslib alignedLength (M,D,N,=,X)
+        int n_soft = 0;
+        uint32_t clipL = 0, clipR = 0;
+        int64_t aligned = 0;
+        bool first = true;
+        for (uint32_t k = c0; k < c1; k++) {
+            const uint32_t op = a.cigar_ops[k] & 15u, len = a.cigar_ops[k] >> 4;
+            if (op == 4) n_soft++;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) aligned += len;
+            if (op == 5) continue;  // util.d:44-45 skips hard clips
+            const bool is_sc = (op == 4);
+            if (first && !is_sc) first = false;
+            else if (first && is_sc) clipL = len;
+            else if (is_sc) clipR = len;
+        }
+        const uint32_t flag = a.flag[i];
+        uint8_t rs = 0;
+        bool want = false;
+        if (!((flag & 4u) || n_soft == 0)) {          // anno.d:61-65
+            if (clipL != 0 || clipR != 0) rs |= 1;    // anno.d:69-70
+            if (a.has_sa[i]) rs |= 32;                // anno.d:73-74
+            // analysis.d:34: only clips strictly longer than the floor are re-aligned
+            want = (clipL != 0 && (int64_t)clipL > a.floor_len) || (clipR != 0 && (int64_t)clipR > a.floor_len);
+        }
+        a.rs[i] = rs;
+        const int32_t tid = a.tid[i];
+        const int32_t lq = a.l_seq[i];
+        if (want && (tid < 0 || tid >= a.n_contigs)) {
+            errbits |= 1u;  // mapped record without a valid contig
+            want = false;
+        }
+        if (want && lq > 0) {
+            // analysis.d:45-59
+            const int64_t pos = a.pos[i];
+            int64_t start = pos - a.window;
+            if (start < 0) start = 0;
+            int64_t end = pos + aligned + a.window;
+            if (end > a.contig_len[tid]) end = a.contig_len[tid];
+            const int64_t lr = end - start;
+            if (lr > 0) {
+                cls = class_of_len(lq);
+                if (cls < 0) errbits |= 2u;  // read longer than FADEHIP_MAX_QUERY
+                else if (lr > a.max_ref_len) { errbits |= 4u; cls = -1; }  // window longer than max_ref_len
+                else {
+                    cells = (unsigned long long)lq * (unsigned long long)lr;
+                    seq_bytes = (unsigned long long)((lq + 1) / 2 + (lr + 1) / 2);
+                    lr_for_max = (uint32_t)lr;
+                    w.r_base = a.contig_base[tid] + (uint64_t)start;
+                    w.q_base = a.seq_off[i] * 2u;
+                    w.lq = (uint32_t)lq;
+                    w.lr = (uint32_t)lr;
+                    w.idx = (uint32_t)i;
+                    w.flags = 1u;
+                    w.pad = 0;
+                    m.win_start = start;
+                    m.clip_left = (int32_t)clipL;
+                    m.clip_right = (int32_t)clipR;
+                    m.aligned_len = (int32_t)aligned;
+                    m.pad[0] = m.pad[1] = m.pad[2] = 0;
+                }
+            }
+        }
+    }
+    // wave-aggregated append: one atomic per wave and class reserves slots for all its lanes
+    // (a per-lane atomicAdd on one address costs ~12 ns each and dominated this kernel)
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < NUM_CLASSES; c++) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (mask == 0) continue;
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)mask) - 1;
+        if (lane == leader) base = atomicAdd(&a.counters[c], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (cls == c) {
+            const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            a.work[c][slot] = w;
+            a.meta[c][slot] = m;
+        }
+    }
+    // one atomic per wave and counter instead of one per qualifying read
+    for (int c = 0; c < NUM_CLASSES; c++) {
+        uint32_t v = (cls == c) ? lr_for_max : 0u;
+        if (__ballot(v != 0) == 0) continue;
+        for (int m = 32; m >= 1; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&a.counters[NUM_CLASSES + c], v);
+    }
+    if (__ballot(cells != 0)) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            cells += __shfl_xor(cells, m, 64);
+            seq_bytes += __shfl_xor(seq_bytes, m, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&a.counters64[0], cells);
+            atomicAdd(&a.counters64[1], seq_bytes);
+        }
+    }
+    if (errbits) atomicOr(&a.counters[2 * NUM_CLASSES], errbits);
 }
 
 // ---------------------------------------------------------------- forward SW with trace
@@ -506,7 +538,8 @@ __global__ void traceback_kernel(TbArgs a) {
 }
 
 // ---------------------------------------------------------------- stats.d:45-54 over rs
-__global__ void stats_kernel(const uint8_t *rs, int n, unsigned long long *counters) {
+__global__ __launch_bounds__(256) void stats_kernel(const uint8_t *rs, int n, unsigned long long *counters) {
+    __shared__ unsigned long long part[4][8];
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t v = rs[i];
@@ -525,7 +558,12 @@ __global__ void stats_kernel(const uint8_t *rs, int n, unsigned long long *count
     for (int k = 0; k < 8; k++) {
         unsigned long long v = c[k];
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[k], v);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (v) atomicAdd(&counters[threadIdx.x], v);
     }
 }
 

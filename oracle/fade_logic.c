@@ -311,3 +311,28 @@ int fo_annotate_batch(const fo_params *p, const fo_genome *g, const fo_read *rea
     free(args);
     return 0;
 }
+
+/* Same over the BAM-native structure-of-arrays batch layout of include/fadehip.h (plus quals). */
+int fo_annotate_batch_soa(const fo_params *p, const fo_genome *g, int n, const int32_t *tid, const int32_t *pos,
+                          const uint16_t *flag, const uint8_t *has_sa, const int32_t *l_seq,
+                          const uint32_t *cigar_off, const uint32_t *cigar_ops, const uint32_t *seq_off,
+                          const uint8_t *seq_packed, const int64_t *qual_off, const uint8_t *qual,
+                          int floor_len, int window, int threads, uint8_t *rs_out, char **am_out) {
+    fo_read *reads = (fo_read *)calloc((size_t)(n > 0 ? n : 1), sizeof(fo_read));
+    if (!reads) return -1;
+    for (int i = 0; i < n; i++) {
+        reads[i].qname = "r";
+        reads[i].flag = flag[i];
+        reads[i].tid = tid[i];
+        reads[i].pos = pos[i];
+        reads[i].n_cigar = (int)(cigar_off[i + 1] - cigar_off[i]);
+        reads[i].cigar = cigar_ops + cigar_off[i];
+        reads[i].l_seq = l_seq[i];
+        reads[i].seq4 = seq_packed + seq_off[i];
+        reads[i].qual = qual + qual_off[i];
+        reads[i].has_sa = has_sa[i];
+    }
+    int rc = fo_annotate_batch(p, g, reads, n, floor_len, window, threads, rs_out, am_out);
+    free(reads);
+    return rc;
+}

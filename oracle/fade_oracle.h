@@ -127,6 +127,13 @@ void fo_anno_free(fo_anno *a);
 int fo_annotate_batch(const fo_params *p, const fo_genome *g, const fo_read *reads, int n,
                       int floor_len, int window, int threads, uint8_t *rs_out, char **am_out);
 
+/* Same over the BAM-native structure-of-arrays batch layout of include/fadehip.h (plus quals). */
+int fo_annotate_batch_soa(const fo_params *p, const fo_genome *g, int n, const int32_t *tid, const int32_t *pos,
+                          const uint16_t *flag, const uint8_t *has_sa, const int32_t *l_seq,
+                          const uint32_t *cigar_off, const uint32_t *cigar_ops, const uint32_t *seq_off,
+                          const uint8_t *seq_packed, const int64_t *qual_off, const uint8_t *qual,
+                          int floor_len, int window, int threads, uint8_t *rs_out, char **am_out);
+
 /* stats.d:45-54 Stats.parse over an rs byte; counters[8] = read_count, clipped, sup, art_sup,
  * art, art_mate, aln_l, aln_r. */
 void fo_stats_parse(uint8_t rs, int64_t counters[8]);

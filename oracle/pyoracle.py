@@ -68,6 +68,9 @@ def lib():
         L.fo_annotate_batch.argtypes = [C.POINTER(Params), C.POINTER(Genome), C.POINTER(Read), C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fo_annotate_batch.restype = C.c_int
+        L.fo_annotate_batch_soa.argtypes = [C.POINTER(Params), C.POINTER(Genome), C.c_int] + [C.c_void_p] * 11 + \
+            [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fo_annotate_batch_soa.restype = C.c_int
         L.fo_reverse_complement_packed.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         L.fo_parse_clips.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
         L.fo_stats_parse.argtypes = [C.c_uint8, C.POINTER(C.c_int64)]
@@ -198,6 +201,37 @@ def annotate_batch(genome, reads, n, floor_len=5, window=300, threads=1, want_am
     am_ptrs = (C.c_void_p * n)() if want_am else None
     L.fo_annotate_batch(C.byref(p), C.byref(genome.c), reads, n, floor_len, window, threads, rs.ctypes.data,
                         C.cast(am_ptrs, C.c_void_p) if want_am else None)
+    am = None
+    if want_am:
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        am = []
+        for i in range(n):
+            if am_ptrs[i]:
+                am.append(C.string_at(am_ptrs[i]).decode())
+                libc.free(am_ptrs[i])
+            else:
+                am.append(None)
+    return rs, am
+
+
+def annotate_batch_soa(genome, batch, floor_len=5, window=300, threads=1, want_am=True, params=None):
+    """annotateTask over a whole SoA batch (dict of numpy arrays).  Returns (rs uint8[n], am list|None)."""
+    L = lib()
+    p = params or default_params()
+    n = len(batch["pos"])
+    a = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in
+         (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("has_sa", np.uint8), ("l_seq", np.int32),
+          ("cigar_off", np.uint32), ("cigar_ops", np.uint32), ("seq_off", np.uint32), ("seq_packed", np.uint8),
+          ("qual_off", np.int64), ("qual", np.uint8))}
+    rs = np.zeros(n, dtype=np.uint8)
+    am_ptrs = (C.c_void_p * n)() if want_am else None
+    rc = L.fo_annotate_batch_soa(C.byref(p), C.byref(genome.c), n, *[a[k].ctypes.data for k in
+                                 ("tid", "pos", "flag", "has_sa", "l_seq", "cigar_off", "cigar_ops", "seq_off",
+                                  "seq_packed", "qual_off", "qual")], floor_len, window, threads, rs.ctypes.data,
+                                 C.cast(am_ptrs, C.c_void_p) if want_am else None)
+    if rc != 0:
+        raise RuntimeError("oracle annotate_batch_soa failed rc=%d" % rc)
     am = None
     if want_am:
         libc = C.CDLL(None)

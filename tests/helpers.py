@@ -42,7 +42,8 @@ def make_pairs(rng, n, lq_range=(20, 260), lr_range=(30, 900), kinds=("random", 
         elif kind == "planted":
             r = rand_seq(rng, lr)
             q = rand_seq(rng, lq)
-            L = int(rng.integers(4, min(lq, lr, 60) + 1))
+            hi = min(lq, lr, 60)
+            L = int(rng.integers(min(4, hi), hi + 1))
             s = int(rng.integers(0, lr - L + 1))
             if rng.random() < 0.5:
                 q[lq - L:] = r[s:s + L]
