@@ -1,0 +1,114 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/fadehip.h declares;
+host-side packing / formatting logic; no compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "fadehip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fadehip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from fade_amd import _lib
+    L = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 16
+    for name in declared:
+        assert hasattr(L, name), "libfadehip.so lacks %s" % name
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.fadehip_abi_version() == 1
+    p = _lib.Params()
+    L.fadehip_params_default(ctypes.byref(p))
+    assert (p.open, p.ext, p.match, p.mismatch) == (10, 2, 2, -3)  # anno.d:36
+
+
+def test_struct_layouts_match_header():
+    from fade_amd import _lib
+    assert ctypes.sizeof(_lib.SwResult) == 24 + 4 * 16
+    assert ctypes.sizeof(_lib.Aln) == 32 + ctypes.sizeof(_lib.SwResult)
+    assert _lib.ALN_DTYPE.fields["sw"][1] == 32
+
+
+def test_create_fails_loudly_without_gpu():
+    """There is no CPU fallback: without a gfx950 device the product path refuses to start."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import fade_amd
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        fade_amd.Context(device=0)
+    assert e.value.code in (-2, -3)
+
+
+def test_product_path_does_not_touch_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fade_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in txt and "fade_oracle" not in txt and "libfadeoracle" not in txt, f
+
+
+def test_synth_is_deterministic_and_well_formed():
+    from fade_amd import synth
+    cfg, g, b = synth.make_config("C2", 5000, contig_len=120_000)
+    _, _, b2 = synth.make_config("C2", 5000, contig_len=120_000)
+    for k in ("pos", "flag", "cigar_ops", "seq_packed", "qual"):
+        assert np.array_equal(b[k], b2[k])
+    n = len(b["pos"])
+    assert b["cigar_off"][-1] == len(b["cigar_ops"])
+    mapped = (b["flag"] & 4) == 0
+    # query-consuming ops add up to l_seq
+    for i in np.nonzero(mapped)[0][:500]:
+        ops = b["cigar_ops"][b["cigar_off"][i]:b["cigar_off"][i + 1]]
+        assert sum(int(o) >> 4 for o in ops if (int(o) & 15) in (0, 1, 4, 7, 8)) == int(b["l_seq"][i])
+    frac = ((b["cigar_off"][1:] - b["cigar_off"][:-1]) > 1).mean()
+    assert 0.07 < frac < 0.13  # p_sc = 0.10
+    sub = synth.take(b, np.array([3, 10, 11]))
+    assert np.array_equal(sub["pos"], b["pos"][[3, 10, 11]])
+    assert np.array_equal(sub["seq_packed"][:75], b["seq_packed"][3 * 75:4 * 75])
+
+
+def test_format_tags_against_oracle_strings(oracle):
+    """fade_amd.format_tags (analysis.d:84-92,108-118) fed with the oracle's own alignment must give
+    the oracle's am/as/ar/ab — host formatting logic checked without a GPU."""
+    from fade_amd import format_tags, synth
+    from fade_amd._lib import ALN_DTYPE
+    cfg, g, b = synth.make_config("C2", 3000, contig_len=150_000)
+    G = oracle.GenomeHolder(g.names, [a.tobytes() for a in g.ascii_contigs()])
+    reads, keep = oracle.make_reads(b)
+    contigs = [a.tobytes() for a in g.ascii_contigs()]
+    aln, rs_all, exp = [], np.zeros(len(b["pos"]), np.uint8), {}
+    for i in range(len(b["pos"])):
+        a = oracle.annotate_one(G, reads[i], cfg["floor_len"], cfg["window"])
+        rs_all[i] = a["rs"]
+        if not a["has_tags"]:
+            continue
+        exp[i] = dict(rs=a["rs"], am=a["am"], as_=a["as_"], ar=a["ar"], ab=a["ab"])
+        # rebuild the alignment record the device would return, from the oracle's SW
+        ops = b["cigar_ops"][b["cigar_off"][i]:b["cigar_off"][i + 1]]
+        cl, cr = oracle.parse_clips([int(o) for o in ops])
+        al = sum(int(o) >> 4 for o in ops if (int(o) & 15) in (0, 2, 3, 7, 8))
+        pos, tid = int(b["pos"][i]), int(b["tid"][i])
+        start = max(pos - cfg["window"], 0)
+        end = min(pos + al + cfg["window"], len(contigs[tid]))
+        q = oracle.reverse_complement_packed(b["seq_packed"][b["seq_off"][i]:b["seq_off"][i + 1]], int(b["l_seq"][i]))
+        r = oracle.sw(q, contigs[tid][start:end])
+        rec = np.zeros(1, dtype=ALN_DTYPE)[0]
+        rec["read_idx"], rec["art"], rec["win_start"], rec["win_len"] = i, (a["rs"] >> 1) & 3, start, end - start
+        rec["clip_left"], rec["clip_right"], rec["aligned_len"] = cl >> 4, cr >> 4, al
+        for k in ("score", "end_query", "end_ref", "beg_query", "beg_ref", "n_ops"):
+            rec["sw"][k] = r[k]
+        rec["sw"]["ops"][:len(r["ops"])] = r["ops"]
+        aln.append(rec)
+    got = format_tags(b, g.names, rs_all, np.array(aln, dtype=ALN_DTYPE))
+    assert len(exp) > 50 and got == exp
