@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,6 +57,7 @@ struct fadehip_ctx {
     std::vector<int64_t> h_contig_len;
     std::vector<uint64_t> h_contig_base;
     int cu_count = 0;
+    bool use_packed = true;  // FADEHIP_KERNEL=int32 selects the unpacked reference kernel (A/B runs)
 };
 
 namespace {
@@ -153,17 +155,20 @@ int record(fadehip_ctx *ctx, Slot &s, int *idx) {
 }
 
 template <int C>
-int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size_t lds, hipStream_t st) {
+int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size_t lds, hipStream_t st, bool packed) {
     if constexpr (C >= NUM_CLASSES) {
         return set_err(ctx, FADEHIP_E_INVALID, "bad class %d", cls);
     } else {
         if (cls == C) {
             constexpr int R = class_rows(C);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward_kernel<R>), dim3(quads), dim3(64), lds, st, a);
+            if (packed)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward_pk_kernel<R>), dim3(quads), dim3(64), lds, st, a);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward_kernel<R>), dim3(quads), dim3(64), lds, st, a);
             HIPCHK(ctx, hipGetLastError());
             return 0;
         }
-        return launch_forward_c<C + 1>(ctx, cls, a, quads, lds, st);
+        return launch_forward_c<C + 1>(ctx, cls, a, quads, lds, st, packed);
     }
 }
 
@@ -172,15 +177,18 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
               int max_lr, const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out, uint8_t *rs, int floor_len,
               int gate, int64_t trace_budget, bool timed) {
     const int R = class_rows(cls);
+    const bool packed = ctx->use_packed;
+    const int per_wave = packed ? 8 : 4;  // alignments per wavefront
     const int n_blocks = (max_lr + 15 + 3) / 4;
-    const uint64_t quad_stride = (uint64_t)n_blocks * (R / 2) * 64;  // dwords
-    const int ref_stride = ((n_blocks * 4 + 15) / 16) * 16;
+    // dwords of trace per wave: 4 bits per cell slot either way
+    const uint64_t quad_stride = (uint64_t)n_blocks * (packed ? R : R / 2) * 64;
+    const int ref_stride = (((n_blocks * 4) * (packed ? 2 : 1) + 15) / 16) * 16;
     const size_t lds = (size_t)ref_stride * 4;
     if (lds > 64 * 1024)
         return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, lds);
     const int64_t quad_bytes = (int64_t)quad_stride * 4;
     int64_t max_quads = std::max<int64_t>(1, trace_budget / quad_bytes);
-    const int total_quads = (n_items + 3) / 4;
+    const int total_quads = (n_items + per_wave - 1) / per_wave;
     const int64_t chunk_quads = std::min<int64_t>(max_quads, total_quads);
     int rc = reserve(ctx, s.trace, (size_t)(chunk_quads * quad_bytes));
     if (rc) return rc;
@@ -188,8 +196,8 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
     if (rc) return rc;
     for (int64_t q0 = 0; q0 < total_quads; q0 += chunk_quads) {
         const int quads = (int)std::min<int64_t>(chunk_quads, total_quads - q0);
-        const int i0 = (int)(q0 * 4);
-        const int n = std::min(n_items - i0, quads * 4);
+        const int i0 = (int)(q0 * per_wave);
+        const int n = std::min(n_items - i0, quads * per_wave);
         SwArgs a;
         a.work = work + i0;
         a.n_items = n;
@@ -202,7 +210,7 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         a.sc = ctx->sc;
         int e0 = -1, e1 = -1, e2 = -1;
         if (timed && (rc = record(ctx, s, &e0))) return rc;
-        rc = launch_forward_c<0>(ctx, cls, a, quads, lds, st);
+        rc = launch_forward_c<0>(ctx, cls, a, quads, lds, st, packed);
         if (rc) return rc;
         if (timed && (rc = record(ctx, s, &e1))) return rc;
         TbArgs t;
@@ -220,6 +228,7 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         t.rs = rs;
         t.floor_len = floor_len;
         t.gate = gate;
+        t.packed = packed ? 1 : 0;
         hipLaunchKernelGGL(traceback_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t);
         HIPCHK(ctx, hipGetLastError());
         if (timed) {
@@ -298,6 +307,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         return fail(FADEHIP_E_NODEVICE);
     }
     ctx->cu_count = prop.multiProcessorCount;
+    if (const char *kv = getenv("FADEHIP_KERNEL")) ctx->use_packed = strcmp(kv, "int32") != 0;
     uint8_t table[256];
     fill_ascii_table(table);
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_ascii_code), table, 256) != hipSuccess) {

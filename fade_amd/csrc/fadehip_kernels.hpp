@@ -383,6 +383,203 @@ __global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- forward SW, packed int16 (two alignments per 16-lane row)
+// Same recurrence as sw_forward_kernel with every DP value scaled by 8 and held as a pair of int16:
+// low half = alignment A, high half = alignment B of the same 16-lane row, so one v_pk_* instruction
+// advances two cells.  The scale makes every positive difference >= 8, which turns the four trace
+// flags into v_pk_min_u16(diff, weight) with weights 8,4,2,1 — a nibble per cell by plain addition.
+// One wave = 8 alignments ("octet").  Trace: [block of 4 steps][R dwords][64 lanes], each dword =
+// 4 cell-pairs, nibble (3 - p%4) of the low / high half for alignment A / B, p = s*R + r.
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v as_s2(uint32_t x) { return __builtin_bit_cast(s2v, x); }
+__device__ __forceinline__ u2v as_u2(uint32_t x) { return __builtin_bit_cast(u2v, x); }
+__device__ __forceinline__ uint32_t as_u32(s2v x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t as_u32(u2v x) { return __builtin_bit_cast(uint32_t, x); }
+// flag arithmetic goes through asm so that hipcc keeps it packed (it otherwise rewrites min(x-y,1)
+// into per-half compares + selects)
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ uint32_t pk_min_k(uint32_t a) {
+    uint32_t d;
+    asm("v_pk_min_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "n"(K));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_shl4_add(uint32_t acc, uint32_t m) {
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, 16, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(acc), "v"(m));
+    return d;
+}
+
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b) {  // (a << SH) + b in one VALU op
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) {  // (a & mask) | c
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    return d;
+}
+
+constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and log2(8) + 16
+
+template <int R>
+__global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, lig = lane & 15;
+    const int oct = blockIdx.x;
+    const int itemA = oct * 8 + g * 2, itemB = itemA + 1;
+    Work wa, wb;
+    wa.r_base = wb.r_base = 0; wa.q_base = wb.q_base = 0; wa.lq = wb.lq = 0; wa.lr = wb.lr = 0;
+    wa.idx = wb.idx = 0; wa.flags = wb.flags = 0; wa.pad = wb.pad = 0;
+    if (itemA < a.n_items) wa = a.work[itemA];
+    if (itemB < a.n_items) wb = a.work[itemB];
+    const int lqA = (int)wa.lq, lrA = (int)wa.lr, lqB = (int)wb.lq, lrB = (int)wb.lr;
+    int mx = max(lrA, lrB);
+    int maxlr = __builtin_amdgcn_readlane(mx, 0);
+    maxlr = max(maxlr, __builtin_amdgcn_readlane(mx, 16));
+    maxlr = max(maxlr, __builtin_amdgcn_readlane(mx, 32));
+    maxlr = max(maxlr, __builtin_amdgcn_readlane(mx, 48));
+    const int n_blocks = (maxlr + 15 + 3) >> 2;
+
+    // ---- stage both windows: 16 bits per column = classA*4 | classB*4 << 8
+    uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
+    const int n_cols = n_blocks * 4;
+    for (int k = lig; k < n_cols; k += 16) {
+        uint32_t ca = PAD_CLASS * 4, cb = PAD_CLASS * 4;
+        if (k < lrA) ca = lut4(CLASS_LUT, nib_at(a.r_nib, wa.r_base + (uint64_t)k)) * 4u;
+        if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k)) * 4u;
+        lref[k] = (uint16_t)(ca | (cb << 8));
+    }
+    uint32_t profA[R], profB[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = lig * R + r;
+        uint32_t pa = a.sc.prof[PAD_CLASS], pb = a.sc.prof[PAD_CLASS];
+        if (row < lqA) {
+            uint32_t code;
+            if (wa.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)wa.q_base + (uint32_t)(lqA - 1 - row)));
+            else code = nib_at(a.q_nib, (uint64_t)wa.q_base + (uint32_t)row);
+            pa = a.sc.prof[lut4(CLASS_LUT, code)];
+        }
+        if (row < lqB) {
+            uint32_t code;
+            if (wb.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)(lqB - 1 - row)));
+            else code = nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)row);
+            pb = a.sc.prof[lut4(CLASS_LUT, code)];
+        }
+        profA[r] = pa;
+        profB[r] = pb;
+    }
+    __syncthreads();
+
+    uint32_t Hl[R], Eh[R], bestA[R], bestB[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; bestA[r] = 0; bestB[r] = 0; }
+    uint32_t hu_out = 0, fu_out = 0, hu_prev = 0;
+    uint32_t rc = (PAD_CLASS * 4) | (PAD_CLASS * 4 << 8);
+    const uint32_t ext8 = (uint32_t)(a.sc.ext * PK_SCALE) * 0x10001u;
+    const uint32_t open8 = (uint32_t)(a.sc.open * PK_SCALE) * 0x10001u;
+    uint32_t *tq = a.trace + (uint64_t)oct * a.quad_stride + lane;
+    const uint32_t himask = __builtin_amdgcn_readfirstlane(0xffff0000u);
+
+    for (int blk = 0; blk < n_blocks; blk++) {
+        const uint64_t rw = *reinterpret_cast<const uint64_t *>(lref + blk * 4);
+        uint32_t acc[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) acc[k] = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int t = blk * 4 + s;
+            const uint32_t fresh = (uint32_t)(rw >> (16 * s)) & 0xffffu;
+            rc = (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)rc, DPP_ROW_SHR1, 0xf, 0xf, false);
+            uint32_t hu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
+            uint32_t fu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
+            const uint32_t rcB = rc >> 8;
+            const uint32_t ct = (uint32_t)(0xffff - t);
+            uint32_t hd = hu_prev;
+            hu_prev = hu;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t wA = __builtin_amdgcn_ubfe(profA[r], rc, 4);
+                const uint32_t wB = __builtin_amdgcn_ubfe(profB[r], rcB, 4);
+                // Dp = hd + 8*W' per half (no carry: each half stays below 2^15)
+                const uint32_t Dp = lshl_add<19>(wB, lshl_add<3>(wA, hd));
+                const uint32_t hl = Hl[r];
+                const uint32_t Ee = as_u32(as_s2(Eh[r]) - as_s2(ext8));
+                const uint32_t En = as_u32(__builtin_elementwise_max(as_s2(hl), as_s2(Ee)));
+                const uint32_t Fe = as_u32(as_s2(fu) - as_s2(ext8));
+                const uint32_t Fn = as_u32(__builtin_elementwise_max(as_s2(hu), as_s2(Fe)));
+                const uint32_t T = as_u32(__builtin_elementwise_max(__builtin_elementwise_max(as_s2(Dp), as_s2(En)), as_s2(Fn)));
+                const uint32_t H = as_u32(__builtin_elementwise_sub_sat(as_u2(T), as_u2(open8)));
+                // trace nibble: 8*(H!=D) + 4*(H!=F) + 2*(E opened) + 1*(F opened)
+                const uint32_t m1 = pk_min_k<8>(pk_sub(T, Dp));
+                const uint32_t m2 = pk_min_k<4>(pk_sub(T, Fn));
+                const uint32_t m3 = pk_min_k<2>(pk_sub(En, Ee));
+                const uint32_t m4 = pk_min_k<1>(pk_sub(Fn, Fe));
+                uint32_t &ac = acc[(s * R + r) >> 2];
+                ac = pk_shl4_add(ac, m1) + m2 + m3 + m4;
+                // end-cell keys: (H, 0xffff - t) per alignment
+                bestA[r] = max(bestA[r], (H << 16) | ct);
+                bestB[r] = max(bestB[r], and_or(H, himask, ct));
+                hd = hl;
+                Hl[r] = H;
+                Eh[r] = En;
+                hu = H;
+                fu = Fn;
+            }
+            hu_out = hu;
+            fu_out = fu;
+        }
+        uint32_t *tp = tq + (uint64_t)blk * (R * 64);
+#pragma unroll
+        for (int k = 0; k < R; k++) tp[k * 64] = acc[k];
+    }
+
+    // ---- end cells (Appendix A.3) for A and B
+    uint32_t bka = 0, bkb = 0;
+    int browa = 0, browb = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = lig * R + r;
+        if (row < lqA && bestA[r] > bka) { bka = bestA[r]; browa = row; }
+        if (row < lqB && bestB[r] > bkb) { bkb = bestB[r]; browb = row; }
+    }
+    uint64_t ca = (bka >> 16) ? ((((uint64_t)(bka + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browa)) : 0ull;
+    uint64_t cb = (bkb >> 16) ? ((((uint64_t)(bkb + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browb)) : 0ull;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const uint64_t oa = __shfl_xor(ca, m, 64), ob = __shfl_xor(cb, m, 64);
+        ca = oa > ca ? oa : ca;
+        cb = ob > cb ? ob : cb;
+    }
+    if (lig == 0) {
+        if (itemA < a.n_items) {
+            Fwd f;
+            f.score = (int32_t)(ca >> 32) / PK_SCALE;
+            f.end_r = ca ? (int32_t)(0xffff - ((ca >> 16) & 0xffff)) : 0;
+            f.end_q = ca ? (int32_t)(0xffff - (ca & 0xffff)) : 0;
+            f.pad = 0;
+            a.fwd[itemA] = f;
+        }
+        if (itemB < a.n_items) {
+            Fwd f;
+            f.score = (int32_t)(cb >> 32) / PK_SCALE;
+            f.end_r = cb ? (int32_t)(0xffff - ((cb >> 16) & 0xffff)) : 0;
+            f.end_q = cb ? (int32_t)(0xffff - (cb & 0xffff)) : 0;
+            f.pad = 0;
+            a.fwd[itemB] = f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- traceback + artifact gates
 struct TbArgs {
     const Work *work;
@@ -398,6 +595,7 @@ struct TbArgs {
     uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
+    int32_t packed;         // trace written by sw_forward_pk_kernel (octets) instead of sw_forward_kernel (quads)
 };
 
 __device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int g, int i, int j) {
@@ -408,13 +606,23 @@ __device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int 
     return (wv >> (28 - (k0 & 31))) & 15u;
 }
 
+__device__ __forceinline__ uint32_t trace_nibble_pk(const uint32_t *to, int R, int g, int half, int i, int j) {
+    const int lig = i / R, r = i - lig * R;
+    const int t = j + lig;
+    const int p = (t & 3) * R + r;
+    const uint32_t wv = to[((uint64_t)(t >> 2) * R + (p >> 2)) * 64 + (g * 16 + lig)];
+    return (wv >> (16 * half + 4 * (3 - (p & 3)))) & 15u;
+}
+
 __global__ void traceback_kernel(TbArgs a) {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= a.n_items) return;
     const Work w = a.work[item];
     const Fwd f = a.fwd[item];
-    const int R = a.R, g = item & 3;
-    const uint32_t *tq = a.trace + (uint64_t)(item >> 2) * a.quad_stride;
+    const int R = a.R;
+    const int g = a.packed ? ((item >> 1) & 3) : (item & 3);
+    const int half = item & 1;
+    const uint32_t *tq = a.trace + (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
     const int lq = (int)w.lq;
     const bool rcq = w.flags & 1u;
     const int32_t open = a.sc.open, ext = a.sc.ext;
@@ -429,7 +637,7 @@ __global__ void traceback_kernel(TbArgs a) {
     int i = f.end_q, j = f.end_r, state = 0;
     int32_t h = f.score;
     while (i >= 0 && j >= 0) {
-        const uint32_t nb = trace_nibble(tq, R, g, i, j);
+        const uint32_t nb = a.packed ? trace_nibble_pk(tq, R, g, half, i, j) : trace_nibble(tq, R, g, i, j);
         int op;
         if (state == 0) {
             if (h == 0) break;
