@@ -624,7 +624,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     }
     g.counters = (uint32_t *)s.counters.p;
     g.counters64 = (unsigned long long *)s.counters64.p;
-    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gate_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, g);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(s.h_counters, s.counters.p, sizeof(uint32_t) * (2 * NUM_CLASSES + 1), hipMemcpyDeviceToHost, st));

@@ -122,7 +122,8 @@ struct GateArgs {
     unsigned long long *counters64;  // [0] DP cells, [1] packed sequence bytes read (query + window)
 };
 
-__global__ void gate_kernel(GateArgs a) {
+constexpr int GATE_BLOCK = 1024;
+__global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // per-thread contribution to the batch counters; reduced per wave before touching memory
     unsigned long long cells = 0, seq_bytes = 0;
@@ -195,40 +196,48 @@ __global__ void gate_kernel(GateArgs a) {
             }
         }
     }
-    // wave-aggregated append: one atomic per wave and class reserves slots for all its lanes
-    // (a per-lane atomicAdd on one address costs ~12 ns each and dominated this kernel)
-    const int lane = threadIdx.x & 63;
-    for (int c = 0; c < NUM_CLASSES; c++) {
-        const unsigned long long mask = __ballot(cls == c);
-        if (mask == 0) continue;
-        uint32_t base = 0;
-        const int leader = __ffsll((long long)mask) - 1;
-        if (lane == leader) base = atomicAdd(&a.counters[c], (uint32_t)__popcll(mask));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (cls == c) {
-            const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            a.work[c][slot] = w;
-            a.meta[c][slot] = m;
-        }
-    }
-    // one atomic per wave and counter instead of one per qualifying read
-    for (int c = 0; c < NUM_CLASSES; c++) {
-        uint32_t v = (cls == c) ? lr_for_max : 0u;
-        if (__ballot(v != 0) == 0) continue;
-        for (int m = 32; m >= 1; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(&a.counters[NUM_CLASSES + c], v);
+    // block-aggregated append: slots are first reserved in LDS, then one global atomic per block and
+    // class (per-lane or even per-wave atomics on one address serialise at ~12 ns each and dominated
+    // this kernel)
+    __shared__ uint32_t s_cnt[NUM_CLASSES], s_base[NUM_CLASSES], s_maxlr[NUM_CLASSES], s_err;
+    __shared__ unsigned long long s_cells, s_bytes;
+    if (threadIdx.x < NUM_CLASSES) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; }
+    __syncthreads();
+    uint32_t local_slot = 0;
+    if (cls >= 0) {
+        local_slot = atomicAdd(&s_cnt[cls], 1u);
+        atomicMax(&s_maxlr[cls], lr_for_max);
     }
     if (__ballot(cells != 0)) {
-        for (int m = 32; m >= 1; m >>= 1) {
-            cells += __shfl_xor(cells, m, 64);
-            seq_bytes += __shfl_xor(seq_bytes, m, 64);
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            cells += __shfl_xor(cells, sh, 64);
+            seq_bytes += __shfl_xor(seq_bytes, sh, 64);
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&a.counters64[0], cells);
-            atomicAdd(&a.counters64[1], seq_bytes);
+            atomicAdd(&s_cells, cells);
+            atomicAdd(&s_bytes, seq_bytes);
         }
     }
-    if (errbits) atomicOr(&a.counters[2 * NUM_CLASSES], errbits);
+    if (errbits) atomicOr(&s_err, errbits);
+    __syncthreads();
+    if (threadIdx.x < NUM_CLASSES && s_cnt[threadIdx.x]) {
+        s_base[threadIdx.x] = atomicAdd(&a.counters[threadIdx.x], s_cnt[threadIdx.x]);
+        atomicMax(&a.counters[NUM_CLASSES + threadIdx.x], s_maxlr[threadIdx.x]);
+    }
+    if (threadIdx.x == 0) {
+        if (s_cells) {
+            atomicAdd(&a.counters64[0], s_cells);
+            atomicAdd(&a.counters64[1], s_bytes);
+        }
+        if (s_err) atomicOr(&a.counters[2 * NUM_CLASSES], s_err);
+    }
+    __syncthreads();
+    if (cls >= 0) {
+        const uint32_t slot = s_base[cls] + local_slot;
+        a.work[cls][slot] = w;
+        a.meta[cls][slot] = m;
+    }
 }
 
 // ---------------------------------------------------------------- forward SW with trace

@@ -1,0 +1,390 @@
+// fade_main.cpp — `fade annotate` host driver over the fadehip C ABI.
+//
+// Mirrors the CLI surface of the reference:
+//   source/app.d:64-101   main, getopt(annotate): -t/--threads, --min-length, -w/--window-size, -b/--bam, -u/--ubam,
+//                         -h/--help; `-b -u` together is an error (exit 1); < 3 args or -h prints help (exit 0)
+//   source/anno.d:16-52   annotate(): warning line, open BAM/SAM + FASTA, @PG header line, per-record
+//                         annotateTask, write to stdout as SAM / uBAM / BAM (source/util.d:65-76)
+//   source/anno.d:94-107  tag order rs, am, as, ar, ab;  analysis.d:84-92,108-118 string contents
+// The loop at anno.d:44-50 becomes read-chunk -> pack (pointers into the BAM bytes) -> fadehip_annotate_*
+// -> format tags -> write, pipelined over two device slots.  Additive flags: --gpus N, --batch N, --stats.
+// There is no CPU alignment path in this program.
+#include <memory>
+#include "hts_lite.hpp"
+#include "../../../include/fadehip.h"
+
+#include <chrono>
+#include <cstdlib>
+#include <deque>
+#include <iostream>
+
+#ifndef FADE_VERSION
+#define FADE_VERSION "v0.5.0-mi355x"
+#endif
+
+using namespace htsl;
+
+static const char *kHeader = "Fragmentase Artifact Detection and Elimination\nversion: " FADE_VERSION "\n";
+
+static void print_full_help() {
+    fprintf(stderr,
+            "%s\nusage: fade [subcommand]\n"
+            "    annotate: marks artifact reads in bam tags (must be done first)\n"
+            "    out: eliminates artifact from reads(may require queryname sorted bam)\n"
+            "    stats: reports extended information about artifact reads\n"
+            "    stats-clip: reports extended information about all soft-clipped reads\n"
+            "    extract: extracts artifacts into a mapped bam\n\n"
+            "-h --help This help information.\n\n",
+            kHeader);
+}
+
+static void print_anno_help() {
+    fprintf(stderr,
+            "%s\nannotate: performs re-alignment of soft-clips and annotates bam records with bitflag (rs) and "
+            "realignment tags (am)\nusage: fade annotate [options] <input BAM/SAM> <Indexed fasta reference>\n\n"
+            "-t     --threads extra threads for parsing the bam file\n"
+            "    --min-length Minimum number of bases for a soft-clip to be considered for artifact detection\n"
+            "-w --window-size Number of bases considered outside of read or mate region for re-alignment\n"
+            "-b         --bam output bam\n"
+            "-u        --ubam output uncompressed bam\n"
+            "          --gpus number of MI355X devices to shard batches over (default 1)\n"
+            "         --batch records per device batch (default 262144)\n"
+            "         --stats print the stats.d summary of this run to stderr\n"
+            "-h        --help This help information.\n\n",
+            kHeader);
+}
+
+struct Opts {
+    int threads = 0, floor_len = 5, window = 300, gpus = 1, batch = 262144;
+    bool bam = false, ubam = false, help = false, stats = false;
+    std::vector<std::string> pos;
+};
+
+// std.getopt with config.bundling: short flags bundle (-bu), values attach (-w100, -w 100, --window-size=100)
+static bool parse_opts(int argc, char **argv, Opts &o, std::string &err) {
+    auto need_int = [&](const std::string &name, const char *v, int &dst) {
+        char *e = nullptr;
+        long x = strtol(v, &e, 10);
+        if (!v[0] || *e) { err = "Invalid value for option " + name + ": " + v; return false; }
+        dst = (int)x;
+        return true;
+    };
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "--") { for (int k = i + 1; k < argc; k++) o.pos.push_back(argv[k]); break; }
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            std::string name = a.substr(2), val;
+            bool has_val = false;
+            size_t eq = name.find('=');
+            if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+            auto take = [&](int &dst) {
+                if (!has_val) {
+                    if (i + 1 >= argc) { err = "Missing value for argument --" + name; return false; }
+                    val = argv[++i];
+                }
+                return need_int("--" + name, val.c_str(), dst);
+            };
+            if (name == "threads") { if (!take(o.threads)) return false; }
+            else if (name == "min-length") { if (!take(o.floor_len)) return false; }
+            else if (name == "window-size") { if (!take(o.window)) return false; }
+            else if (name == "gpus") { if (!take(o.gpus)) return false; }
+            else if (name == "batch") { if (!take(o.batch)) return false; }
+            else if (name == "bam") o.bam = true;
+            else if (name == "ubam") o.ubam = true;
+            else if (name == "stats") o.stats = true;
+            else if (name == "help") o.help = true;
+            else { err = "Unrecognized option --" + name; return false; }
+        } else if (a.size() > 1 && a[0] == '-' && a != "-") {
+            for (size_t k = 1; k < a.size(); k++) {
+                const char c = a[k];
+                if (c == 'b') o.bam = true;
+                else if (c == 'u') o.ubam = true;
+                else if (c == 'h') o.help = true;
+                else if (c == 't' || c == 'w') {
+                    std::string val = a.substr(k + 1);
+                    if (!val.empty() && val[0] == '=') val = val.substr(1);
+                    if (val.empty()) {
+                        if (i + 1 >= argc) { err = std::string("Missing value for argument -") + c; return false; }
+                        val = argv[++i];
+                    }
+                    if (!need_int(std::string("-") + c, val.c_str(), c == 't' ? o.threads : o.window)) return false;
+                    break;
+                } else { err = std::string("Unrecognized option -") + c; return false; }
+            }
+        } else o.pos.push_back(a);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ one batch in flight
+struct Chunk {
+    std::vector<Rec> recs;
+    // SoA views handed to the device
+    std::vector<int32_t> tid, pos, l_seq;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> has_sa, seq, rs;
+    std::vector<uint32_t> cigar_off, cigar_ops, seq_off;
+    std::vector<fadehip_aln> aln;
+    fadehip_anno_out out;
+    int dev = 0, slot = 0;
+};
+
+static void pack_chunk(Chunk &c, Pool &pool) {
+    const size_t n = c.recs.size();
+    c.tid.resize(n); c.pos.resize(n); c.l_seq.resize(n); c.flag.resize(n); c.has_sa.resize(n);
+    c.cigar_off.resize(n + 1); c.seq_off.resize(n + 1);
+    size_t nc = 0, ns = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Rec &r = c.recs[i];
+        c.cigar_off[i] = (uint32_t)nc;
+        c.seq_off[i] = (uint32_t)ns;
+        nc += (size_t)r.n_cigar();
+        ns += ((size_t)r.l_seq() + 1) / 2;
+    }
+    c.cigar_off[n] = (uint32_t)nc;
+    c.seq_off[n] = (uint32_t)ns;
+    c.cigar_ops.resize(nc ? nc : 1);
+    c.seq.resize(ns ? ns : 1);
+    const size_t nt = (size_t)pool.size();
+    pool.parallel_for(nt, [&](size_t t) {
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+            const Rec &r = c.recs[i];
+            c.tid[i] = r.tid();
+            c.pos[i] = r.pos();
+            c.l_seq[i] = r.l_seq();
+            c.flag[i] = (uint16_t)r.flag();
+            c.has_sa[i] = r.aux_exists("SA") ? 1 : 0;  // anno.d:73
+            if (r.n_cigar()) memcpy(&c.cigar_ops[c.cigar_off[i]], r.cigar_bytes(), 4 * (size_t)r.n_cigar());
+            if (r.l_seq()) memcpy(&c.seq[c.seq_off[i]], r.seq(), ((size_t)r.l_seq() + 1) / 2);
+        }
+    });
+    c.rs.assign(n ? n : 1, 0);
+    c.aln.resize(n ? n : 1);
+}
+
+static std::string cigar_string(const uint32_t *ops, int n) {
+    std::string s;
+    for (int k = 0; k < n; k++) {
+        append_int(s, ops[k] >> 4);
+        s += CIGAR_STR[std::min<uint32_t>(ops[k] & 15, 9)];
+    }
+    return s;
+}
+
+// analysis.d:84-92 / 108-118 + anno.d:94-107
+static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
+    const size_t n = c.recs.size();
+    static const uint8_t comp[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};  // util.d:18-20
+    // artifact strings first (few), then rs for everyone, keeping the reference's tag order rs, am, as, ar, ab
+    std::vector<int> art_of(n, -1);
+    for (int k = 0; k < c.out.n_aln; k++)
+        if (c.aln[k].art) art_of[(size_t)c.aln[k].read_idx] = k;
+    const size_t nt = (size_t)pool.size();
+    pool.parallel_for(nt, [&](size_t t) {
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+            Rec &r = c.recs[i];
+            r.aux_update_uint("rs", c.rs[i]);  // anno.d:63,94
+            const int k = art_of[i];
+            if (k < 0) continue;
+            const fadehip_aln &a = c.aln[(size_t)k];
+            const int lq = r.l_seq();
+            std::string seq((size_t)lq, 'N'), qrc((size_t)lq, 'N'), bq((size_t)lq, '!');
+            const uint8_t *sq = r.seq(), *ql = r.qual();
+            for (int j = 0; j < lq; j++) {
+                const int code = (sq[j >> 1] >> ((~j & 1) << 2)) & 15;
+                seq[(size_t)j] = NT16_STR[code];
+                qrc[(size_t)(lq - 1 - j)] = NT16_STR[comp[code]];  // util.d:23-34
+                bq[(size_t)j] = (char)(ql[j] + 33);
+            }
+            const int nops = std::min(a.sw.n_ops, FADEHIP_MAX_OPS);
+            const std::string cig = cigar_string(a.sw.ops, nops);
+            const int64_t apos = a.win_start + a.sw.beg_ref;
+            const int64_t pos = r.pos();
+            std::string am = (r.tid() >= 0 && r.tid() < (int)h.names.size() ? h.names[(size_t)r.tid()] : std::string("*"));
+            am += ',';
+            append_int(am, apos);
+            am += ',';
+            am += cig;
+            std::string l[4], rr[4];
+            if (a.art & 1) {  // analysis.d:84-92
+                const int64_t clip = a.clip_left;
+                const int64_t overlap = apos >= pos - clip ? apos - (pos - clip) : 0;
+                const int64_t lead = (a.sw.ops[0] & 15) == 4 ? (a.sw.ops[0] >> 4) : 0;
+                const int64_t plen = std::min<int64_t>(lq, (lq - lead) + overlap);
+                l[0] = am; l[1] = seq.substr(0, (size_t)plen); l[2] = qrc.substr((size_t)(lq - plen)); l[3] = bq.substr(0, (size_t)plen);
+            }
+            if (a.art & 2) {  // analysis.d:108-118
+                const int64_t clip = a.clip_right;
+                int64_t res_al = 0;
+                for (int q = 0; q < nops; q++) {
+                    const uint32_t op = a.sw.ops[q] & 15;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) res_al += a.sw.ops[q] >> 4;
+                }
+                const int64_t lhs = pos + a.aligned_len + clip, rhs = apos + res_al;
+                const int64_t overlap = lhs >= rhs ? lhs - rhs : 0;
+                const int64_t trail = (a.sw.ops[nops - 1] & 15) == 4 ? (a.sw.ops[nops - 1] >> 4) : 0;
+                const int64_t plen = std::min<int64_t>(lq, (lq - trail) + overlap);
+                rr[0] = am; rr[1] = seq.substr((size_t)(lq - plen)); rr[2] = qrc.substr(0, (size_t)plen); rr[3] = bq.substr((size_t)(lq - plen));
+            }
+            r.aux_update_str("am", l[0] + ";" + rr[0]);  // anno.d:100
+            r.aux_update_str("as", l[1] + ";" + rr[1]);  // anno.d:102
+            r.aux_update_str("ar", l[2] + ";" + rr[2]);  // anno.d:104
+            r.aux_update_str("ab", l[3] + ";" + rr[3]);  // anno.d:106
+        }
+    });
+}
+
+static int annotate_main(const std::string &cl, const Opts &o) {
+    // anno.d:18-19 (htslib log format)
+    fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+    const int nthreads = o.threads > 0 ? o.threads : std::max(1u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u);
+    Pool pool(nthreads);
+    try {
+        Reader reader(o.pos[1], &pool);   // anno.d:22
+        Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
+        Header hdr = reader.header();     // anno.d:24
+        hdr.add_pg("fade-annotate", "fade", FADE_VERSION, cl);  // anno.d:25-32
+
+        // contigs of the BAM header, in tid order, must be present in the FASTA (fetchSequence by name, analysis.d:63)
+        const Header &h = reader.header();
+        std::vector<int64_t> lens(h.names.size());
+        std::vector<const uint8_t *> ptrs(h.names.size());
+        static const std::string empty;
+        for (size_t k = 0; k < h.names.size(); k++) {
+            size_t f = 0;
+            while (f < fa.names.size() && fa.names[f] != h.names[k]) f++;
+            if (f == fa.names.size()) {
+                fprintf(stderr, "[E::fade annotate] reference %s of the BAM header is not in %s\n", h.names[k].c_str(), o.pos[2].c_str());
+                return 1;
+            }
+            // analysis.d:55-59 clamps the window at the header's targetLength; the FASTA may be longer, never shorter
+            if ((int64_t)fa.seqs[f].size() < h.lens[k]) {
+                fprintf(stderr, "[E::fade annotate] %s is shorter in the FASTA (%zu) than in the header (%lld)\n", h.names[k].c_str(), fa.seqs[f].size(), (long long)h.lens[k]);
+                return 1;
+            }
+            lens[k] = h.lens[k];
+            ptrs[k] = (const uint8_t *)fa.seqs[f].data();
+        }
+        if (h.names.empty()) {
+            fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n");
+            return 1;
+        }
+        const int ngpu = std::max(1, o.gpus);
+        std::vector<fadehip_ctx *> ctxs((size_t)ngpu, nullptr);
+        fadehip_params prm;
+        fadehip_params_default(&prm);
+        prm.max_batch_reads = std::max(o.batch, 1);
+        auto die = [&](fadehip_ctx *c, const char *what) {
+            fprintf(stderr, "[E::fade annotate] %s: %s\n", what, fadehip_last_error(c));
+            for (auto *x : ctxs) fadehip_destroy(x);
+            return 1;
+        };
+        for (int d = 0; d < ngpu; d++) {
+            if (fadehip_create(&ctxs[(size_t)d], d, &prm)) return die(nullptr, "cannot open the GPU path");
+            if (fadehip_genome_upload(ctxs[(size_t)d], (int)lens.size(), lens.data(), ptrs.data())) return die(ctxs[(size_t)d], "genome upload");
+        }
+        fa.seqs.clear();
+        fa.seqs.shrink_to_fit();
+        // nothing is written to stdout before the GPU path is known to be usable
+        const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;  // util.d:65-76
+        Writer writer(stdout, fmt, hdr, &pool);
+
+        std::deque<std::unique_ptr<Chunk>> inflight;
+        int64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<std::vector<int64_t>> per_dev((size_t)ngpu, std::vector<int64_t>(8, 0));
+        auto finish = [&](std::unique_ptr<Chunk> c) -> int {
+            c->out.rs = c->rs.data();
+            c->out.aln = c->aln.data();
+            c->out.aln_cap = (int)c->aln.size();
+            if (fadehip_annotate_collect(ctxs[(size_t)c->dev], c->slot, &c->out)) return die(ctxs[(size_t)c->dev], "collect");
+            for (int k = 0; k < 8; k++) per_dev[(size_t)c->dev][(size_t)k] += c->out.stats[k];
+            apply_tags(*c, hdr, pool);
+            writer.write(c->recs);
+            return 0;
+        };
+        size_t seq_no = 0;
+        for (;;) {
+            std::unique_ptr<Chunk> c(new Chunk());
+            if (reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1)) == 0) break;
+            c->dev = (int)(seq_no % (size_t)ngpu);
+            c->slot = (int)((seq_no / (size_t)ngpu) % FADEHIP_NUM_SLOTS);
+            seq_no++;
+            pack_chunk(*c, pool);
+            // the slot about to be reused must have been collected
+            while (inflight.size() >= (size_t)ngpu * FADEHIP_NUM_SLOTS) {
+                if (finish(std::move(inflight.front()))) return 1;
+                inflight.pop_front();
+            }
+            fadehip_read_batch b;
+            b.n_reads = (int)c->recs.size();
+            b.tid = c->tid.data(); b.pos = c->pos.data(); b.flag = c->flag.data(); b.has_sa = c->has_sa.data();
+            b.l_seq = c->l_seq.data(); b.cigar_off = c->cigar_off.data(); b.cigar_ops = c->cigar_ops.data();
+            b.seq_off = c->seq_off.data(); b.seq_packed = c->seq.data();
+            if (fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &b, o.floor_len, o.window)) return die(ctxs[(size_t)c->dev], "submit");
+            inflight.push_back(std::move(c));
+            // keep one batch per slot in flight; write the oldest while the newest computes
+            while (inflight.size() > (size_t)ngpu * (FADEHIP_NUM_SLOTS - 1)) {
+                if (finish(std::move(inflight.front()))) return 1;
+                inflight.pop_front();
+            }
+        }
+        while (!inflight.empty()) {
+            if (finish(std::move(inflight.front()))) return 1;
+            inflight.pop_front();
+        }
+        writer.close();
+        // the one collective of the path: sum the stats.d counters over the devices (RCCL over xGMI)
+        if (ngpu > 1) {
+            std::vector<int64_t> flat((size_t)ngpu * 8);
+            for (int d = 0; d < ngpu; d++) std::copy(per_dev[(size_t)d].begin(), per_dev[(size_t)d].end(), flat.begin() + d * 8);
+            if (fadehip_stats_allreduce(ctxs.data(), ngpu, flat.data(), 8)) return die(ctxs[0], "stats all-reduce");
+            std::copy(flat.begin(), flat.begin() + 8, totals);
+        } else std::copy(per_dev[0].begin(), per_dev[0].end(), totals);
+        if (o.stats) {  // stats.d:56-72 layout
+            const double rc = (double)std::max<int64_t>(totals[0], 1);
+            fprintf(stderr, "read count:\t%lld\nClipped %%:\t%g\n%% With Supplementary alns:\t%g\nArtifact rate:\t%g\n"
+                            "%% With Supplementary alns and artifacts:\t%g\nArtifact rate left only:\t%g\nArtifact rate right only:\t%g\n",
+                    (long long)totals[0], totals[1] / rc, totals[2] / rc, totals[4] / rc, totals[3] / rc, totals[6] / rc, totals[7] / rc);
+        }
+        for (auto *x : ctxs) fadehip_destroy(x);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "[E::fade annotate] %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    std::string cl;  // app.d:66
+    for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
+    if (argc == 1) { print_full_help(); return 0; }  // app.d:67-73
+    const std::string sub = argv[1];
+    if (sub == "annotate") {
+        Opts o;
+        std::string err;
+        if (!parse_opts(argc, argv, o, err)) {
+            fprintf(stderr, "std.getopt.GetOptException: %s\n", err.c_str());
+            return 1;
+        }
+        // app.d:84-89: helpWanted | args.length < 3 (args = prog, "annotate", positionals...)
+        if (o.help || o.pos.size() < 2) { print_anno_help(); return 0; }
+        if (o.pos.size() < 3) {  // the reference indexes args[2] and dies; say why instead
+            print_anno_help();
+            fprintf(stderr, "[E::fade-annotate] an indexed fasta reference is required\n");
+            return 1;
+        }
+        if (o.bam && o.ubam) {  // app.d:94-99
+            fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");
+            return 1;
+        }
+        return annotate_main(cl, o);
+    }
+    if (sub == "out" || sub == "extract" || sub == "stats" || sub == "stats-clip") {
+        fprintf(stderr, "[E::fade] %s is outside the MI355X annotate hot path; run the reference fade for it\n", sub.c_str());
+        return 1;
+    }
+    if (sub == "-h" || sub == "--help") { print_full_help(); return 0; }
+    fprintf(stderr, "[E::fade] %s is not a fade subcommand\n", sub.c_str());  // app.d:218-220
+    print_full_help();
+    return 1;
+}

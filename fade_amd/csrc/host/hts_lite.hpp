@@ -1,0 +1,960 @@
+// hts_lite.hpp — the slice of htslib/dhtslib that `fade annotate` touches, over zlib only
+// (htslib is not present in this image: SURVEY.md H2).  Replaces, for this path:
+//   SAMReader(args[1]) / bam.allRecords           source/anno.d:22,44      -> Reader
+//   IndexedFastaFile(args[2])                     source/anno.d:23         -> load_fasta (whole file, uploaded to HBM once)
+//   header.dup + header.addLine(@PG ...)          source/anno.d:24-32      -> Header::add_pg
+//   getWriter(con, header): SAM / uBAM / BAM      source/util.d:65-76      -> Writer
+//   rec["rs"] = ubyte, rec["am"] = string ...     source/anno.d:63,94-106  -> Rec::aux_update_int / aux_update_str
+// BAM records are kept in their on-disk byte layout so CIGAR ops and the 4-bit sequence can be handed
+// to the device without re-encoding.
+#pragma once
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace htsl {
+
+// ------------------------------------------------------------------ small thread pool
+class Pool {
+public:
+    explicit Pool(int n) : n_(std::max(1, n)) {
+        for (int i = 1; i < n_; i++) th_.emplace_back([this, i] { worker(i); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return n_; }
+    // fn(i) for i in [0, count), dynamic distribution; returns when all are done
+    void parallel_for(size_t count, const std::function<void(size_t)> &fn) {
+        if (count == 0) return;
+        if (n_ == 1 || count == 1) {
+            for (size_t i = 0; i < count; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn;
+            count_ = count;
+            next_.store(0);
+            pending_ = n_ - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        run();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            size_t i = next_.fetch_add(1);
+            if (i >= count_) break;
+            (*fn_)(i);
+        }
+    }
+    void worker(int) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            run();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t count_ = 0;
+    std::atomic<size_t> next_{0};
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// ------------------------------------------------------------------ header
+struct Header {
+    std::string text;                // SAM header text (lines end with '\n')
+    std::vector<std::string> names;  // @SQ SN
+    std::vector<int64_t> lens;       // @SQ LN
+
+    int tid_of(const std::string &n) const {
+        for (size_t i = 0; i < names.size(); i++)
+            if (names[i] == n) return (int)i;
+        return -1;
+    }
+    void parse_sq_from_text() {
+        names.clear();
+        lens.clear();
+        size_t p = 0;
+        while (p < text.size()) {
+            size_t e = text.find('\n', p);
+            if (e == std::string::npos) e = text.size();
+            if (text.compare(p, 4, "@SQ\t") == 0) {
+                std::string sn;
+                int64_t ln = 0;
+                size_t f = p + 4;
+                while (f < e) {
+                    size_t g = text.find('\t', f);
+                    if (g == std::string::npos || g > e) g = e;
+                    if (text.compare(f, 3, "SN:") == 0) sn = text.substr(f + 3, g - f - 3);
+                    if (text.compare(f, 3, "LN:") == 0) ln = std::strtoll(text.c_str() + f + 3, nullptr, 10);
+                    f = g + 1;
+                }
+                names.push_back(sn);
+                lens.push_back(ln);
+            }
+            p = e + 1;
+        }
+    }
+    // ID of the last @PG line ("" if none) — header.valueByPos(PG, numRecords(PG)-1, "ID"), anno.d:30
+    std::string last_pg_id() const {
+        std::string id;
+        size_t p = 0;
+        while (p < text.size()) {
+            size_t e = text.find('\n', p);
+            if (e == std::string::npos) e = text.size();
+            if (text.compare(p, 4, "@PG\t") == 0) {
+                size_t f = text.find("\tID:", p);
+                if (f != std::string::npos && f < e) {
+                    size_t g = text.find_first_of("\t\n", f + 4);
+                    if (g == std::string::npos) g = e;
+                    id = text.substr(f + 4, g - f - 4);
+                }
+            }
+            p = e + 1;
+        }
+        return id;
+    }
+    // anno.d:25-32
+    void add_pg(const std::string &id, const std::string &pn, const std::string &vn, const std::string &cl) {
+        std::string pp = last_pg_id();
+        if (!text.empty() && text.back() != '\n') text += '\n';
+        text += "@PG\tID:" + id + "\tPN:" + pn + "\tVN:" + vn;
+        if (!pp.empty()) text += "\tPP:" + pp;
+        text += "\tCL:" + cl + "\n";
+    }
+};
+
+// ------------------------------------------------------------------ record (BAM byte layout, no block_size)
+static const char NT16_STR[] = "=ACMGRSVTWYHKDBN";
+static const char CIGAR_STR[] = "MIDNSHP=XB";
+
+inline int aux_type_size(uint8_t t) {
+    switch (t) {
+        case 'A': case 'c': case 'C': return 1;
+        case 's': case 'S': return 2;
+        case 'i': case 'I': case 'f': return 4;
+        case 'd': return 8;
+        default: return 0;
+    }
+}
+
+struct Rec {
+    std::vector<uint8_t> d;
+
+    template <class T> T rd(size_t off) const { T v; memcpy(&v, d.data() + off, sizeof(T)); return v; }
+    template <class T> void wr(size_t off, T v) { memcpy(d.data() + off, &v, sizeof(T)); }
+    int32_t tid() const { return rd<int32_t>(0); }
+    int32_t pos() const { return rd<int32_t>(4); }
+    int l_qname() const { return d[8]; }
+    int mapq() const { return d[9]; }
+    int n_cigar() const { return rd<uint16_t>(12); }
+    int flag() const { return rd<uint16_t>(14); }
+    int32_t l_seq() const { return rd<int32_t>(16); }
+    int32_t mtid() const { return rd<int32_t>(20); }
+    int32_t mpos() const { return rd<int32_t>(24); }
+    int32_t tlen() const { return rd<int32_t>(28); }
+    const char *qname() const { return (const char *)d.data() + 32; }
+    size_t cigar_off() const { return 32 + (size_t)l_qname(); }
+    const uint8_t *cigar_bytes() const { return d.data() + cigar_off(); }
+    uint32_t cigar_op(int k) const { return rd<uint32_t>(cigar_off() + 4 * (size_t)k); }
+    size_t seq_off() const { return cigar_off() + 4 * (size_t)n_cigar(); }
+    const uint8_t *seq() const { return d.data() + seq_off(); }
+    size_t qual_off() const { return seq_off() + ((size_t)l_seq() + 1) / 2; }
+    const uint8_t *qual() const { return d.data() + qual_off(); }
+    size_t aux_off() const { return qual_off() + (size_t)l_seq(); }
+
+    // size in bytes of the aux field whose type byte is at p (p points at the type), 0 on corruption
+    size_t aux_field_size(size_t p) const {
+        if (p >= d.size()) return 0;
+        const uint8_t t = d[p];
+        int s = aux_type_size(t);
+        if (s) return 1 + (size_t)s;
+        if (t == 'Z' || t == 'H') {
+            size_t q = p + 1;
+            while (q < d.size() && d[q]) q++;
+            return q < d.size() ? q - p + 1 : 0;
+        }
+        if (t == 'B') {
+            if (p + 6 > d.size()) return 0;
+            int es = aux_type_size(d[p + 1]);
+            uint32_t n = rd<uint32_t>(p + 2);
+            return es ? 6 + (size_t)es * n : 0;
+        }
+        return 0;
+    }
+    // offset of the tag's 2-byte name, or npos
+    size_t aux_find(const char tag[2]) const {
+        size_t p = aux_off();
+        while (p + 3 <= d.size()) {
+            size_t fs = aux_field_size(p + 2);
+            if (!fs) break;
+            if (d[p] == (uint8_t)tag[0] && d[p + 1] == (uint8_t)tag[1]) return p;
+            p += 2 + fs;
+        }
+        return std::string::npos;
+    }
+    bool aux_exists(const char tag[2]) const { return aux_find(tag) != std::string::npos; }
+    void aux_append(const char tag[2], uint8_t type, const void *data, size_t len) {
+        size_t o = d.size();
+        d.resize(o + 3 + len);
+        d[o] = (uint8_t)tag[0];
+        d[o + 1] = (uint8_t)tag[1];
+        d[o + 2] = type;
+        memcpy(d.data() + o + 3, data, len);
+    }
+    // htslib bam_aux_update_int for a non-negative value: in place when the existing integer type
+    // is wide enough, else replaced at the same position; appended (smallest type) when absent.
+    void aux_update_uint(const char tag[2], uint32_t v) {
+        uint8_t type = v <= 0xff ? 'C' : v <= 0xffff ? 'S' : 'I';
+        uint8_t buf[4];
+        memcpy(buf, &v, 4);
+        size_t p = aux_find(tag);
+        size_t need = type == 'C' ? 1 : type == 'S' ? 2 : 4;
+        if (p == std::string::npos) {
+            aux_append(tag, type, buf, need);
+            return;
+        }
+        const uint8_t ot = d[p + 2];
+        const size_t os = (size_t)aux_type_size(ot);
+        const bool is_int = ot == 'c' || ot == 'C' || ot == 's' || ot == 'S' || ot == 'i' || ot == 'I';
+        const uint64_t omax = ot == 'c' ? 0x7f : ot == 'C' ? 0xff : ot == 's' ? 0x7fff : ot == 'S' ? 0xffff
+                              : ot == 'i' ? 0x7fffffff : 0xffffffffull;
+        if (is_int && v <= omax) {
+            memcpy(d.data() + p + 3, buf, os);  // little endian: low bytes first
+            return;
+        }
+        const size_t fs = aux_field_size(p + 2);
+        replace_bytes(p + 2, fs, type, buf, need);
+    }
+    // htslib bam_aux_update_str: replaced at the same position when present, appended otherwise
+    void aux_update_str(const char tag[2], const std::string &s) {
+        size_t p = aux_find(tag);
+        if (p == std::string::npos) {
+            aux_append(tag, 'Z', s.c_str(), s.size() + 1);
+            return;
+        }
+        const size_t fs = aux_field_size(p + 2);
+        replace_bytes(p + 2, fs, 'Z', s.c_str(), s.size() + 1);
+    }
+
+private:
+    void replace_bytes(size_t at, size_t old_len, uint8_t type, const void *data, size_t len) {
+        std::vector<uint8_t> tail(d.begin() + at + old_len, d.end());
+        d.resize(at);
+        d.push_back(type);
+        d.insert(d.end(), (const uint8_t *)data, (const uint8_t *)data + len);
+        d.insert(d.end(), tail.begin(), tail.end());
+    }
+};
+
+inline int64_t cigar_ref_len(const Rec &r) {
+    int64_t n = 0;
+    for (int k = 0; k < r.n_cigar(); k++) {
+        uint32_t c = r.cigar_op(k), op = c & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) n += c >> 4;
+    }
+    return n;
+}
+
+inline int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+// ------------------------------------------------------------------ SAM text <-> Rec
+struct Nt16Table {
+    uint8_t t[256];
+    Nt16Table() {
+        memset(t, 15, sizeof t);
+        for (int k = 0; k < 16; k++) {
+            t[(unsigned char)NT16_STR[k]] = (uint8_t)k;
+            t[(unsigned char)(NT16_STR[k] | 0x20)] = (uint8_t)k;
+        }
+    }
+};
+inline const Nt16Table &nt16_table() {
+    static Nt16Table tb;
+    return tb;
+}
+
+inline void append_int(std::string &s, int64_t v) {
+    char buf[24];
+    int n = 0;
+    bool neg = v < 0;
+    uint64_t u = neg ? (uint64_t)(-v) : (uint64_t)v;
+    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (neg) s += '-';
+    while (n) s += buf[--n];
+}
+
+// One SAM line (no newline) -> record.  Throws std::runtime_error on malformed input.
+inline void sam_parse(const char *line, size_t len, const Header &h, Rec &r) {
+    const char *f[12];
+    size_t fl[12];
+    int nf = 0;
+    const char *p = line, *end = line + len;
+    while (nf < 11 && p <= end) {
+        const char *q = (const char *)memchr(p, '\t', (size_t)(end - p));
+        if (!q) q = end;
+        f[nf] = p;
+        fl[nf] = (size_t)(q - p);
+        nf++;
+        p = q + 1;
+    }
+    if (nf < 11) throw std::runtime_error("SAM line has fewer than 11 fields");
+    const char *aux = p <= end ? p : end;
+    const std::string rname(f[2], fl[2]), rnext(f[6], fl[6]);
+    const int tid = rname == "*" ? -1 : h.tid_of(rname);
+    if (rname != "*" && tid < 0) throw std::runtime_error("SAM record names unknown reference " + rname);
+    const int mtid = rnext == "*" ? -1 : rnext == "=" ? tid : h.tid_of(rnext);
+    const int64_t pos = std::strtoll(f[3], nullptr, 10) - 1;
+    std::vector<uint32_t> cig;
+    if (!(fl[5] == 1 && f[5][0] == '*')) {
+        uint64_t num = 0;
+        for (size_t k = 0; k < fl[5]; k++) {
+            char c = f[5][k];
+            if (c >= '0' && c <= '9') num = num * 10 + (uint64_t)(c - '0');
+            else {
+                const char *o = strchr(CIGAR_STR, c);
+                if (!o) throw std::runtime_error("bad CIGAR operator");
+                cig.push_back((uint32_t)(num << 4) | (uint32_t)(o - CIGAR_STR));
+                num = 0;
+            }
+        }
+    }
+    const bool noseq = fl[9] == 1 && f[9][0] == '*';
+    const size_t lseq = noseq ? 0 : fl[9];
+    const size_t lq = fl[0] + 1;
+    r.d.assign(32 + lq + 4 * cig.size() + (lseq + 1) / 2 + lseq, 0);
+    int64_t reflen = 0;
+    for (uint32_t c : cig) {
+        uint32_t op = c & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += c >> 4;
+    }
+    r.wr<int32_t>(0, tid);
+    r.wr<int32_t>(4, (int32_t)pos);
+    r.d[8] = (uint8_t)lq;
+    r.d[9] = (uint8_t)std::strtol(f[4], nullptr, 10);
+    r.wr<uint16_t>(10, (uint16_t)reg2bin(pos < 0 ? 0 : pos, (pos < 0 ? 0 : pos) + (reflen > 0 ? reflen : 1)));
+    r.wr<uint16_t>(12, (uint16_t)cig.size());
+    r.wr<uint16_t>(14, (uint16_t)std::strtol(f[1], nullptr, 10));
+    r.wr<int32_t>(16, (int32_t)lseq);
+    r.wr<int32_t>(20, mtid);
+    r.wr<int32_t>(24, (int32_t)(std::strtoll(f[7], nullptr, 10) - 1));
+    r.wr<int32_t>(28, (int32_t)std::strtoll(f[8], nullptr, 10));
+    memcpy(r.d.data() + 32, f[0], fl[0]);
+    size_t o = 32 + lq;
+    if (!cig.empty()) memcpy(r.d.data() + o, cig.data(), 4 * cig.size());
+    o += 4 * cig.size();
+    const uint8_t *tb = nt16_table().t;
+    for (size_t k = 0; k < lseq; k++) r.d[o + (k >> 1)] |= (uint8_t)(tb[(unsigned char)f[9][k]] << ((~k & 1) << 2));
+    o += (lseq + 1) / 2;
+    if (fl[10] == 1 && f[10][0] == '*') memset(r.d.data() + o, 0xff, lseq);
+    else {
+        if (fl[10] != lseq) throw std::runtime_error("SEQ and QUAL differ in length");
+        for (size_t k = 0; k < lseq; k++) r.d[o + k] = (uint8_t)(f[10][k] - 33);
+    }
+    // aux
+    while (aux < end) {
+        const char *q = (const char *)memchr(aux, '\t', (size_t)(end - aux));
+        if (!q) q = end;
+        const size_t n = (size_t)(q - aux);
+        if (n < 5 || aux[2] != ':' || aux[4] != ':') throw std::runtime_error("malformed SAM tag");
+        const char tag[2] = {aux[0], aux[1]};
+        const char ty = aux[3];
+        const char *v = aux + 5;
+        const size_t vl = n - 5;
+        if (ty == 'A') r.aux_append(tag, 'A', v, 1);
+        else if (ty == 'i') {
+            const long long x = std::strtoll(v, nullptr, 10);
+            if (x < 0) {
+                if (x >= -128) { int8_t y = (int8_t)x; r.aux_append(tag, 'c', &y, 1); }
+                else if (x >= -32768) { int16_t y = (int16_t)x; r.aux_append(tag, 's', &y, 2); }
+                else { int32_t y = (int32_t)x; r.aux_append(tag, 'i', &y, 4); }
+            } else {
+                if (x <= 0xff) { uint8_t y = (uint8_t)x; r.aux_append(tag, 'C', &y, 1); }
+                else if (x <= 0xffff) { uint16_t y = (uint16_t)x; r.aux_append(tag, 'S', &y, 2); }
+                else { uint32_t y = (uint32_t)x; r.aux_append(tag, 'I', &y, 4); }
+            }
+        } else if (ty == 'f') {
+            float y = std::strtof(v, nullptr);
+            r.aux_append(tag, 'f', &y, 4);
+        } else if (ty == 'Z' || ty == 'H') {
+            std::string s(v, vl);
+            r.aux_append(tag, (uint8_t)ty, s.c_str(), s.size() + 1);
+        } else if (ty == 'B') {
+            if (vl < 1) throw std::runtime_error("malformed B tag");
+            const char st = v[0];
+            const int es = aux_type_size((uint8_t)st);
+            if (!es) throw std::runtime_error("bad B subtype");
+            std::vector<uint8_t> buf;
+            uint32_t cnt = 0;
+            const char *c = v + 1;
+            while (c < v + vl) {
+                if (*c == ',') c++;
+                char *e2 = nullptr;
+                uint8_t tmp[8];
+                if (st == 'f') { float y = std::strtof(c, &e2); memcpy(tmp, &y, 4); }
+                else { long long y = std::strtoll(c, &e2, 10); memcpy(tmp, &y, 8); }
+                if (e2 == c) break;
+                buf.insert(buf.end(), tmp, tmp + es);
+                cnt++;
+                c = e2;
+            }
+            std::vector<uint8_t> all(5 + buf.size());
+            all[0] = (uint8_t)st;
+            memcpy(all.data() + 1, &cnt, 4);
+            if (!buf.empty()) memcpy(all.data() + 5, buf.data(), buf.size());
+            r.aux_append(tag, 'B', all.data(), all.size());
+        } else throw std::runtime_error("unknown SAM tag type");
+        aux = q + 1;
+    }
+}
+
+inline void sam_format(const Rec &r, const Header &h, std::string &s) {
+    s.append(r.qname());
+    s += '\t';
+    append_int(s, r.flag());
+    s += '\t';
+    const int tid = r.tid(), mtid = r.mtid();
+    if (tid >= 0 && tid < (int)h.names.size()) s += h.names[tid]; else s += '*';
+    s += '\t';
+    append_int(s, (int64_t)r.pos() + 1);
+    s += '\t';
+    append_int(s, r.mapq());
+    s += '\t';
+    if (r.n_cigar() == 0) s += '*';
+    for (int k = 0; k < r.n_cigar(); k++) {
+        uint32_t c = r.cigar_op(k);
+        append_int(s, c >> 4);
+        s += CIGAR_STR[std::min<uint32_t>(c & 15, 9)];
+    }
+    s += '\t';
+    if (mtid < 0) s += '*';
+    else if (mtid == tid) s += '=';
+    else if (mtid < (int)h.names.size()) s += h.names[mtid];
+    else s += '*';
+    s += '\t';
+    append_int(s, (int64_t)r.mpos() + 1);
+    s += '\t';
+    append_int(s, r.tlen());
+    s += '\t';
+    const int lseq = r.l_seq();
+    if (lseq == 0) s += '*';
+    else {
+        const uint8_t *sq = r.seq();
+        for (int k = 0; k < lseq; k++) s += NT16_STR[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
+    }
+    s += '\t';
+    const uint8_t *ql = r.qual();
+    if (lseq == 0 || ql[0] == 0xff) s += '*';
+    else for (int k = 0; k < lseq; k++) s += (char)(ql[k] + 33);
+    size_t p = r.aux_off();
+    char buf[64];
+    while (p + 3 <= r.d.size()) {
+        const size_t fs = r.aux_field_size(p + 2);
+        if (!fs) break;
+        s += '\t';
+        s += (char)r.d[p];
+        s += (char)r.d[p + 1];
+        s += ':';
+        const uint8_t t = r.d[p + 2];
+        const uint8_t *v = r.d.data() + p + 3;
+        switch (t) {
+            case 'A': s += "A:"; s += (char)v[0]; break;
+            case 'c': s += "i:"; append_int(s, (int8_t)v[0]); break;
+            case 'C': s += "i:"; append_int(s, v[0]); break;
+            case 's': { int16_t x; memcpy(&x, v, 2); s += "i:"; append_int(s, x); break; }
+            case 'S': { uint16_t x; memcpy(&x, v, 2); s += "i:"; append_int(s, x); break; }
+            case 'i': { int32_t x; memcpy(&x, v, 4); s += "i:"; append_int(s, x); break; }
+            case 'I': { uint32_t x; memcpy(&x, v, 4); s += "i:"; append_int(s, x); break; }
+            case 'f': { float x; memcpy(&x, v, 4); snprintf(buf, sizeof buf, "%g", x); s += "f:"; s += buf; break; }
+            case 'd': { double x; memcpy(&x, v, 8); snprintf(buf, sizeof buf, "%g", x); s += "d:"; s += buf; break; }
+            case 'Z': s += "Z:"; s += (const char *)v; break;
+            case 'H': s += "H:"; s += (const char *)v; break;
+            case 'B': {
+                const uint8_t st = v[0];
+                uint32_t n;
+                memcpy(&n, v + 1, 4);
+                s += "B:";
+                s += (char)st;
+                const uint8_t *e = v + 5;
+                const int es = aux_type_size(st);
+                for (uint32_t k = 0; k < n; k++, e += es) {
+                    s += ',';
+                    switch (st) {
+                        case 'c': append_int(s, (int8_t)e[0]); break;
+                        case 'C': append_int(s, e[0]); break;
+                        case 's': { int16_t x; memcpy(&x, e, 2); append_int(s, x); break; }
+                        case 'S': { uint16_t x; memcpy(&x, e, 2); append_int(s, x); break; }
+                        case 'i': { int32_t x; memcpy(&x, e, 4); append_int(s, x); break; }
+                        case 'I': { uint32_t x; memcpy(&x, e, 4); append_int(s, x); break; }
+                        case 'f': { float x; memcpy(&x, e, 4); snprintf(buf, sizeof buf, "%g", x); s += buf; break; }
+                    }
+                }
+                break;
+            }
+        }
+        p += 2 + fs;
+    }
+    s += '\n';
+}
+
+// ------------------------------------------------------------------ BGZF
+static const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
+                                     0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// compress one block of <= 0xff00 bytes into out (appended); level 0 gives stored (uBAM)
+inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::vector<uint8_t> &out) {
+    uint8_t buf[0x10000 + 64];
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+    zs.next_in = const_cast<uint8_t *>(src);
+    zs.avail_in = (uInt)n;
+    zs.next_out = buf + 18;
+    zs.avail_out = sizeof buf - 18 - 8;
+    const int rc = deflate(&zs, Z_FINISH);
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("BGZF deflate overflow");
+    const size_t clen = zs.total_out;
+    const size_t bsize = 18 + clen + 8;
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+    memcpy(buf, hdr, 16);
+    const uint16_t bs = (uint16_t)(bsize - 1);
+    memcpy(buf + 16, &bs, 2);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n), isz = (uint32_t)n;
+    memcpy(buf + 18 + clen, &crc, 4);
+    memcpy(buf + 18 + clen + 4, &isz, 4);
+    out.insert(out.end(), buf, buf + bsize);
+}
+
+class ByteSource {  // buffered FILE* with peek
+public:
+    explicit ByteSource(FILE *f) : f_(f), buf_(1 << 20) {}
+    size_t peek(uint8_t *dst, size_t n) {
+        fill(n);
+        const size_t k = std::min(n, end_ - beg_);
+        memcpy(dst, buf_.data() + beg_, k);
+        return k;
+    }
+    size_t read(uint8_t *dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            if (beg_ == end_) {
+                beg_ = end_ = 0;
+                if (n - got >= buf_.size()) {
+                    const size_t k = fread(dst + got, 1, n - got, f_);
+                    got += k;
+                    if (k == 0) break;
+                    continue;
+                }
+                end_ = fread(buf_.data(), 1, buf_.size(), f_);
+                if (end_ == 0) break;
+            }
+            const size_t k = std::min(n - got, end_ - beg_);
+            memcpy(dst + got, buf_.data() + beg_, k);
+            beg_ += k;
+            got += k;
+        }
+        return got;
+    }
+    // next text line without the newline; false at EOF
+    bool getline(std::string &s) {
+        s.clear();
+        for (;;) {
+            if (beg_ == end_) {
+                beg_ = 0;
+                end_ = fread(buf_.data(), 1, buf_.size(), f_);
+                if (end_ == 0) return !s.empty();
+            }
+            const uint8_t *p = (const uint8_t *)memchr(buf_.data() + beg_, '\n', end_ - beg_);
+            if (p) {
+                s.append((const char *)buf_.data() + beg_, (size_t)(p - (buf_.data() + beg_)));
+                beg_ = (size_t)(p - buf_.data()) + 1;
+                if (!s.empty() && s.back() == '\r') s.pop_back();
+                return true;
+            }
+            s.append((const char *)buf_.data() + beg_, end_ - beg_);
+            beg_ = end_;
+        }
+    }
+
+private:
+    void fill(size_t n) {
+        if (end_ - beg_ >= n) return;
+        memmove(buf_.data(), buf_.data() + beg_, end_ - beg_);
+        end_ -= beg_;
+        beg_ = 0;
+        while (end_ < n) {
+            const size_t k = fread(buf_.data() + end_, 1, buf_.size() - end_, f_);
+            if (!k) break;
+            end_ += k;
+        }
+    }
+    FILE *f_;
+    std::vector<uint8_t> buf_;
+    size_t beg_ = 0, end_ = 0;
+};
+
+// Inflates BGZF blocks in parallel batches and serves the uncompressed byte stream.
+class BgzfIn {
+public:
+    BgzfIn(ByteSource *src, Pool *pool) : src_(src), pool_(pool) {}
+    size_t read(uint8_t *dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            if (pos_ == out_.size()) {
+                if (!refill()) break;
+            }
+            const size_t k = std::min(n - got, out_.size() - pos_);
+            memcpy(dst + got, out_.data() + pos_, k);
+            pos_ += k;
+            got += k;
+        }
+        return got;
+    }
+
+private:
+    bool refill() {
+        out_.clear();
+        pos_ = 0;
+        comp_.clear();
+        offs_.clear();
+        const size_t kBatch = 256;
+        while (offs_.size() < kBatch) {
+            uint8_t h[18];
+            if (src_->peek(h, 18) < 18) break;
+            if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
+            // find BC subfield (almost always at byte 12)
+            uint16_t xlen;
+            memcpy(&xlen, h + 10, 2);
+            if (xlen < 6 || h[12] != 'B' || h[13] != 'C') throw std::runtime_error("BGZF block lacks the BC subfield first");
+            uint16_t bs;
+            memcpy(&bs, h + 16, 2);
+            const size_t bsize = (size_t)bs + 1;
+            const size_t o = comp_.size();
+            comp_.resize(o + bsize);
+            if (src_->read(comp_.data() + o, bsize) != bsize) throw std::runtime_error("truncated BGZF block");
+            offs_.push_back({o, bsize, (size_t)xlen});
+        }
+        if (offs_.empty()) return false;
+        std::vector<size_t> isz(offs_.size()), ooff(offs_.size() + 1, 0);
+        for (size_t k = 0; k < offs_.size(); k++) {
+            uint32_t v;
+            memcpy(&v, comp_.data() + offs_[k].off + offs_[k].size - 4, 4);
+            isz[k] = v;
+            ooff[k + 1] = ooff[k] + v;
+        }
+        out_.resize(ooff.back());
+        pool_->parallel_for(offs_.size(), [&](size_t k) {
+            if (isz[k] == 0) return;
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
+            const size_t hl = 12 + offs_[k].xlen;
+            zs.next_in = comp_.data() + offs_[k].off + hl;
+            zs.avail_in = (uInt)(offs_[k].size - hl - 8);
+            zs.next_out = out_.data() + ooff[k];
+            zs.avail_out = (uInt)isz[k];
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) bad_ = true;
+        });
+        if (bad_) throw std::runtime_error("BGZF inflate failed");
+        return true;
+    }
+    struct Blk { size_t off, size, xlen; };
+    ByteSource *src_;
+    Pool *pool_;
+    std::vector<uint8_t> comp_, out_;
+    std::vector<Blk> offs_;
+    size_t pos_ = 0;
+    std::atomic<bool> bad_{false};
+};
+
+// ------------------------------------------------------------------ reader (SAM text or BAM)
+class Reader {
+public:
+    Reader(const std::string &path, Pool *pool) : pool_(pool) {
+        f_ = path == "-" ? stdin : fopen(path.c_str(), "rb");
+        if (!f_) throw std::runtime_error("cannot open " + path);
+        src_.reset(new ByteSource(f_));
+        uint8_t m[4] = {0, 0, 0, 0};
+        src_->peek(m, 4);
+        if (m[0] == 0x1f && m[1] == 0x8b) {
+            bam_ = true;
+            bgzf_.reset(new BgzfIn(src_.get(), pool_));
+            read_bam_header();
+        } else {
+            read_sam_header();
+        }
+    }
+    ~Reader() {
+        if (f_ && f_ != stdin) fclose(f_);
+    }
+    const Header &header() const { return hdr_; }
+    bool is_bam() const { return bam_; }
+    // reads up to max_n records into out (appending); returns number read
+    size_t read_chunk(std::vector<Rec> &out, size_t max_n) {
+        size_t n = 0;
+        if (bam_) {
+            while (n < max_n) {
+                uint8_t b4[4];
+                const size_t k = bgzf_->read(b4, 4);
+                if (k == 0) break;
+                if (k != 4) throw std::runtime_error("truncated BAM record");
+                uint32_t bs;
+                memcpy(&bs, b4, 4);
+                if (bs < 32) throw std::runtime_error("corrupt BAM record");
+                out.emplace_back();
+                out.back().d.resize(bs);
+                if (bgzf_->read(out.back().d.data(), bs) != bs) throw std::runtime_error("truncated BAM record");
+                n++;
+            }
+            return n;
+        }
+        // SAM: gather lines first, parse in parallel
+        std::vector<std::string> lines;
+        if (!pending_.empty()) {
+            lines.push_back(std::move(pending_));
+            pending_.clear();
+        }
+        std::string s;
+        while (lines.size() < max_n && src_->getline(s)) {
+            if (s.empty()) continue;
+            lines.push_back(s);
+        }
+        const size_t base = out.size();
+        out.resize(base + lines.size());
+        std::atomic<bool> bad{false};
+        std::string err;
+        std::mutex em;
+        pool_->parallel_for(lines.size(), [&](size_t i) {
+            try {
+                sam_parse(lines[i].data(), lines[i].size(), hdr_, out[base + i]);
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> l(em);
+                bad = true;
+                err = e.what();
+            }
+        });
+        if (bad) throw std::runtime_error(err);
+        return lines.size();
+    }
+
+private:
+    void read_sam_header() {
+        std::string s;
+        while (src_->getline(s)) {
+            if (!s.empty() && s[0] == '@') hdr_.text += s + "\n";
+            else {
+                pending_ = s;
+                break;
+            }
+        }
+        hdr_.parse_sq_from_text();
+    }
+    void read_bam_header() {
+        uint8_t m[4];
+        if (bgzf_->read(m, 4) != 4 || memcmp(m, "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file");
+        int32_t lt;
+        bgzf_->read((uint8_t *)&lt, 4);
+        hdr_.text.resize((size_t)lt);
+        if (lt) bgzf_->read((uint8_t *)&hdr_.text[0], (size_t)lt);
+        while (!hdr_.text.empty() && hdr_.text.back() == '\0') hdr_.text.pop_back();
+        int32_t nref;
+        bgzf_->read((uint8_t *)&nref, 4);
+        for (int k = 0; k < nref; k++) {
+            int32_t ln;
+            bgzf_->read((uint8_t *)&ln, 4);
+            std::string nm((size_t)ln, '\0');
+            bgzf_->read((uint8_t *)&nm[0], (size_t)ln);
+            while (!nm.empty() && nm.back() == '\0') nm.pop_back();
+            int32_t l;
+            bgzf_->read((uint8_t *)&l, 4);
+            hdr_.names.push_back(nm);
+            hdr_.lens.push_back(l);
+        }
+    }
+    Pool *pool_;
+    FILE *f_ = nullptr;
+    std::unique_ptr<ByteSource> src_;
+    std::unique_ptr<BgzfIn> bgzf_;
+    bool bam_ = false;
+    Header hdr_;
+    std::string pending_;
+};
+
+// ------------------------------------------------------------------ writer: SAM / uBAM / BAM to a FILE*
+enum class OutFmt { SAM = 0, UBAM = 1, BAM = 2 };  // `con` of util.d:65-76
+
+class Writer {
+public:
+    Writer(FILE *f, OutFmt fmt, const Header &h, Pool *pool) : f_(f), fmt_(fmt), hdr_(h), pool_(pool) {
+        if (fmt_ == OutFmt::SAM) {
+            fwrite(hdr_.text.data(), 1, hdr_.text.size(), f_);
+        } else {
+            std::vector<uint8_t> b;
+            auto put32 = [&](int32_t v) { b.insert(b.end(), (uint8_t *)&v, (uint8_t *)&v + 4); };
+            b.insert(b.end(), {'B', 'A', 'M', 1});
+            put32((int32_t)hdr_.text.size());
+            b.insert(b.end(), hdr_.text.begin(), hdr_.text.end());
+            put32((int32_t)hdr_.names.size());
+            for (size_t k = 0; k < hdr_.names.size(); k++) {
+                put32((int32_t)hdr_.names[k].size() + 1);
+                b.insert(b.end(), hdr_.names[k].begin(), hdr_.names[k].end());
+                b.push_back(0);
+                put32((int32_t)hdr_.lens[k]);
+            }
+            raw_.insert(raw_.end(), b.begin(), b.end());
+            flush_blocks(true);  // htslib flushes the header into its own block(s)
+        }
+    }
+    void write(const std::vector<Rec> &recs) {
+        if (fmt_ == OutFmt::SAM) {
+            const size_t n = recs.size(), nt = (size_t)pool_->size();
+            std::vector<std::string> parts(nt);
+            pool_->parallel_for(nt, [&](size_t t) {
+                const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+                std::string &s = parts[t];
+                s.reserve((hi - lo) * 400);
+                for (size_t i = lo; i < hi; i++) sam_format(recs[i], hdr_, s);
+            });
+            for (auto &s : parts) fwrite(s.data(), 1, s.size(), f_);
+            return;
+        }
+        for (const Rec &r : recs) {
+            const uint32_t bs = (uint32_t)r.d.size();
+            raw_.insert(raw_.end(), (const uint8_t *)&bs, (const uint8_t *)&bs + 4);
+            raw_.insert(raw_.end(), r.d.begin(), r.d.end());
+        }
+        flush_blocks(false);
+    }
+    void close() {
+        if (closed_) return;
+        closed_ = true;
+        if (fmt_ != OutFmt::SAM) {
+            flush_blocks(true);
+            fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, f_);
+        }
+        fflush(f_);
+    }
+
+private:
+    void flush_blocks(bool all) {
+        const size_t B = 0xff00;
+        size_t nblk = raw_.size() / B;
+        if (all && raw_.size() % B) nblk++;
+        if (!nblk) return;
+        std::vector<std::vector<uint8_t>> outs(nblk);
+        const int level = fmt_ == OutFmt::UBAM ? 0 : 6;
+        pool_->parallel_for(nblk, [&](size_t k) {
+            const size_t o = k * B, n = std::min(B, raw_.size() - o);
+            outs[k].reserve(n + 64);
+            bgzf_compress_block(raw_.data() + o, n, level, outs[k]);
+        });
+        for (auto &o : outs) fwrite(o.data(), 1, o.size(), f_);
+        const size_t used = std::min(raw_.size(), nblk * B);
+        raw_.erase(raw_.begin(), raw_.begin() + used);
+    }
+    FILE *f_;
+    OutFmt fmt_;
+    Header hdr_;
+    Pool *pool_;
+    std::vector<uint8_t> raw_;
+    bool closed_ = false;
+};
+
+// ------------------------------------------------------------------ FASTA
+struct Fasta {
+    std::vector<std::string> names;
+    std::vector<std::string> seqs;  // residues as in the file (case preserved)
+};
+
+inline Fasta load_fasta(const std::string &path) {
+    gzFile g = gzopen(path.c_str(), "rb");  // transparent for plain, gzip and bgzip files
+    if (!g) throw std::runtime_error("cannot open " + path);
+    gzbuffer(g, 1 << 20);
+    Fasta fa;
+    std::vector<char> buf(1 << 20);
+    std::string carry;
+    bool in_name = false;
+    int n;
+    while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) {
+        const char *p = buf.data(), *e = p + n;
+        while (p < e) {
+            if (in_name) {
+                const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+                carry.append(p, q ? q : e);
+                if (!q) { p = e; break; }
+                size_t w = carry.find_first_of(" \t\r");
+                fa.names.push_back(carry.substr(0, w));
+                fa.seqs.emplace_back();
+                carry.clear();
+                in_name = false;
+                p = q + 1;
+            } else if (*p == '>') {
+                in_name = true;
+                p++;
+            } else {
+                const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+                const char *stop = q ? q : e;
+                // a '>' can only start a line, so anything up to the newline is sequence
+                if (fa.seqs.empty()) throw std::runtime_error("FASTA does not start with '>'");
+                const char *a = p;
+                size_t len = (size_t)(stop - a);
+                if (len && a[len - 1] == '\r') len--;
+                fa.seqs.back().append(a, len);
+                p = q ? q + 1 : e;
+            }
+        }
+    }
+    gzclose(g);
+    if (fa.names.empty()) throw std::runtime_error("no sequences in " + path);
+    return fa;
+}
+
+}  // namespace htsl

@@ -113,3 +113,73 @@ def read_fasta(text):
     if names:
         seqs.append("".join(cur))
     return names, seqs
+
+
+def bam_to_sam_records(data):
+    """Decode a (BGZF) BAM byte string -> (header_text, ref_names, records as parse_sam dicts)."""
+    import gzip
+    import struct
+    raw = gzip.decompress(data)  # BGZF is a series of gzip members
+    assert raw[:4] == b"BAM\x01"
+    l_text, = struct.unpack_from("<i", raw, 4)
+    text = raw[8:8 + l_text].decode()
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, o)
+    o += 4
+    names = []
+    for _ in range(n_ref):
+        ln, = struct.unpack_from("<i", raw, o)
+        names.append(raw[o + 4:o + 4 + ln - 1].decode())
+        o += 4 + ln + 4
+    recs = []
+    while o < len(raw):
+        bs, = struct.unpack_from("<i", raw, o)
+        b = raw[o + 4:o + 4 + bs]
+        o += 4 + bs
+        tid, pos, lqn, mapq, _bin, ncig, flag, lseq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", b, 0)
+        p = 32
+        qname = b[p:p + lqn - 1].decode()
+        p += lqn
+        cig = "".join("%d%s" % (c >> 4, CIGAR_OPS[c & 15]) for c in struct.unpack_from("<%dI" % ncig, b, p)) or "*"
+        p += 4 * ncig
+        sq = b[p:p + (lseq + 1) // 2]
+        seq = "".join(NT16[(sq[k >> 1] >> (4 if k % 2 == 0 else 0)) & 15] for k in range(lseq)) or "*"
+        p += (lseq + 1) // 2
+        ql = b[p:p + lseq]
+        qual = "*" if (lseq == 0 or ql[0] == 0xFF) else "".join(chr(x + 33) for x in ql)
+        p += lseq
+        tags, order = {}, []
+        while p < len(b):
+            tag = b[p:p + 2].decode()
+            ty = chr(b[p + 2])
+            p += 3
+            if ty in "cCsSiI":
+                fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[ty]
+                v, = struct.unpack_from(fmt, b, p)
+                p += struct.calcsize(fmt)
+                tags[tag] = ("i", str(v))
+                tags[tag + ".bamtype"] = ty
+            elif ty == "A":
+                tags[tag] = ("A", chr(b[p]))
+                p += 1
+            elif ty == "f":
+                v, = struct.unpack_from("<f", b, p)
+                p += 4
+                tags[tag] = ("f", "%g" % v)
+            elif ty in "ZH":
+                e = b.index(b"\0", p)
+                tags[tag] = (ty, b[p:e].decode())
+                p = e + 1
+            elif ty == "B":
+                st = chr(b[p])
+                n, = struct.unpack_from("<I", b, p + 1)
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[st]
+                vals = struct.unpack_from("<%d%s" % (n, fmt), b, p + 5)
+                p += 5 + n * struct.calcsize(fmt)
+                tags[tag] = ("B", st + "".join(",%g" % v if st == "f" else ",%d" % v for v in vals))
+            else:
+                raise ValueError("bad aux type " + ty)
+            order.append(tag)
+        recs.append(dict(qname=qname, flag=flag, rname=names[tid] if tid >= 0 else "*", pos=pos, mapq=mapq, cigar=cig,
+                         seq=seq, qual=qual, tags=tags, tag_order=order, mtid=mtid, mpos=mpos, tlen=tlen))
+    return text, names, recs
