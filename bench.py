@@ -20,6 +20,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# int VALU issue: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured by fade_amd/csrc/bench/valu_peak.hip: one
+# wave-instruction per 4 cycles per SIMD for v_pk_*, v_add/max, v_bfe, DPP moves alike)
+VALU_PEAK_TLANE = 39.3
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+
+
+def pmc_traffic(workload, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/collect.sh), already corrected (FETCH_SIZE x2, calibrated on known byte counts).
+    None when the summary does not cover this workload."""
+    try:
+        s = json.load(open(PMC_SUMMARY))
+    except (OSError, ValueError):
+        return None, None
+    if not workload.startswith(s.get("workload", "\0")):
+        return None, None
+    for name, k in s["kernels"].items():
+        if kernel_prefix in name:
+            return k["hbm_bytes_per_launch"], k
+    return None, None
 
 
 def cpu_baseline(genome, cfg, n_sample, seed):
@@ -108,6 +128,9 @@ def main():
     if rank == 0:
         fwd = float(np.mean(fwd_ms))
         achieved = prof["algorithmic_bytes"] / (fwd * 1e-3) / 1e9
+        workload = "%s: %d x %d bp PE reads per GPU per step, -w %d, --min-length %d, p_softclip %.2f" % (
+            args.config, args.batch_reads, cfg["read_len"], cfg["window"], cfg["floor_len"], cfg["p_sc"])
+        traffic, pmc = pmc_traffic(workload, "sw_forward")
         out = {
             "metric": "annotate reads/sec at 1/2/4/8 MI355X; rs/am tag bit-exact vs ref",
             "value": total_reads / dt_max,
@@ -121,14 +144,18 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d x %d bp PE reads per GPU per step, -w %d, --min-length %d, p_softclip %.2f"
-                                   % (args.config, args.batch_reads, cfg["read_len"], cfg["window"], cfg["floor_len"],
-                                      cfg["p_sc"]),
+            "config": {"workload": workload,
                        "alignments_per_step": int(prof["alignments"]), "dp_cells_per_step": int(prof["cells"])},
             "roofline": {"bound": "hbm", "kernel": "sw_forward_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(prof["algorithmic_bytes"]),
                          "kernel_ms": fwd, "gcups": prof["cells"] / (fwd * 1e-3) / 1e9},
+            # the kernel is integer-VALU issue bound, not HBM bound; PMC view of the same launch
+            "roofline_valu": None if pmc is None else {
+                "bound": "valu_int_issue", "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s",
+                "achieved": pmc["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12,
+                "frac": pmc["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12 / VALU_PEAK_TLANE,
+                "valu_busy_frac_pmc": pmc["valu_busy_frac"], "source": "profiles/r01_pmc_summary.json"},
             "kernels_ms": {"gate": float(np.mean(gate_ms)), "sw_forward": fwd, "traceback": float(np.mean(tb_ms))},
             "stats": {k: int(v) for k, v in zip(
                 ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"], st.tolist())},
