@@ -1,0 +1,182 @@
+"""Edge cases of the annotate path on the GPU, each compared with the oracle's annotateTask:
+hard clips, mid-CIGAR S, clip lengths around --min-length, contig-edge windows, unmapped records,
+empty sequences, soft-masked / IUPAC FASTA, N-rich reads, mixed read lengths (several row classes),
+trace chunking, batch-split invariance, and the limits that must fail loudly."""
+import numpy as np
+import pytest
+
+import fade_amd
+import samutil
+from fade_amd import format_tags, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ctx, oracle, names, seqs, batch, floor_len, window):
+    ctx.genome_upload(names, [s.encode() if isinstance(s, str) else s for s in seqs])
+    rs, aln, stats = ctx.annotate(batch, floor_len, window)
+    tags = format_tags(batch, names, rs, aln)
+    G = oracle.GenomeHolder(names, seqs)
+    ors, oam = oracle.annotate_batch_soa(G, batch, floor_len, window, threads=8)
+    assert np.array_equal(rs, ors), np.nonzero(rs != ors)[0][:10]
+    for i in range(len(ors)):
+        if oam[i] is None:
+            assert i not in tags
+        else:
+            assert tags[i]["am"] == oam[i], i
+    return rs, aln, tags
+
+
+def _sam(lines, contigs):
+    hdr = "".join("@SQ\tSN:%s\tLN:%d\n" % (n, len(s)) for n, s in contigs)
+    return hdr + "\n".join(lines) + "\n"
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+
+
+def test_handmade_records(ctx, oracle):
+    rng = np.random.default_rng(3)
+    ref = "".join("ACGT"[k] for k in rng.integers(0, 4, size=3000))
+    contigs = [("c1", ref), ("c2", ref[::-1])]
+    q = "I" * 150
+    lines = []
+
+    def add(name, flag, rname, pos, cigar, seq, extra=""):
+        lines.append("\t".join([name, str(flag), rname, str(pos + 1), "60", cigar, "*", "0", "0", seq, q[:len(seq)]]) + extra)
+
+    def read_with_left_artifact(pos, L, seg_start, lq=150):
+        clip = _rc(ref[seg_start:seg_start + L])
+        return clip + ref[pos:pos + lq - L]
+
+    # left artifacts with hard clip in front, clip lengths around the floor, SA tag
+    for k, L in enumerate([4, 5, 6, 7, 20, 50]):
+        pos = 600 + 200 * k
+        add("lh%d" % L, 0, "c1", pos, "10H%dS%dM" % (L, 150 - L), read_with_left_artifact(pos, L, pos - 60))
+        add("ls%d" % L, 16, "c1", pos, "%dS%dM" % (L, 150 - L), read_with_left_artifact(pos, L, pos - 60), "\tSA:Z:c2,5,+,50M,60,0;")
+    # right artifacts near the contig end (window clamps at targetLength)
+    for L in (8, 30):
+        pos = len(ref) - (150 - L) - 20
+        seg_end = len(ref) - 2
+        seq = ref[pos:pos + 150 - L] + _rc(ref[seg_end - L:seg_end])
+        add("re%d" % L, 0, "c1", pos, "%dM%dS" % (150 - L, L), seq)
+    # left artifact at the contig start (window clamps at 0)
+    add("l0", 0, "c1", 30, "20S130M", read_with_left_artifact(30, 20, 2))
+    # both clips, mid-CIGAR S (parse_clips sees none at the ends? it sees a right clip), S after H at the end
+    add("both", 0, "c1", 1500, "12S120M18S", _rc(ref[1420:1432]) + ref[1500:1620] + _rc(ref[1660:1678]))
+    add("mid", 0, "c1", 1700, "50M10S90M", ref[1700:1750] + "ACGTACGTAC" + ref[1750:1840], "\tSA:Z:c1,9,+,50M,60,0;")
+    add("endh", 0, "c1", 1900, "130M20S5H", ref[1900:2030] + _rc(ref[2050:2070]))
+    # unmapped with a CIGAR that has S (anno.d:61: !isMapped wins), mapped without S, empty SEQ with S
+    add("un", 4, "c1", 100, "20S130M", read_with_left_artifact(100, 20, 60))
+    add("nos", 0, "c1", 100, "150M", ref[100:250])
+    lines.append("\t".join(["noseq", "0", "c1", "301", "60", "20S130M", "*", "0", "0", "*", "*"]))
+    # N-rich read and clip of Ns
+    nr = list(read_with_left_artifact(2200, 30, 2150))
+    for p in range(0, 150, 7):
+        nr[p] = "N"
+    add("nrich", 0, "c1", 2200, "30S120M", "".join(nr))
+    # second contig
+    add("c2l", 0, "c2", 500, "25S125M", _rc(contigs[1][1][430:455]) + contigs[1][1][500:625])
+    text = _sam(lines, contigs)
+    names, lens, batch, qnames = samutil.sam_to_batch(text)
+    for floor_len, window in ((5, 300), (5, 100), (0, 40), (6, 1000)):
+        rs, aln, tags = _compare(ctx, oracle, names, [c[1] for c in contigs], batch, floor_len, window)
+    by = dict(zip(qnames, rs))
+    assert by["un"] == 0 and by["nos"] == 0
+    assert by["mid"] == 33  # parse_clips finds the mid-CIGAR S as a right clip: sc | sup
+    assert by["lh50"] == 3 and by["ls50"] == 35 and by["re30"] == 5
+
+
+def test_softmasked_and_iupac_reference(ctx, oracle):
+    cfg, g, b = synth.make_config("C2", 3000, contig_len=60_000)
+    rng = np.random.default_rng(8)
+    seqs = []
+    for a in g.ascii_contigs():
+        s = bytearray(a.tobytes())
+        for p in rng.integers(0, len(s), size=len(s) // 50):
+            s[p] = rng.choice(list(b"NRYKMSWnryacgt"))
+        lo = bytes(s).lower()
+        s[10_000:20_000] = lo[10_000:20_000]
+        seqs.append(bytes(s).decode())
+    _compare(ctx, oracle, g.names, seqs, b, cfg["floor_len"], cfg["window"])
+
+
+def test_mixed_read_lengths_and_classes(ctx, oracle):
+    g = synth.Genome(2, 80_000, 5)
+    parts = []
+    for k, lq in enumerate([36, 76, 101, 150, 151, 200, 250, 300, 400, 512]):
+        parts.append(synth.make_reads(g, 400, 50 + k, read_len=lq, window=120, p_sc=0.5, clip_min=6, clip_max=min(30, lq // 3)))
+    keys = ("tid", "pos", "flag", "has_sa", "l_seq")
+    b = {k: np.concatenate([p[k] for p in parts]) for k in keys}
+    for off, data in (("cigar_off", "cigar_ops"), ("seq_off", "seq_packed"), ("qual_off", "qual")):
+        b[data] = np.concatenate([p[data] for p in parts])
+        offs, base = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            offs.append(p[off][1:].astype(np.int64) + base)
+            base += int(p[off][-1])
+        b[off] = np.concatenate(offs)
+    rs, aln, tags = _compare(ctx, oracle, g.names, [a.tobytes().decode() for a in g.ascii_contigs()], b, 5, 120)
+    assert len(tags) > 100
+
+
+def test_trace_chunking_and_batch_split_invariance(oracle):
+    cfg, g, b = synth.make_config("C2", 20_000, contig_len=200_000)
+    contigs = g.ascii_contigs()
+    big = fade_amd.Context(device=0)
+    big.genome_upload(g.names, contigs)
+    rs, aln, stats = big.annotate(b, cfg["floor_len"], cfg["window"])
+    key = lambda a: {int(x["read_idx"]): x["sw"].tobytes() + bytes([int(x["art"])]) for x in a}
+    ref = key(aln)
+    # a 4 MB trace budget forces dozens of forward/traceback chunks per class
+    small = fade_amd.Context(device=0, trace_bytes=4 << 20)
+    small.genome_upload(g.names, contigs)
+    rs2, aln2, stats2 = small.annotate(b, cfg["floor_len"], cfg["window"])
+    assert np.array_equal(rs, rs2) and key(aln2) == ref and list(stats) == list(stats2)
+    assert small.last_profile(0)["trace_bytes"] >= big.last_profile(0)["trace_bytes"] * 0.9
+    # the same reads in two halves, on the two slots: every read's result is independent of its batch
+    n = len(rs)
+    h1, h2 = synth.take(b, np.arange(0, n // 2)), synth.take(b, np.arange(n // 2, n))
+    big.annotate_upload(0, h1)
+    big.annotate_upload(1, h2)
+    big.annotate_run(0, cfg["floor_len"], cfg["window"])
+    big.annotate_run(1, cfg["floor_len"], cfg["window"])
+    r1, a1, s1 = big.annotate_collect(0)
+    r2, a2, s2 = big.annotate_collect(1)
+    assert np.array_equal(np.concatenate([r1, r2]), rs)
+    k2 = {k + n // 2: v for k, v in key(a2).items()}
+    assert {**key(a1), **k2} == ref
+    assert list(s1 + s2) == list(stats)
+    # idempotence: running the same slot again gives the same bytes
+    big.annotate_run(1, cfg["floor_len"], cfg["window"])
+    r2b, a2b, _ = big.annotate_collect(1)
+    assert np.array_equal(r2, r2b) and key(a2b) == key(a2)
+    big.close()
+    small.close()
+
+
+def test_limits_fail_loudly(ctx):
+    g = synth.Genome(1, 50_000, 2)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    long_reads = synth.make_reads(g, 50, 1, read_len=600, window=100, p_sc=1.0, clip_min=10, clip_max=20)
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(long_reads, 5, 100)
+    assert e.value.code == -5 and "512" in str(e.value)
+    ok = synth.make_reads(g, 50, 1, read_len=150, window=100, p_sc=1.0, clip_min=10, clip_max=20)
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(ok, 5, 9000)  # window beyond max_ref_len
+    assert e.value.code == -5
+    bad = dict(ok)
+    bad["tid"] = np.where((ok["flag"] & 4) == 0, 7, ok["tid"]).astype(np.int32)
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(bad, 5, 100)
+    assert e.value.code == -1
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.genome_upload(["x"], [b"ACGT=ACGT"])
+    assert e.value.code == -7
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    rs, aln, stats = ctx.annotate(ok, 5, 100)  # the context stays usable after the errors
+    assert int(stats[0]) == 50
+    empty = synth.take(ok, np.arange(0))
+    rs, aln, stats = ctx.annotate(empty, 5, 100)
+    assert len(rs) == 0 and len(aln) == 0 and int(stats[0]) == 0
