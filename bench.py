@@ -43,19 +43,23 @@ def pmc_traffic(workload, kernel_prefix):
 
 
 def cpu_baseline(genome, cfg, n_sample, seed):
-    """The oracle (CPU restatement of the reference path, kind "port") timed on this host's cores
-    over a bounded sample of the same workload.  Checker code: never on the product path."""
+    """The oracle's striped AVX2 restatement of the reference path (kind "port": the reference's own
+    parasail/htslib build cannot exist in this image) timed on this host's cores over a bounded sample
+    of the same workload, one SW call per qualifying clip as the reference does.  Checker code: never on
+    the product path."""
     from fade_amd import synth
     from oracle import pyoracle as O
-    cores = len(os.sched_getaffinity(0))
+    # one GPU's share of the host: the box exposes the whole node's threads, a 1-GPU job is sized to 16 cores
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FADE_BENCH_CPU_THREADS", "32")))
     b = synth.make_reads(genome, n_sample, seed, **cfg)
     G = O.GenomeHolder(genome.names, [a.tobytes() for a in genome.ascii_contigs()])
     t0 = time.perf_counter()
-    rs, _ = O.annotate_batch_soa(G, b, cfg["floor_len"], cfg["window"], threads=cores, want_am=False)
+    rs, _ = O.annotate_batch_soa(G, b, cfg["floor_len"], cfg["window"], threads=cores, want_am=False,
+                                 params=O.default_params(striped=True))
     dt = time.perf_counter() - t0
     return dict(value=n_sample / dt, unit="reads/s", cores=cores, kind="port",
-                sample="%d reads of the same synthetic workload (%.2f s wall = %.0f core-seconds, scalar "
-                       "oracle on %d threads)" % (n_sample, dt, dt * cores, cores)), b, rs
+                sample="%d reads of the same synthetic workload (%.2f s wall = %.0f core-seconds, striped "
+                       "AVX2 int16 SW+trace oracle on %d threads)" % (n_sample, dt, dt * cores, cores)), b, rs
 
 
 def main():
@@ -161,8 +165,8 @@ def main():
                 ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"], st.tolist())},
         }
         if not args.no_cpu and world == 1:
-            cores = len(os.sched_getaffinity(0))
-            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(600_000, 2500 * cores)
+            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FADE_BENCH_CPU_THREADS", "32")))
+            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(2_000_000, 30000 * cores)
             cb, sb, srs = cpu_baseline(genome, cfg, n_sample, 1000 + rank)
             cb["gpu_over_cpu"] = out["value"] / cb["value"]
             out["cpu_baseline"] = cb

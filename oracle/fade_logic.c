@@ -114,7 +114,8 @@ static void align_clip(int left, const fo_params *p, const fo_genome *g, const f
     fo_sw_result res;
     const int cap = lq + (int)lr + 4;
     uint32_t *ops = (uint32_t *)malloc((size_t)cap * sizeof(uint32_t));
-    fo_sw_trace(p, q_seq, lq, ref_seq, (int)lr, &res, ops, cap);
+    if (p->striped) fo_sw_striped(p, q_seq, lq, ref_seq, (int)lr, &res, ops, cap);
+    else fo_sw_trace(p, q_seq, lq, ref_seq, (int)lr, &res, ops, cap);
     (*n_sw)++;
     /* analysis.d:69-70 */
     if (res.n_ops == 0 || res.n_ops > 10) goto done;

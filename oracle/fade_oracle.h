@@ -45,6 +45,7 @@ typedef struct {
     int mismatch;  /* -3 */
     const char *alphabet; /* "ACTGN" (anno.d:36) */
     uint32_t rules; /* FO_RULES_DEFAULT */
+    int striped;    /* 1: fo_annotate_* call the striped AVX2 restatement instead of the scalar one */
 } fo_params;
 
 void fo_params_default(fo_params *p); /* Parasail("ACTGN", 10, 2, 2, -3), anno.d:36 */
@@ -69,9 +70,14 @@ int fo_sw_trace(const fo_params *p, const char *q, int lq, const char *r, int lr
 int fo_sw_trace_table(const fo_params *p, const char *q, int lq, const char *r, int lr,
                       fo_sw_result *res, uint32_t *ops, int ops_cap, uint8_t *trace);
 
+/* Striped (Farrar) 16-bit AVX2 restatement of the same alignment; identical results by contract
+ * (tests/test_oracle_striped.py).  Falls back to the scalar code for non-default rules or no AVX2. */
+int fo_sw_striped(const fo_params *p, const char *q, int lq, const char *r, int lr,
+                  fo_sw_result *res, uint32_t *ops, int ops_cap);
+
 /* n alignments over concatenated ASCII buffers; q_off/r_off have n+1 entries.
  * res: n x 6 int32 (score,end_q,end_r,beg_q,beg_r,n_ops); ops: n x max_ops uint32 (front of CIGAR).
- * `variant` 0 = scalar.  `threads` pthreads over contiguous ranges. */
+ * `variant` 0 = scalar, 1 = striped AVX2.  `threads` pthreads over contiguous ranges. */
 int fo_sw_batch(const fo_params *p, int n, int threads, const uint8_t *q, const int64_t *q_off,
                 const uint8_t *r, const int64_t *r_off, int32_t *res, uint32_t *ops, int max_ops,
                 int variant);

@@ -23,7 +23,7 @@ def build(force=False):
 
 class Params(C.Structure):
     _fields_ = [("open", C.c_int), ("ext", C.c_int), ("match", C.c_int), ("mismatch", C.c_int),
-                ("alphabet", C.c_char_p), ("rules", C.c_uint32)]
+                ("alphabet", C.c_char_p), ("rules", C.c_uint32), ("striped", C.c_int)]
 
 
 class SwResult(C.Structure):
@@ -59,6 +59,8 @@ def lib():
         L.fo_sw_trace.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                   C.POINTER(SwResult), C.POINTER(C.c_uint32), C.c_int]
         L.fo_sw_trace.restype = C.c_int
+        L.fo_sw_striped.argtypes = L.fo_sw_trace.argtypes
+        L.fo_sw_striped.restype = C.c_int
         L.fo_sw_trace_table.argtypes = L.fo_sw_trace.argtypes + [C.c_void_p]
         L.fo_sw_trace_table.restype = C.c_int
         L.fo_annotate_task.argtypes = [C.POINTER(Params), C.POINTER(Genome), C.POINTER(Read), C.c_int,
@@ -81,11 +83,12 @@ def lib():
     return _lib
 
 
-def default_params(rules=None):
+def default_params(rules=None, striped=False):
     p = Params()
     lib().fo_params_default(C.byref(p))
     if rules is not None:
         p.rules = rules
+    p.striped = 1 if striped else 0
     return p
 
 
@@ -104,9 +107,7 @@ def sw(q, r, params=None, striped=False, ops_cap=None):
     cap = ops_cap or (len(q) + len(r) + 4)
     ops = (C.c_uint32 * cap)()
     res = SwResult()
-    if striped:
-        raise NotImplementedError("striped restatement not built yet")
-    fn = L.fo_sw_trace
+    fn = L.fo_sw_striped if striped else L.fo_sw_trace
     rc = fn(C.byref(p), q, len(q), r, len(r), C.byref(res), ops, cap)
     if rc != 0:
         raise RuntimeError("oracle sw failed rc=%d" % rc)

@@ -25,6 +25,7 @@ void fo_params_default(fo_params *p) {
     p->mismatch = -3;
     p->alphabet = "ACTGN";
     p->rules = FO_RULES_DEFAULT;
+    p->striped = 0;
 }
 
 /* A.1: 256-entry case-insensitive mapper; unknown characters map to the wildcard index. */
