@@ -81,15 +81,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FADE_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 control flow on a 1-GPU box
+    backend = os.environ.get("FADE_BENCH_BACKEND", "nccl")
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
         local = 0
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
 
     cfg = synth.config(args.config)
     genome = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
@@ -166,7 +169,7 @@ def main():
         }
         if not args.no_cpu and world == 1:
             cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FADE_BENCH_CPU_THREADS", "32")))
-            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(2_000_000, 30000 * cores)
+            n_sample = args.cpu_sample if args.cpu_sample > 0 else min(4_000_000, 125000 * cores)
             cb, sb, srs = cpu_baseline(genome, cfg, n_sample, 1000 + rank)
             cb["gpu_over_cpu"] = out["value"] / cb["value"]
             out["cpu_baseline"] = cb

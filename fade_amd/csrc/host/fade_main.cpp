@@ -56,7 +56,7 @@ static void print_anno_help() {
 
 struct Opts {
     int threads = 0, floor_len = 5, window = 300, gpus = 1, batch = 262144;
-    bool bam = false, ubam = false, help = false, stats = false;
+    bool bam = false, ubam = false, help = false, stats = false, timing = false;
     std::vector<std::string> pos;
 };
 
@@ -92,6 +92,7 @@ static bool parse_opts(int argc, char **argv, Opts &o, std::string &err) {
             else if (name == "bam") o.bam = true;
             else if (name == "ubam") o.ubam = true;
             else if (name == "stats") o.stats = true;
+            else if (name == "timing") o.timing = true;
             else if (name == "help") o.help = true;
             else { err = "Unrecognized option --" + name; return false; }
         } else if (a.size() > 1 && a[0] == '-' && a != "-") {
@@ -115,6 +116,41 @@ static bool parse_opts(int argc, char **argv, Opts &o, std::string &err) {
     }
     return true;
 }
+
+// ------------------------------------------------------------------ stage hand-off
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        not_full_.wait(l, [&] { return q_.size() < cap_ || closed_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    bool pop(T &v) {  // false once closed and drained
+        std::unique_lock<std::mutex> l(m_);
+        not_empty_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> l(m_);
+        closed_ = true;
+        not_empty_.notify_all();
+        not_full_.notify_all();
+    }
+
+private:
+    size_t cap_;
+    std::deque<T> q_;
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    bool closed_ = false;
+};
 
 // ------------------------------------------------------------------ one batch in flight
 struct Chunk {
@@ -234,14 +270,26 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
     });
 }
 
+struct StageClock {
+    double t = 0;
+    std::chrono::steady_clock::time_point t0;
+    void start() { t0 = std::chrono::steady_clock::now(); }
+    void stop() { t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 static int annotate_main(const std::string &cl, const Opts &o) {
+    StageClock ck_total, ck_fasta, ck_upload, ck_read, ck_pack, ck_submit, ck_collect, ck_tags, ck_write;
+    ck_total.start();
     // anno.d:18-19 (htslib log format)
     fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
     const int nthreads = o.threads > 0 ? o.threads : std::max(1u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u);
     Pool pool(nthreads);
     try {
-        Reader reader(o.pos[1], &pool);   // anno.d:22
+        Pool rpool0(nthreads);
+        Reader reader(o.pos[1], &rpool0);   // anno.d:22 (the reader stage inflates / parses on its own pool)
+        ck_fasta.start();
         Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
+        ck_fasta.stop();
         Header hdr = reader.header();     // anno.d:24
         hdr.add_pg("fade-annotate", "fade", FADE_VERSION, cl);  // anno.d:25-32
 
@@ -279,58 +327,120 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             for (auto *x : ctxs) fadehip_destroy(x);
             return 1;
         };
+        ck_upload.start();
         for (int d = 0; d < ngpu; d++) {
             if (fadehip_create(&ctxs[(size_t)d], d, &prm)) return die(nullptr, "cannot open the GPU path");
             if (fadehip_genome_upload(ctxs[(size_t)d], (int)lens.size(), lens.data(), ptrs.data())) return die(ctxs[(size_t)d], "genome upload");
         }
+        ck_upload.stop();
         fa.seqs.clear();
         fa.seqs.shrink_to_fit();
         // nothing is written to stdout before the GPU path is known to be usable
         const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;  // util.d:65-76
-        Writer writer(stdout, fmt, hdr, &pool);
+        Pool wpool0(nthreads);
+        Writer writer(stdout, fmt, hdr, &wpool0);
 
+        // three stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack, device, tags] -> [writer: format,
+        // BGZF deflate].  Each stage has its own pool; chunks keep their input order.
+        BoundedQueue<std::unique_ptr<Chunk>> q_in(2), q_out(2);
+        std::string stage_err;
+        std::mutex err_m;
+        auto set_stage_err = [&](const std::string &e) {
+            std::lock_guard<std::mutex> l(err_m);
+            if (stage_err.empty()) stage_err = e;
+        };
+        std::thread t_reader([&] {
+            try {
+                for (;;) {
+                    std::unique_ptr<Chunk> c(new Chunk());
+                    ck_read.start();
+                    const size_t got = reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
+                    ck_read.stop();
+                    if (got == 0) break;
+                    q_in.push(std::move(c));
+                }
+            } catch (const std::exception &e) {
+                set_stage_err(e.what());
+            }
+            q_in.close();
+        });
+        std::thread t_writer([&] {
+            std::unique_ptr<Chunk> c;
+            try {
+                while (q_out.pop(c)) { ck_write.start(); writer.write(c->recs); ck_write.stop(); }
+            } catch (const std::exception &e) {
+                set_stage_err(e.what());
+                while (q_out.pop(c)) {}
+            }
+        });
         std::deque<std::unique_ptr<Chunk>> inflight;
         int64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         std::vector<std::vector<int64_t>> per_dev((size_t)ngpu, std::vector<int64_t>(8, 0));
+        bool failed = false;
         auto finish = [&](std::unique_ptr<Chunk> c) -> int {
             c->out.rs = c->rs.data();
             c->out.aln = c->aln.data();
             c->out.aln_cap = (int)c->aln.size();
-            if (fadehip_annotate_collect(ctxs[(size_t)c->dev], c->slot, &c->out)) return die(ctxs[(size_t)c->dev], "collect");
+            ck_collect.start();
+            const int crc = fadehip_annotate_collect(ctxs[(size_t)c->dev], c->slot, &c->out);
+            ck_collect.stop();
+            if (crc) {
+                fprintf(stderr, "[E::fade annotate] collect: %s\n", fadehip_last_error(ctxs[(size_t)c->dev]));
+                return 1;
+            }
             for (int k = 0; k < 8; k++) per_dev[(size_t)c->dev][(size_t)k] += c->out.stats[k];
+            ck_tags.start();
             apply_tags(*c, hdr, pool);
-            writer.write(c->recs);
+            ck_tags.stop();
+            q_out.push(std::move(c));
             return 0;
         };
         size_t seq_no = 0;
-        for (;;) {
-            std::unique_ptr<Chunk> c(new Chunk());
-            if (reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1)) == 0) break;
+        std::unique_ptr<Chunk> c;
+        while (!failed && q_in.pop(c)) {
             c->dev = (int)(seq_no % (size_t)ngpu);
             c->slot = (int)((seq_no / (size_t)ngpu) % FADEHIP_NUM_SLOTS);
             seq_no++;
+            ck_pack.start();
             pack_chunk(*c, pool);
-            // the slot about to be reused must have been collected
-            while (inflight.size() >= (size_t)ngpu * FADEHIP_NUM_SLOTS) {
-                if (finish(std::move(inflight.front()))) return 1;
-                inflight.pop_front();
-            }
+            ck_pack.stop();
             fadehip_read_batch b;
             b.n_reads = (int)c->recs.size();
             b.tid = c->tid.data(); b.pos = c->pos.data(); b.flag = c->flag.data(); b.has_sa = c->has_sa.data();
             b.l_seq = c->l_seq.data(); b.cigar_off = c->cigar_off.data(); b.cigar_ops = c->cigar_ops.data();
             b.seq_off = c->seq_off.data(); b.seq_packed = c->seq.data();
-            if (fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &b, o.floor_len, o.window)) return die(ctxs[(size_t)c->dev], "submit");
+            ck_submit.start();
+            const int src = fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &b, o.floor_len, o.window);
+            ck_submit.stop();
+            if (src) {
+                fprintf(stderr, "[E::fade annotate] submit: %s\n", fadehip_last_error(ctxs[(size_t)c->dev]));
+                failed = true;
+                break;
+            }
             inflight.push_back(std::move(c));
-            // keep one batch per slot in flight; write the oldest while the newest computes
-            while (inflight.size() > (size_t)ngpu * (FADEHIP_NUM_SLOTS - 1)) {
-                if (finish(std::move(inflight.front()))) return 1;
+            // one batch per slot in flight: the oldest is collected while the newest computes
+            while (!failed && inflight.size() > (size_t)ngpu * (FADEHIP_NUM_SLOTS - 1)) {
+                if (finish(std::move(inflight.front()))) failed = true;
                 inflight.pop_front();
             }
         }
-        while (!inflight.empty()) {
-            if (finish(std::move(inflight.front()))) return 1;
+        while (!failed && !inflight.empty()) {
+            if (finish(std::move(inflight.front()))) failed = true;
             inflight.pop_front();
+        }
+        if (failed) {  // drain the reader so that it can exit
+            while (q_in.pop(c)) {}
+        }
+        q_out.close();
+        t_reader.join();
+        t_writer.join();
+        if (!stage_err.empty()) {
+            fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str());
+            failed = true;
+        }
+        if (failed) {
+            for (auto *x : ctxs) fadehip_destroy(x);
+            return 1;
         }
         writer.close();
         // the one collective of the path: sum the stats.d counters over the devices (RCCL over xGMI)
@@ -347,6 +457,11 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                     (long long)totals[0], totals[1] / rc, totals[2] / rc, totals[4] / rc, totals[3] / rc, totals[6] / rc, totals[7] / rc);
         }
         for (auto *x : ctxs) fadehip_destroy(x);
+        ck_total.stop();
+        if (o.timing)
+            fprintf(stderr, "[timing] total %.3f s: fasta %.3f, create+genome upload %.3f | reader stage %.3f | pack %.3f, "
+                            "submit %.3f, collect %.3f, tags %.3f | writer stage %.3f (stages overlap)\n",
+                    ck_total.t, ck_fasta.t, ck_upload.t, ck_read.t, ck_pack.t, ck_submit.t, ck_collect.t, ck_tags.t, ck_write.t);
     } catch (const std::exception &e) {
         fprintf(stderr, "[E::fade annotate] %s\n", e.what());
         return 1;
