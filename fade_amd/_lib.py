@@ -25,7 +25,8 @@ EXPORTS = [
 
 class Params(C.Structure):
     _fields_ = [("open", C.c_int32), ("ext", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
-                ("max_ref_len", C.c_int32), ("max_batch_reads", C.c_int32), ("trace_bytes", C.c_int64)]
+                ("max_ref_len", C.c_int32), ("max_batch_reads", C.c_int32), ("trace_bytes", C.c_int64),
+                ("trace_all", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SwResult(C.Structure):

@@ -32,7 +32,7 @@ class Context:
     """One fadehip_ctx (one GPU)."""
 
     def __init__(self, device=-1, open=10, ext=2, match=2, mismatch=-3, max_ref_len=0, max_batch_reads=0,
-                 trace_bytes=0):
+                 trace_bytes=0, trace_all=False):
         self._L = _lib.load()
         p = _lib.Params()
         self._L.fadehip_params_default(C.byref(p))
@@ -42,6 +42,7 @@ class Context:
         if max_batch_reads:
             p.max_batch_reads = max_batch_reads
         p.trace_bytes = trace_bytes
+        p.trace_all = 1 if trace_all else 0
         h = C.c_void_p()
         rc = self._L.fadehip_create(C.byref(h), device, C.byref(p))
         if rc != 0:

@@ -27,9 +27,11 @@ struct Slot {
     hipStream_t stream = nullptr;
     DevBuf tid, pos, lseq, flag, has_sa, cigar_off, cigar_ops, seq_off, seq;
     DevBuf rs, fwd, aln, counters, counters64, stats, trace;
+    DevBuf ckpt, cand, sel_counters, incomplete;  // two-pass path
+    uint32_t *h_sel = nullptr;                   // pinned: NUM_BUCKETS + 1
     DevBuf work[NUM_CLASSES], meta[NUM_CLASSES];
     uint32_t *h_counters = nullptr;            // pinned: 2*NC+1
-    unsigned long long *h_counters64 = nullptr;  // pinned: 2
+    unsigned long long *h_counters64 = nullptr;  // pinned: 3
     unsigned long long *h_stats = nullptr;       // pinned: 8
     int n_reads = 0;
     int state = 0;  // 0 idle, 1 uploaded, 2 ran
@@ -41,6 +43,7 @@ struct Slot {
     int ev_gate0 = -1, ev_gate1 = -1, ev_end = -1;
     int64_t prof_counts[4] = {0, 0, 0, 0};
     int n_fwd_launches = 0;
+    int64_t n_cand = 0, n_rerun = 0;  // two-pass: candidates traced / candidates re-run from column 0
 };
 
 }  // namespace
@@ -57,7 +60,9 @@ struct fadehip_ctx {
     std::vector<int64_t> h_contig_len;
     std::vector<uint64_t> h_contig_base;
     int cu_count = 0;
-    bool use_packed = true;  // FADEHIP_KERNEL=int32 selects the unpacked reference kernel (A/B runs)
+    // FADEHIP_KERNEL = twopass (default) | pk (single-pass packed int16) | int32 (single-pass int32): A/B runs
+    bool use_packed = true;
+    bool two_pass = true;
 };
 
 namespace {
@@ -162,7 +167,7 @@ int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size
         if (cls == C) {
             constexpr int R = class_rows(C);
             if (packed)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward_pk_kernel<R>), dim3(quads), dim3(64), lds, st, a);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 0>), dim3(quads), dim3(64), lds, st, a);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward_kernel<R>), dim3(quads), dim3(64), lds, st, a);
             HIPCHK(ctx, hipGetLastError());
@@ -172,10 +177,213 @@ int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size
     }
 }
 
+template <int C>
+int launch_pk_mode(fadehip_ctx *ctx, int cls, int mode, const SwArgs &a, int octets, size_t lds, hipStream_t st) {
+    if constexpr (C >= NUM_CLASSES) {
+        return set_err(ctx, FADEHIP_E_INVALID, "bad class %d", cls);
+    } else {
+        if (cls == C) {
+            constexpr int R = class_rows(C);
+            if (mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 1>), dim3(octets), dim3(64), lds, st, a);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 2>), dim3(octets), dim3(64), lds, st, a);
+            HIPCHK(ctx, hipGetLastError());
+            return 0;
+        }
+        return launch_pk_mode<C + 1>(ctx, cls, mode, a, octets, lds, st);
+    }
+}
+
+__global__ void make_cand_back_kernel(const Cand *in, int n, int back, Cand *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        Cand c = in[k];
+        c.c0 = (int)c.c0 > back ? c.c0 - (uint32_t)back : 0u;
+        out[k] = c;
+    }
+}
+
+// Two-pass path for one class list: pass 1 scores every alignment and leaves H/E checkpoints
+// every CK_COLS columns; the selection keeps the alignments that can still become an artifact call; pass 2
+// re-computes, with trace, only columns [c0, end_ref] of each candidate and walks the traceback; a candidate
+// whose path leaves that range on the left is re-run from column 0.
+int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *work, const Meta *meta,
+                       int n_items, int max_lr, const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out,
+                       uint8_t *rs, int floor_len, int gate, int64_t budget, bool timed) {
+    const int R = class_rows(cls);
+    const int n_ck = (max_lr + 15 + CK_COLS - 1) / CK_COLS;
+    const uint64_t ck_stride = (uint64_t)n_ck * ck_dwords(R) * 64;  // dwords per pass-1 octet
+    auto strides = [&](int steps, int *n_blocks, uint64_t *stride, int *ref_stride, size_t *lds) {
+        *n_blocks = (steps + 3) / 4;
+        *stride = (uint64_t)*n_blocks * R * 64;
+        *ref_stride = (((*n_blocks * 4) * 2 + 15) / 16) * 16;
+        *lds = (size_t)*ref_stride * 4;
+    };
+    int nb1, ref_stride1;
+    uint64_t stride_unused;
+    size_t lds1;
+    strides(max_lr + 15, &nb1, &stride_unused, &ref_stride1, &lds1);
+    if (lds1 > 64 * 1024)
+        return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, lds1);
+    // chunk so that the checkpoints of a chunk fit half the budget (the other half is pass-2 trace scratch)
+    const int64_t ck_bytes = (int64_t)ck_stride * 4;
+    const int total_oct = (n_items + 7) / 8;
+    const int64_t chunk_oct = std::max<int64_t>(1, std::min<int64_t>(total_oct, (budget / 2) / std::max<int64_t>(ck_bytes, 1)));
+    int rc;
+    if ((rc = reserve(ctx, s.ckpt, (size_t)(chunk_oct * ck_bytes))) || (rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd))) ||
+        (rc = reserve(ctx, s.sel_counters, sizeof(uint32_t) * (NUM_BUCKETS + 1))))
+        return rc;
+    for (int64_t o0 = 0; o0 < total_oct; o0 += chunk_oct) {
+        const int octs = (int)std::min<int64_t>(chunk_oct, total_oct - o0);
+        const int i0 = (int)(o0 * 8);
+        const int n = std::min(n_items - i0, octs * 8);
+        if ((rc = reserve(ctx, s.cand, sizeof(Cand) * (size_t)NUM_BUCKETS * (size_t)n)) ||
+            (rc = reserve(ctx, s.incomplete, sizeof(Cand) * (size_t)n)))
+            return rc;
+        HIPCHK(ctx, hipMemsetAsync(s.sel_counters.p, 0, sizeof(uint32_t) * (NUM_BUCKETS + 1), st));
+        SwArgs a;
+        a.work = work + i0;
+        a.n_items = n;
+        a.q_nib = q_nib;
+        a.r_nib = r_nib;
+        a.trace = nullptr;
+        a.quad_stride = 0;
+        a.ref_stride = ref_stride1;
+        a.fwd = (Fwd *)s.fwd.p + i0;
+        a.sc = ctx->sc;
+        a.cand = nullptr;
+        a.ckpt = (uint32_t *)s.ckpt.p;
+        a.ck_stride = ck_stride;
+        a.n_ck = n_ck;
+        int e0 = -1, e1 = -1, e2 = -1;
+        if (timed && (rc = record(ctx, s, &e0))) return rc;
+        if ((rc = launch_pk_mode<0>(ctx, cls, 1, a, octs, lds1, st))) return rc;
+        if (timed && (rc = record(ctx, s, &e1))) return rc;
+        SelArgs sel;
+        sel.work = work + i0;
+        sel.meta = meta ? meta + i0 : nullptr;
+        sel.fwd = (const Fwd *)s.fwd.p + i0;
+        sel.n_items = n;
+        sel.floor_len = floor_len;
+        sel.trace_all = ctx->prm.trace_all;
+        sel.R = R;
+        sel.cand = (Cand *)s.cand.p;
+        sel.cap = (uint32_t)n;
+        sel.bucket_n = (uint32_t *)s.sel_counters.p;
+        sel.out = out + i0;
+        hipLaunchKernelGGL(select_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, sel);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(s.h_sel, s.sel_counters.p, sizeof(uint32_t) * NUM_BUCKETS, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        uint32_t bucket_n[NUM_BUCKETS];
+        for (int b = 0; b < NUM_BUCKETS; b++) bucket_n[b] = s.h_sel[b];
+        // pass 2: every bucket in ONE forward launch and ONE traceback launch (separate launches per bucket
+        // each run a fraction of a wave-round and pay their own ramp and tail)
+        auto pass2 = [&](const Cand *cand, uint32_t cap, const uint32_t *counts, const int *steps_max, int nb,
+                         bool may_be_incomplete) -> int {
+            P2Table tab;
+            memset(&tab, 0, sizeof tab);
+            tab.cap = cap;
+            uint64_t off = 0;
+            uint32_t oct = 0;
+            size_t lds2 = 0;
+            int ref_stride2 = 16;
+            for (int b = 0; b < NUM_BUCKETS; b++) {
+                tab.oct_first[b] = oct;
+                if (b >= nb || !counts[b]) continue;
+                int nb2, rs2;
+                uint64_t st2;
+                size_t l2;
+                strides(steps_max[b], &nb2, &st2, &rs2, &l2);
+                tab.count[b] = counts[b];
+                tab.trace_base[b] = off;
+                tab.stride[b] = st2;
+                const uint32_t octs_b = (counts[b] + 7) / 8;
+                off += (uint64_t)octs_b * st2;
+                oct += octs_b;
+                lds2 = std::max(lds2, l2);
+                ref_stride2 = std::max(ref_stride2, rs2);
+            }
+            tab.oct_first[NUM_BUCKETS] = oct;
+            if (!oct) return 0;
+            int r2 = reserve(ctx, s.trace, (size_t)off * 4);
+            if (r2) return r2;
+            SwArgs b2 = a;
+            b2.n_items = 0;
+            b2.cand = cand;
+            b2.trace = (uint32_t *)s.trace.p;
+            b2.quad_stride = 0;
+            b2.ref_stride = ref_stride2;
+            b2.tab = tab;
+            if ((r2 = launch_pk_mode<0>(ctx, cls, 2, b2, (int)oct, lds2, st))) return r2;
+            TbArgs t;
+            t.work = work + i0;
+            t.meta = meta ? meta + i0 : nullptr;
+            t.fwd = (const Fwd *)s.fwd.p + i0;
+            t.n_items = (int)oct * 8;
+            t.R = R;
+            t.q_nib = q_nib;
+            t.r_nib = r_nib;
+            t.trace = (const uint32_t *)s.trace.p;
+            t.quad_stride = 0;
+            t.sc = ctx->sc;
+            t.out = out + i0;
+            t.rs = rs;
+            t.floor_len = floor_len;
+            t.gate = gate;
+            t.packed = 1;
+            t.cand = cand;
+            t.incomplete = may_be_incomplete ? (Cand *)s.incomplete.p : nullptr;
+            t.incomplete_n = (uint32_t *)s.sel_counters.p + NUM_BUCKETS;
+            t.tab = tab;
+            hipLaunchKernelGGL(traceback_kernel, dim3((oct * 8 + 63) / 64), dim3(64), 0, st, t);
+            HIPCHK(ctx, hipGetLastError());
+            s.prof_counts[2] += (int64_t)off * 4;
+            return 0;
+        };
+        int steps_max[NUM_BUCKETS];
+        for (int b = 0; b < NUM_BUCKETS; b++) steps_max[b] = std::min(bucket_cols(b), max_lr + 15);
+        if ((rc = pass2((const Cand *)s.cand.p, (uint32_t)n, bucket_n, steps_max, NUM_BUCKETS, true))) return rc;
+        // candidates whose path left the traced steps: first from 4 snapshots further back, then from step 0
+        int n_inc = 0;
+        for (int round = 0; round < 2; round++) {
+            HIPCHK(ctx, hipMemcpyAsync(s.h_sel + NUM_BUCKETS, (uint32_t *)s.sel_counters.p + NUM_BUCKETS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            const int m = (int)s.h_sel[NUM_BUCKETS];
+            if (m == 0) break;
+            n_inc += m;
+            Cand *again = (Cand *)s.cand.p;  // the bucket lists are consumed, reuse their storage
+            hipLaunchKernelGGL(make_cand_back_kernel, dim3((m + 255) / 256), dim3(256), 0, st, (const Cand *)s.incomplete.p, m,
+                               round == 0 ? 4 * CK_COLS : (1 << 30), again);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemsetAsync((uint32_t *)s.sel_counters.p + NUM_BUCKETS, 0, sizeof(uint32_t), st));
+            const uint32_t cnt1[1] = {(uint32_t)m};
+            const int st1[1] = {max_lr + 15};
+            if ((rc = pass2(again, (uint32_t)m, cnt1, st1, 1, round == 0))) return rc;
+        }
+        s.n_rerun += n_inc;
+        if (getenv("FADEHIP_DEBUG")) {
+            fprintf(stderr, "[fadehip] class R=%d chunk n=%d: buckets", R, n);
+            for (int b = 0; b < NUM_BUCKETS; b++) fprintf(stderr, " %u", bucket_n[b]);
+            fprintf(stderr, " | re-run from step 0: %d\n", n_inc);
+        }
+        if (timed) {
+            if ((rc = record(ctx, s, &e2))) return rc;
+            s.fwd_spans.push_back({e0, e1});
+            s.tb_spans.push_back({e1, e2});
+        }
+        s.n_fwd_launches++;
+        for (int b = 0; b < NUM_BUCKETS; b++) s.n_cand += bucket_n[b];
+    }
+    return 0;
+}
+
 // Runs forward + traceback for one class list, chunked so the trace fits `trace`.
 int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *work, const Meta *meta, int n_items,
               int max_lr, const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out, uint8_t *rs, int floor_len,
               int gate, int64_t trace_budget, bool timed) {
+    if (ctx->two_pass)
+        return run_class_two_pass(ctx, s, st, cls, work, meta, n_items, max_lr, q_nib, r_nib, out, rs, floor_len, gate,
+                                  trace_budget, timed);
     const int R = class_rows(cls);
     const bool packed = ctx->use_packed;
     const int per_wave = packed ? 8 : 4;  // alignments per wavefront
@@ -208,6 +416,10 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         a.ref_stride = ref_stride;
         a.fwd = (Fwd *)s.fwd.p + i0;
         a.sc = ctx->sc;
+        a.cand = nullptr;
+        a.ckpt = nullptr;
+        a.ck_stride = 0;
+        a.n_ck = 0;
         int e0 = -1, e1 = -1, e2 = -1;
         if (timed && (rc = record(ctx, s, &e0))) return rc;
         rc = launch_forward_c<0>(ctx, cls, a, quads, lds, st, packed);
@@ -229,6 +441,9 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         t.floor_len = floor_len;
         t.gate = gate;
         t.packed = packed ? 1 : 0;
+        t.cand = nullptr;
+        t.incomplete = nullptr;
+        t.incomplete_n = nullptr;
         hipLaunchKernelGGL(traceback_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t);
         HIPCHK(ctx, hipGetLastError());
         if (timed) {
@@ -261,6 +476,8 @@ void fadehip_params_default(fadehip_params *p) {
     p->max_ref_len = 8192;
     p->max_batch_reads = 1 << 20;
     p->trace_bytes = 0;
+    p->trace_all = 0;
+    p->reserved = 0;
 }
 
 int fadehip_abi_version(void) { return FADEHIP_ABI_VERSION; }
@@ -307,7 +524,10 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         return fail(FADEHIP_E_NODEVICE);
     }
     ctx->cu_count = prop.multiProcessorCount;
-    if (const char *kv = getenv("FADEHIP_KERNEL")) ctx->use_packed = strcmp(kv, "int32") != 0;
+    if (const char *kv = getenv("FADEHIP_KERNEL")) {
+        ctx->use_packed = strcmp(kv, "int32") != 0;
+        ctx->two_pass = strcmp(kv, "twopass") == 0;
+    }
     uint8_t table[256];
     fill_ascii_table(table);
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_ascii_code), table, 256) != hipSuccess) {
@@ -318,7 +538,8 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         Slot &s = ctx->slots[k];
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipHostMalloc((void **)&s.h_counters, sizeof(uint32_t) * (2 * NUM_CLASSES + 1)) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_counters64, sizeof(unsigned long long) * 2) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_counters64, sizeof(unsigned long long) * 3) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_sel, sizeof(uint32_t) * (NUM_BUCKETS + 1)) != hipSuccess ||
             hipHostMalloc((void **)&s.h_stats, sizeof(unsigned long long) * 8) != hipSuccess) {
             set_err(ctx, FADEHIP_E_HIP, "stream / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(FADEHIP_E_HIP);
@@ -335,7 +556,8 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
         for (DevBuf *b : {&s.tid, &s.pos, &s.lseq, &s.flag, &s.has_sa, &s.cigar_off, &s.cigar_ops, &s.seq_off, &s.seq,
-                          &s.rs, &s.fwd, &s.aln, &s.counters, &s.counters64, &s.stats, &s.trace})
+                          &s.rs, &s.fwd, &s.aln, &s.counters, &s.counters64, &s.stats, &s.trace, &s.ckpt, &s.cand,
+                          &s.sel_counters, &s.incomplete})
             release(*b);
         for (int c = 0; c < NUM_CLASSES; c++) {
             release(s.work[c]);
@@ -344,6 +566,7 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
         if (s.h_counters) (void)hipHostFree(s.h_counters);
         if (s.h_counters64) (void)hipHostFree(s.h_counters64);
+        if (s.h_sel) (void)hipHostFree(s.h_sel);
         if (s.h_stats) (void)hipHostFree(s.h_stats);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
@@ -554,7 +777,7 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         (rc = reserve(ctx, s.seq, n_seq + 8)) || (rc = reserve(ctx, s.rs, (size_t)n)) ||
         (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)n)) ||
         (rc = reserve(ctx, s.counters, sizeof(uint32_t) * (2 * NUM_CLASSES + 1))) ||
-        (rc = reserve(ctx, s.counters64, sizeof(unsigned long long) * 2)) ||
+        (rc = reserve(ctx, s.counters64, sizeof(unsigned long long) * 3)) ||
         (rc = reserve(ctx, s.stats, sizeof(unsigned long long) * 8)))
         return rc;
     for (int c = 0; c < NUM_CLASSES; c++) {
@@ -590,6 +813,8 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     s.tb_spans.clear();
     s.n_aln = 0;
     s.n_fwd_launches = 0;
+    s.n_cand = 0;
+    s.n_rerun = 0;
     memset(s.prof_counts, 0, sizeof s.prof_counts);
     if (n == 0) {
         memset(s.h_stats, 0, sizeof(unsigned long long) * 8);
@@ -598,7 +823,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         return 0;
     }
     HIPCHK(ctx, hipMemsetAsync(s.counters.p, 0, sizeof(uint32_t) * (2 * NUM_CLASSES + 1), st));
-    HIPCHK(ctx, hipMemsetAsync(s.counters64.p, 0, sizeof(unsigned long long) * 2, st));
+    HIPCHK(ctx, hipMemsetAsync(s.counters64.p, 0, sizeof(unsigned long long) * 3, st));
     HIPCHK(ctx, hipMemsetAsync(s.stats.p, 0, sizeof(unsigned long long) * 8, st));
     if ((rc = record(ctx, s, &s.ev_gate0))) return rc;
     GateArgs g;
@@ -628,7 +853,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(s.h_counters, s.counters.p, sizeof(uint32_t) * (2 * NUM_CLASSES + 1), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.h_counters64, s.counters64.p, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(s.h_counters64, s.counters64.p, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     const uint32_t errbits = s.h_counters[2 * NUM_CLASSES];
     if (errbits) {
@@ -657,7 +882,9 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     s.prof_counts[1] = (int64_t)s.h_counters64[0];
     // algorithmic bytes of the forward kernel: packed query + packed window +
     // 16 B descriptor + 64 B result slot + 4-bit trace cell
-    s.prof_counts[3] = (int64_t)s.h_counters64[1] + (int64_t)base * 80 + (int64_t)(s.h_counters64[0] / 2);
+    // two-pass: the dominant kernel (pass 1) writes H/E checkpoints instead of the trace
+    s.prof_counts[3] = (int64_t)s.h_counters64[1] + (int64_t)base * 80 +
+                       (ctx->two_pass ? (int64_t)s.h_counters64[2] : (int64_t)(s.h_counters64[0] / 2));
     s.state = 2;
     return 0;
 }

@@ -103,6 +103,21 @@ __global__ void pack_ascii_kernel(const uint8_t *__restrict__ in, uint64_t n_bas
     out[(out_base >> 1) + k] = (uint8_t)((c_ascii_code[a0] << 4) | c_ascii_code[a1]);
 }
 
+struct Cand {           // pass-2 work item: which alignment, and the sweep step its traced re-computation resumes at
+    uint32_t src;       // index into the class work list
+    uint32_t c0;        // first step T0 (multiple of CK_COLS; 0 = from the start of the sweep)
+};
+// Pass 1 snapshots the whole wave state (H, E-hat of every row, the three values in flight between lanes and
+// the reference-class shift register) after every 32 steps of the anti-diagonal sweep, so pass 2 can resume
+// the sweep at any multiple of 32 exactly as if it had never stopped.
+constexpr int CK_SHIFT = 5, CK_COLS = 1 << CK_SHIFT;
+__host__ __device__ constexpr int ck_dwords(int R) { return 2 * R + 4; }  // per lane per snapshot
+constexpr int NUM_BUCKETS = 10;                       // pass-2 lists by number of sweep steps to re-compute
+__host__ __device__ constexpr int bucket_cols(int b) {
+    constexpr int t[NUM_BUCKETS] = {32, 48, 64, 96, 128, 192, 256, 384, 512, 1 << 30};
+    return t[b];
+}
+
 // ---------------------------------------------------------------- gate (anno.d:61-74, analysis.d:34-59)
 struct GateArgs {
     int32_t n_reads;
@@ -119,14 +134,14 @@ struct GateArgs {
     Work *work[NUM_CLASSES];
     Meta *meta[NUM_CLASSES];
     uint32_t *counters;  // [0..NC) item counts, [NC..2NC) max lr, [2NC] error bits
-    unsigned long long *counters64;  // [0] DP cells, [1] packed sequence bytes read (query + window)
+    unsigned long long *counters64;  // [0] DP cells, [1] packed sequence bytes read (query + window), [2] checkpoint bytes
 };
 
 constexpr int GATE_BLOCK = 1024;
 __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // per-thread contribution to the batch counters; reduced per wave before touching memory
-    unsigned long long cells = 0, seq_bytes = 0;
+    unsigned long long cells = 0, seq_bytes = 0, ck_bytes = 0;
     uint32_t lr_for_max = 0, errbits = 0;
     int cls = -1;
     Work w;
@@ -179,6 +194,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
                 else {
                     cells = (unsigned long long)lq * (unsigned long long)lr;
                     seq_bytes = (unsigned long long)((lq + 1) / 2 + (lr + 1) / 2);
+                    ck_bytes = (unsigned long long)lq * (unsigned long long)(lr >> CK_SHIFT) * 4ull;  // H + E-hat, int16 each
                     lr_for_max = (uint32_t)lr;
                     w.r_base = a.contig_base[tid] + (uint64_t)start;
                     w.q_base = a.seq_off[i] * 2u;
@@ -200,9 +216,9 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     // class (per-lane or even per-wave atomics on one address serialise at ~12 ns each and dominated
     // this kernel)
     __shared__ uint32_t s_cnt[NUM_CLASSES], s_base[NUM_CLASSES], s_maxlr[NUM_CLASSES], s_err;
-    __shared__ unsigned long long s_cells, s_bytes;
+    __shared__ unsigned long long s_cells, s_bytes, s_ck;
     if (threadIdx.x < NUM_CLASSES) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; }
+    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; }
     __syncthreads();
     uint32_t local_slot = 0;
     if (cls >= 0) {
@@ -213,10 +229,12 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         for (int sh = 32; sh >= 1; sh >>= 1) {
             cells += __shfl_xor(cells, sh, 64);
             seq_bytes += __shfl_xor(seq_bytes, sh, 64);
+            ck_bytes += __shfl_xor(ck_bytes, sh, 64);
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&s_cells, cells);
             atomicAdd(&s_bytes, seq_bytes);
+            atomicAdd(&s_ck, ck_bytes);
         }
     }
     if (errbits) atomicOr(&s_err, errbits);
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         if (s_cells) {
             atomicAdd(&a.counters64[0], s_cells);
             atomicAdd(&a.counters64[1], s_bytes);
+            atomicAdd(&a.counters64[2], s_ck);
         }
         if (s_err) atomicOr(&a.counters[2 * NUM_CLASSES], s_err);
     }
@@ -241,6 +260,18 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
 }
 
 // ---------------------------------------------------------------- forward SW with trace
+// Pass 2 runs all buckets in one launch: wave `oct` belongs to the bucket b with oct_first[b] <= oct <
+// oct_first[b+1]; its candidates are cand[b * cap + 8 * (oct - oct_first[b]) ...] and its trace scratch starts at
+// trace_base[b] + (oct - oct_first[b]) * stride[b] dwords.
+struct P2Table {
+    uint32_t oct_first[NUM_BUCKETS + 1];
+    uint32_t count[NUM_BUCKETS];
+    uint64_t trace_base[NUM_BUCKETS];
+    uint64_t stride[NUM_BUCKETS];
+    uint32_t cap;
+    uint32_t pad;
+};
+
 struct SwArgs {
     const Work *work;
     int32_t n_items;        // items in this launch (quads = ceil(n/4))
@@ -251,6 +282,12 @@ struct SwArgs {
     int32_t ref_stride;     // LDS bytes per group (multiple of 16)
     Fwd *fwd;
     ScoreTab sc;
+    // two-pass path (sw_pk_kernel MODE 1 / 2)
+    const Cand *cand;       // MODE 2: n_items candidates; item k is alignment cand[k].src
+    uint32_t *ckpt;         // [pass-1 octet][checkpoint][H rows | E rows][64 lanes]
+    uint64_t ck_stride;     // dwords per pass-1 octet
+    int32_t n_ck;           // checkpoints per octet
+    P2Table tab;            // MODE 2
 };
 
 #define DPP_ROW_SHR1 0x111
@@ -438,8 +475,12 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
 
 constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and log2(8) + 16
 
-template <int R>
-__global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
+// MODE 0: single pass — full window, trace to memory, end cell (sw_forward_pk_kernel of round-1 v3)
+// MODE 1: pass 1 — score and end cell only, plus a snapshot of the wave state every CK_COLS steps
+// MODE 2: pass 2 — traced re-computation of sweep steps [T0, end_ref + lane(end_query)] of a candidate,
+//         resumed from the snapshot taken after step T0-1; no end-cell tracking
+template <int R, int MODE>
+__global__ __launch_bounds__(64) void sw_pk_kernel(SwArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x;
     const int g = lane >> 4, lig = lane & 15;
@@ -448,15 +489,47 @@ __global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
     Work wa, wb;
     wa.r_base = wb.r_base = 0; wa.q_base = wb.q_base = 0; wa.lq = wb.lq = 0; wa.lr = wb.lr = 0;
     wa.idx = wb.idx = 0; wa.flags = wb.flags = 0; wa.pad = wb.pad = 0;
-    if (itemA < a.n_items) wa = a.work[itemA];
-    if (itemB < a.n_items) wb = a.work[itemB];
+    uint32_t srcA = 0, srcB = 0, c0A = 0, c0B = 0;
+    int stepsA = 0, stepsB = 0;  // MODE 2: sweep steps to run for each half
+    uint64_t trace_off = (uint64_t)oct * a.quad_stride;
+    if constexpr (MODE == 2) {
+        int b = 0;
+        while (oct >= (int)a.tab.oct_first[b + 1]) b++;
+        const int local = oct - (int)a.tab.oct_first[b];
+        trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
+        const Cand *cl = a.cand + (uint64_t)b * a.tab.cap;
+        const int n_b = (int)a.tab.count[b];
+        const int kA = local * 8 + g * 2, kB = kA + 1;
+        // lane 0 feeds column T0 + tau at relative step tau: the staged "window" is columns [T0, end_ref]
+        if (kA < n_b) {
+            const Cand c = cl[kA];
+            srcA = c.src; c0A = c.c0;
+            wa = a.work[srcA];
+            const Fwd f = a.fwd[srcA];
+            stepsA = f.end_r + f.end_q / R - (int)c0A + 1;
+            wa.lr = (uint32_t)max(0, f.end_r + 1 - (int)c0A);
+            wa.r_base += c0A;
+        }
+        if (kB < n_b) {
+            const Cand c = cl[kB];
+            srcB = c.src; c0B = c.c0;
+            wb = a.work[srcB];
+            const Fwd f = a.fwd[srcB];
+            stepsB = f.end_r + f.end_q / R - (int)c0B + 1;
+            wb.lr = (uint32_t)max(0, f.end_r + 1 - (int)c0B);
+            wb.r_base += c0B;
+        }
+    } else {
+        if (itemA < a.n_items) wa = a.work[itemA];
+        if (itemB < a.n_items) wb = a.work[itemB];
+    }
     const int lqA = (int)wa.lq, lrA = (int)wa.lr, lqB = (int)wb.lq, lrB = (int)wb.lr;
-    int mx = max(lrA, lrB);
-    int maxlr = __builtin_amdgcn_readlane(mx, 0);
-    maxlr = max(maxlr, __builtin_amdgcn_readlane(mx, 16));
-    maxlr = max(maxlr, __builtin_amdgcn_readlane(mx, 32));
-    maxlr = max(maxlr, __builtin_amdgcn_readlane(mx, 48));
-    const int n_blocks = (maxlr + 15 + 3) >> 2;
+    int mx = (MODE == 2) ? max(stepsA, stepsB) : max(lrA, lrB) + 15;
+    int maxst = __builtin_amdgcn_readlane(mx, 0);
+    maxst = max(maxst, __builtin_amdgcn_readlane(mx, 16));
+    maxst = max(maxst, __builtin_amdgcn_readlane(mx, 32));
+    maxst = max(maxst, __builtin_amdgcn_readlane(mx, 48));
+    const int n_blocks = (maxst + 3) >> 2;
 
     // ---- stage both windows: 16 bits per column = classA*4 | classB*4 << 8
     uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
@@ -487,23 +560,59 @@ __global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
         profA[r] = pa;
         profB[r] = pb;
     }
-    __syncthreads();
 
     uint32_t Hl[R], Eh[R], bestA[R], bestB[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; bestA[r] = 0; bestB[r] = 0; }
     uint32_t hu_out = 0, fu_out = 0, hu_prev = 0;
     uint32_t rc = (PAD_CLASS * 4) | (PAD_CLASS * 4 << 8);
+    if constexpr (MODE == 2) {
+        // resume: the wave state pass 1 snapshotted after step T0-1, per half from that half's own octet
+        constexpr int CKD = ck_dwords(R);
+        const uint32_t laneA = ((srcA >> 1) & 3u) * 16u + (uint32_t)lig, laneB = ((srcB >> 1) & 3u) * 16u + (uint32_t)lig;
+        const uint32_t snA = c0A ? (c0A >> CK_SHIFT) - 1 : 0, snB = c0B ? (c0B >> CK_SHIFT) - 1 : 0;
+        const uint32_t *ckA = a.ckpt + (uint64_t)(srcA >> 3) * a.ck_stride + (uint64_t)snA * (CKD * 64) + laneA;
+        const uint32_t *ckB = a.ckpt + (uint64_t)(srcB >> 3) * a.ck_stride + (uint64_t)snB * (CKD * 64) + laneB;
+        const int shA = (srcA & 1u) ? 16 : 0, shB = (srcB & 1u) ? 16 : 0;
+        auto pick = [&](int k) -> uint32_t {
+            uint32_t va = 0, vb = 0;
+            if (c0A) va = (ckA[k * 64] >> shA) & 0xffffu;
+            if (c0B) vb = (ckB[k * 64] >> shB) & 0xffffu;
+            return va | (vb << 16);
+        };
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            Hl[r] = pick(r);
+            Eh[r] = pick(R + r);
+        }
+        hu_out = pick(2 * R);
+        fu_out = pick(2 * R + 1);
+        hu_prev = pick(2 * R + 2);
+        // the class register holds classA | classB << 8 in its low 16 bits
+        uint32_t ra = PAD_CLASS * 4, rb = PAD_CLASS * 4;
+        if (c0A) ra = (ckA[(2 * R + 3) * 64] >> ((srcA & 1u) ? 8 : 0)) & 0xffu;
+        if (c0B) rb = (ckB[(2 * R + 3) * 64] >> ((srcB & 1u) ? 8 : 0)) & 0xffu;
+        rc = ra | (rb << 8);
+    }
+    __syncthreads();
     const uint32_t ext8 = (uint32_t)(a.sc.ext * PK_SCALE) * 0x10001u;
     const uint32_t open8 = (uint32_t)(a.sc.open * PK_SCALE) * 0x10001u;
-    uint32_t *tq = a.trace + (uint64_t)oct * a.quad_stride + lane;
+    uint32_t *tq = a.trace + trace_off + lane;
+    uint32_t *ckw = a.ckpt + (uint64_t)oct * a.ck_stride + lane;
     const uint32_t himask = __builtin_amdgcn_readfirstlane(0xffff0000u);
 
-    for (int blk = 0; blk < n_blocks; blk++) {
+    // MODE 1 runs the blocks in groups of 8 (= CK_COLS steps) and snapshots between groups, so that the hot
+    // loop has the same shape in every mode
+    constexpr int GROUP = (MODE == 1) ? 8 : (1 << 30);
+    for (int blk0 = 0; blk0 < n_blocks; blk0 += GROUP) {
+    const int blk_end = (MODE == 1) ? min(n_blocks, blk0 + 8) : n_blocks;
+    for (int blk = blk0; blk < blk_end; blk++) {
         const uint64_t rw = *reinterpret_cast<const uint64_t *>(lref + blk * 4);
         uint32_t acc[R];
+        if constexpr (MODE != 1) {
 #pragma unroll
-        for (int k = 0; k < R; k++) acc[k] = 0;
+            for (int k = 0; k < R; k++) acc[k] = 0;
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int t = blk * 4 + s;
@@ -519,7 +628,6 @@ __global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
             for (int r = 0; r < R; r++) {
                 const uint32_t wA = __builtin_amdgcn_ubfe(profA[r], rc, 4);
                 const uint32_t wB = __builtin_amdgcn_ubfe(profB[r], rcB, 4);
-                // Dp = hd + 8*W' per half (no carry: each half stays below 2^15)
                 const uint32_t Dp = lshl_add<19>(wB, lshl_add<3>(wA, hd));
                 const uint32_t hl = Hl[r];
                 const uint32_t Ee = as_u32(as_s2(Eh[r]) - as_s2(ext8));
@@ -528,16 +636,20 @@ __global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
                 const uint32_t Fn = as_u32(__builtin_elementwise_max(as_s2(hu), as_s2(Fe)));
                 const uint32_t T = as_u32(__builtin_elementwise_max(__builtin_elementwise_max(as_s2(Dp), as_s2(En)), as_s2(Fn)));
                 const uint32_t H = as_u32(__builtin_elementwise_sub_sat(as_u2(T), as_u2(open8)));
-                // trace nibble: 8*(H!=D) + 4*(H!=F) + 2*(E opened) + 1*(F opened)
-                const uint32_t m1 = pk_min_k<8>(pk_sub(T, Dp));
-                const uint32_t m2 = pk_min_k<4>(pk_sub(T, Fn));
-                const uint32_t m3 = pk_min_k<2>(pk_sub(En, Ee));
-                const uint32_t m4 = pk_min_k<1>(pk_sub(Fn, Fe));
-                uint32_t &ac = acc[(s * R + r) >> 2];
-                ac = pk_shl4_add(ac, m1) + m2 + m3 + m4;
-                // end-cell keys: (H, 0xffff - t) per alignment
-                bestA[r] = max(bestA[r], (H << 16) | ct);
-                bestB[r] = max(bestB[r], and_or(H, himask, ct));
+                if constexpr (MODE != 1) {
+                    // trace nibble: 8*(H!=D) + 4*(H!=F) + 2*(E opened) + 1*(F opened)
+                    const uint32_t m1 = pk_min_k<8>(pk_sub(T, Dp));
+                    const uint32_t m2 = pk_min_k<4>(pk_sub(T, Fn));
+                    const uint32_t m3 = pk_min_k<2>(pk_sub(En, Ee));
+                    const uint32_t m4 = pk_min_k<1>(pk_sub(Fn, Fe));
+                    uint32_t &ac = acc[(s * R + r) >> 2];
+                    ac = pk_shl4_add(ac, m1) + m2 + m3 + m4;
+                }
+                if constexpr (MODE != 2) {
+                    // end-cell keys: (H, 0xffff - t) per alignment
+                    bestA[r] = max(bestA[r], (H << 16) | ct);
+                    bestB[r] = max(bestB[r], and_or(H, himask, ct));
+                }
                 hd = hl;
                 Hl[r] = H;
                 Eh[r] = En;
@@ -547,44 +659,66 @@ __global__ __launch_bounds__(64) void sw_forward_pk_kernel(SwArgs a) {
             hu_out = hu;
             fu_out = fu;
         }
-        uint32_t *tp = tq + (uint64_t)blk * (R * 64);
+        if constexpr (MODE != 1) {
+            uint32_t *tp = tq + (uint64_t)blk * (R * 64);
 #pragma unroll
-        for (int k = 0; k < R; k++) tp[k * 64] = acc[k];
+            for (int k = 0; k < R; k++) tp[k * 64] = acc[k];
+        }
+    }
+    if constexpr (MODE == 1) {
+        // snapshot of the wave state after step 32(k+1)-1
+        const int sn = blk0 >> 3;
+        if (blk_end == blk0 + 8 && sn < a.n_ck) {
+            constexpr int CKD = ck_dwords(R);
+            uint32_t *cp = ckw + (uint64_t)sn * (CKD * 64);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                cp[r * 64] = Hl[r];
+                cp[(R + r) * 64] = Eh[r];
+            }
+            cp[(2 * R) * 64] = hu_out;
+            cp[(2 * R + 1) * 64] = fu_out;
+            cp[(2 * R + 2) * 64] = hu_prev;
+            cp[(2 * R + 3) * 64] = rc;
+        }
+    }
     }
 
-    // ---- end cells (Appendix A.3) for A and B
-    uint32_t bka = 0, bkb = 0;
-    int browa = 0, browb = 0;
+    if constexpr (MODE != 2) {
+        // ---- end cells (Appendix A.3) for A and B
+        uint32_t bka = 0, bkb = 0;
+        int browa = 0, browb = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int row = lig * R + r;
-        if (row < lqA && bestA[r] > bka) { bka = bestA[r]; browa = row; }
-        if (row < lqB && bestB[r] > bkb) { bkb = bestB[r]; browb = row; }
-    }
-    uint64_t ca = (bka >> 16) ? ((((uint64_t)(bka + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browa)) : 0ull;
-    uint64_t cb = (bkb >> 16) ? ((((uint64_t)(bkb + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browb)) : 0ull;
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-        const uint64_t oa = __shfl_xor(ca, m, 64), ob = __shfl_xor(cb, m, 64);
-        ca = oa > ca ? oa : ca;
-        cb = ob > cb ? ob : cb;
-    }
-    if (lig == 0) {
-        if (itemA < a.n_items) {
-            Fwd f;
-            f.score = (int32_t)(ca >> 32) / PK_SCALE;
-            f.end_r = ca ? (int32_t)(0xffff - ((ca >> 16) & 0xffff)) : 0;
-            f.end_q = ca ? (int32_t)(0xffff - (ca & 0xffff)) : 0;
-            f.pad = 0;
-            a.fwd[itemA] = f;
+        for (int r = 0; r < R; r++) {
+            const int row = lig * R + r;
+            if (row < lqA && bestA[r] > bka) { bka = bestA[r]; browa = row; }
+            if (row < lqB && bestB[r] > bkb) { bkb = bestB[r]; browb = row; }
         }
-        if (itemB < a.n_items) {
-            Fwd f;
-            f.score = (int32_t)(cb >> 32) / PK_SCALE;
-            f.end_r = cb ? (int32_t)(0xffff - ((cb >> 16) & 0xffff)) : 0;
-            f.end_q = cb ? (int32_t)(0xffff - (cb & 0xffff)) : 0;
-            f.pad = 0;
-            a.fwd[itemB] = f;
+        uint64_t ca = (bka >> 16) ? ((((uint64_t)(bka + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browa)) : 0ull;
+        uint64_t cb = (bkb >> 16) ? ((((uint64_t)(bkb + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browb)) : 0ull;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            const uint64_t oa = __shfl_xor(ca, m, 64), ob = __shfl_xor(cb, m, 64);
+            ca = oa > ca ? oa : ca;
+            cb = ob > cb ? ob : cb;
+        }
+        if (lig == 0) {
+            if (itemA < a.n_items) {
+                Fwd f;
+                f.score = (int32_t)(ca >> 32) / PK_SCALE;
+                f.end_r = ca ? (int32_t)(0xffff - ((ca >> 16) & 0xffff)) : 0;
+                f.end_q = ca ? (int32_t)(0xffff - (ca & 0xffff)) : 0;
+                f.pad = 0;
+                a.fwd[itemA] = f;
+            }
+            if (itemB < a.n_items) {
+                Fwd f;
+                f.score = (int32_t)(cb >> 32) / PK_SCALE;
+                f.end_r = cb ? (int32_t)(0xffff - ((cb >> 16) & 0xffff)) : 0;
+                f.end_q = cb ? (int32_t)(0xffff - (cb & 0xffff)) : 0;
+                f.pad = 0;
+                a.fwd[itemB] = f;
+            }
         }
     }
 }
@@ -604,7 +738,12 @@ struct TbArgs {
     uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
-    int32_t packed;         // trace written by sw_forward_pk_kernel (octets) instead of sw_forward_kernel (quads)
+    int32_t packed;         // trace written by the packed kernel (octets) instead of sw_forward_kernel (quads)
+    // two-pass path: item k is candidate cand[k]; its trace starts at column c0; results go to out[src]
+    const Cand *cand;
+    Cand *incomplete;       // candidates whose path leaves the traced steps ...
+    uint32_t *incomplete_n; // ... are listed here (with the T0 they had) and re-run from further back
+    P2Table tab;            // with cand: thread k serves slot k & 7 of wave k >> 3
 };
 
 __device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int g, int i, int j) {
@@ -625,13 +764,30 @@ __device__ __forceinline__ uint32_t trace_nibble_pk(const uint32_t *to, int R, i
 
 __global__ void traceback_kernel(TbArgs a) {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= a.n_items) return;
-    const Work w = a.work[item];
-    const Fwd f = a.fwd[item];
+    int src = item, c0 = 0;
+    uint64_t trace_off;
+    if (a.cand) {
+        const int oct = item >> 3;
+        int b = 0;
+        if (oct >= (int)a.tab.oct_first[NUM_BUCKETS]) return;
+        while (oct >= (int)a.tab.oct_first[b + 1]) b++;
+        const int local = oct - (int)a.tab.oct_first[b];
+        const int k = local * 8 + (item & 7);
+        if (k >= (int)a.tab.count[b]) return;
+        const Cand c = a.cand[(uint64_t)b * a.tab.cap + k];
+        src = (int)c.src;
+        c0 = (int)c.c0;
+        trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
+    } else {
+        if (item >= a.n_items) return;
+        trace_off = (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
+    }
+    const Work w = a.work[src];
+    const Fwd f = a.fwd[src];
     const int R = a.R;
     const int g = a.packed ? ((item >> 1) & 3) : (item & 3);
     const int half = item & 1;
-    const uint32_t *tq = a.trace + (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
+    const uint32_t *tq = a.trace + trace_off;
     const int lq = (int)w.lq;
     const bool rcq = w.flags & 1u;
     const int32_t open = a.sc.open, ext = a.sc.ext;
@@ -645,11 +801,13 @@ __global__ void traceback_kernel(TbArgs a) {
     uint32_t cur_len = 0;
     int i = f.end_q, j = f.end_r, state = 0;
     int32_t h = f.score;
+    bool done = false, left_range = false;  // path ended (H reached 0) / path left the traced steps
     while (i >= 0 && j >= 0) {
-        const uint32_t nb = a.packed ? trace_nibble_pk(tq, R, g, half, i, j) : trace_nibble(tq, R, g, i, j);
+        if (c0 > 0 && j + i / R < c0) { left_range = true; break; }  // cell (i, j) was computed at step j + i/R
+        const uint32_t nb = a.packed ? trace_nibble_pk(tq, R, g, half, i, j - c0) : trace_nibble(tq, R, g, i, j);
         int op;
         if (state == 0) {
-            if (h == 0) break;
+            if (h == 0) { done = true; break; }
             if (!(nb & 8u)) {  // H == D
                 uint32_t qc = rcq ? lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)(lq - 1 - i)))
                                   : nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)i);
@@ -690,6 +848,15 @@ __global__ void traceback_kernel(TbArgs a) {
         n_runs++;
     }
 
+    if (left_range && !(state == 0 && h == 0)) {
+        // the path continues before step T0: this candidate is re-run from the start of the sweep
+        const uint32_t k = atomicAdd(a.incomplete_n, 1u);
+        Cand again;
+        again.src = (uint32_t)src;
+        again.c0 = (uint32_t)c0;
+        a.incomplete[k] = again;
+        return;
+    }
     fadehip_aln o;
     o.read_idx = (int32_t)w.idx;
     o.art = 0;
@@ -726,7 +893,7 @@ __global__ void traceback_kernel(TbArgs a) {
     o.sw.n_ops = n;
 
     if (a.meta) {
-        const Meta m = a.meta[item];
+        const Meta m = a.meta[src];
         o.win_start = m.win_start;
         o.win_len = (int32_t)w.lr;
         o.clip_left = m.clip_left;
@@ -751,7 +918,90 @@ __global__ void traceback_kernel(TbArgs a) {
         o.win_len = (int32_t)w.lr;
         o.clip_left = o.clip_right = o.aligned_len = 0;
     }
-    a.out[item] = o;
+    a.out[src] = o;
+}
+
+// ---------------------------------------------------------------- pass-2 selection
+// After pass 1 every alignment has score and end cell.  Level 2: only alignments that can still become an
+// artifact call need a CIGAR — left: clip > floor, 5*score > 9*clip and the end cell in the last query row
+// (analysis.d:74-80 needs the last op to be '=' with no trailing S); right: clip > floor, 5*score > 9*clip and
+// end cell above the last row (analysis.d:102-104 needs a trailing S).  Everything else gets its record
+// here with n_ops = 0 ("not traced").  Level 1 (meta == nullptr) traces everything.
+struct SelArgs {
+    const Work *work;
+    const Meta *meta;
+    const Fwd *fwd;
+    int32_t n_items;
+    int32_t floor_len;
+    int32_t trace_all;
+    int32_t R;
+    Cand *cand;             // [NUM_BUCKETS][cap]
+    uint32_t cap;
+    uint32_t *bucket_n;     // [NUM_BUCKETS]
+    fadehip_aln *out;
+};
+
+__global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_cnt[NUM_BUCKETS], s_base[NUM_BUCKETS];
+    if (threadIdx.x < NUM_BUCKETS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int b = -1;
+    uint32_t local_slot = 0;
+    Cand c;
+    c.src = 0;
+    c.c0 = 0;
+    if (item < a.n_items) {
+        const Work w = a.work[item];
+        const Fwd f = a.fwd[item];
+        bool cand = true;
+        if (a.meta && !a.trace_all) {
+            const Meta m = a.meta[item];
+            const bool left = m.clip_left > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_left &&
+                              f.end_q == (int32_t)w.lq - 1;
+            const bool right = m.clip_right > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_right &&
+                               f.end_q < (int32_t)w.lq - 1;
+            cand = left || right;
+            if (!cand) {
+                fadehip_aln o;
+                o.read_idx = (int32_t)w.idx;
+                o.art = 0;
+                o.win_start = m.win_start;
+                o.win_len = (int32_t)w.lr;
+                o.clip_left = m.clip_left;
+                o.clip_right = m.clip_right;
+                o.aligned_len = m.aligned_len;
+                o.sw.score = f.score;
+                o.sw.end_query = f.end_q;
+                o.sw.end_ref = f.end_r;
+                o.sw.beg_query = -1;
+                o.sw.beg_ref = -1;
+                o.sw.n_ops = 0;
+                for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+                a.out[item] = o;
+            }
+        }
+        if (cand) {
+            // sweep steps the path is expected to span: a cell (i, j) is computed at step j + i / R.  Columns:
+            // score/2 for clean matches, a quarter more for mismatches, + slack; rows ~ columns.  Any value is
+            // correct (a path that leaves the traced steps is re-run from step 0), this one is cheap.
+            const int span_cols = f.score / 2 + f.score / 8 + 24;
+            const int span = span_cols + span_cols / a.R + 2;
+            const int t_end = f.end_r + f.end_q / a.R;
+            int c0 = t_end + 1 - span;
+            c0 = c0 < CK_COLS ? 0 : (c0 & ~(CK_COLS - 1));
+            const int steps = t_end + 1 - c0;
+            b = 0;
+            while (steps > bucket_cols(b)) b++;
+            c.src = (uint32_t)item;
+            c.c0 = (uint32_t)c0;
+            local_slot = atomicAdd(&s_cnt[b], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NUM_BUCKETS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bucket_n[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (b >= 0) a.cand[(uint64_t)b * a.cap + s_base[b] + local_slot] = c;
 }
 
 // ---------------------------------------------------------------- stats.d:45-54 over rs

@@ -61,7 +61,10 @@ typedef struct {
     int32_t mismatch;  /* -3 */
     int32_t max_ref_len;   /* longest reference window accepted; 0 -> 8192 */
     int32_t max_batch_reads; /* capacity of one annotate batch; 0 -> 1<<20 */
-    int64_t trace_bytes;   /* device bytes reserved for trace tables; 0 -> sized on demand */
+    int64_t trace_bytes;   /* device bytes reserved for trace tables / checkpoints; 0 -> sized on demand */
+    int32_t trace_all;     /* 1: level 2 returns a CIGAR for every re-aligned read (default: only for reads whose
+                              score and end cell can still pass FADE's gates; the others have sw.n_ops == 0) */
+    int32_t reserved;
 } fadehip_params;
 
 void fadehip_params_default(fadehip_params *p);
@@ -112,7 +115,9 @@ typedef struct {
     const uint8_t *seq_packed; /* BAM 4-bit sequence bytes, each record byte-aligned */
 } fadehip_read_batch;
 
-/* One entry per read that was re-aligned (clip longer than min-length), in no particular order. */
+/* One entry per read that was re-aligned (clip longer than min-length), in no particular order.
+ * sw.score / end_query / end_ref are always set.  Unless params.trace_all, the traceback (beg_*, ops)
+ * is only run when the result can still be an artifact call; otherwise sw.n_ops == 0, beg_* == -1. */
 typedef struct {
     int32_t read_idx;
     int32_t art;         /* bit0 art_left, bit1 art_right (analysis.d:82,106) */

@@ -36,8 +36,11 @@ def test_full_size_batch_properties(oracle, name, n):
     sw = aln["sw"]
     lq = cfg["read_len"]
     assert (sw["score"] >= 0).all() and (sw["score"] <= 2 * lq).all()
-    assert (sw["beg_ref"] >= 0).all() and (sw["end_ref"] < aln["win_len"]).all() and (sw["beg_ref"] <= sw["end_ref"] + 1).all()
-    ok = sw["n_ops"] <= 16
+    assert (sw["end_ref"] < aln["win_len"]).all() and (sw["beg_ref"] <= sw["end_ref"] + 1).all()
+    traced = sw["n_ops"] > 0  # untraced = cannot be an artifact (include/fadehip.h)
+    assert (art[aln["read_idx"]][~traced] == 0).all() and traced.sum() >= (aln["art"] != 0).sum()
+    assert ((sw["beg_ref"] >= 0) == traced).all()
+    ok = traced & (sw["n_ops"] <= 16)
     qlen = np.zeros(len(aln), dtype=np.int64)
     for k in range(16):
         op, ln = sw["ops"][:, k] & 15, sw["ops"][:, k] >> 4
