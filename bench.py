@@ -23,7 +23,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # int VALU issue: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured by fade_amd/csrc/bench/valu_peak.hip: one
 # wave-instruction per 4 cycles per SIMD for v_pk_*, v_add/max, v_bfe, DPP moves alike)
 VALU_PEAK_TLANE = 39.3
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_twopass_pmc_summary.json")
 
 
 def pmc_traffic(workload, kernel_prefix):
@@ -161,7 +161,7 @@ def main():
         achieved = prof["algorithmic_bytes"] / (fwd * 1e-3) / 1e9
         workload = "%s: %d x %d bp PE reads per GPU per step, -w %d, --min-length %d, p_softclip %.2f" % (
             args.config, args.batch_reads, cfg["read_len"], cfg["window"], cfg["floor_len"], cfg["p_sc"])
-        traffic, pmc = pmc_traffic(workload, "sw_forward")
+        traffic, pmc = pmc_traffic(workload, "sw_pk_kernel<10, 1>")
         out = {
             "metric": "annotate reads/sec at 1/2/4/8 MI355X; rs/am tag bit-exact vs ref",
             "value": total_reads / dt_max,
@@ -178,7 +178,7 @@ def main():
             "config": {"workload": workload,
                        "alignments_per_step": int(prof["alignments"]), "dp_cells_per_step": int(prof["cells"]),
                        "slots_in_flight": n_slots},
-            "roofline": {"bound": "hbm", "kernel": "sw_forward_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "sw_pk_kernel<10,1> (score pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(prof["algorithmic_bytes"]),
                          "kernel_ms": fwd, "gcups": prof["cells"] / (fwd * 1e-3) / 1e9},
@@ -187,7 +187,7 @@ def main():
                 "bound": "valu_int_issue", "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s",
                 "achieved": pmc["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12,
                 "frac": pmc["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12 / VALU_PEAK_TLANE,
-                "valu_busy_frac_pmc": pmc["valu_busy_frac"], "source": "profiles/r01_pmc_summary.json"},
+                "valu_busy_frac_pmc": pmc["valu_busy_frac"], "source": "profiles/r01_twopass_pmc_summary.json"},
             "kernels_ms": {"gate": float(np.mean(gate_ms)), "sw_forward": fwd, "traceback": float(np.mean(tb_ms))},
             "stats": {k: int(v) for k, v in zip(
                 ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"], st.tolist())},

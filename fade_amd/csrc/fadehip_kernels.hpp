@@ -479,8 +479,11 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 // MODE 1: pass 1 — score and end cell only, plus a snapshot of the wave state every CK_COLS steps
 // MODE 2: pass 2 — traced re-computation of sweep steps [T0, end_ref + lane(end_query)] of a candidate,
 //         resumed from the snapshot taken after step T0-1; no end-cell tracking
+// waves per SIMD asked of the register allocator for the score pass (the other modes are left alone)
+__host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return (MODE == 1 && R <= 10) ? 5 : 1; }
+
 template <int R, int MODE>
-__global__ __launch_bounds__(64) void sw_pk_kernel(SwArgs a) {
+__global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x;
     const int g = lane >> 4, lig = lane & 15;
