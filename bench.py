@@ -173,7 +173,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "int16",
             "data": "synthetic",
             "config": {"workload": workload,
                        "alignments_per_step": int(prof["alignments"]), "dp_cells_per_step": int(prof["cells"]),

@@ -63,6 +63,7 @@ struct fadehip_ctx {
     // FADEHIP_KERNEL = twopass (default) | pk (single-pass packed int16) | int32 (single-pass int32): A/B runs
     bool use_packed = true;
     bool two_pass = true;
+    int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
 };
 
 namespace {
@@ -266,6 +267,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         sel.floor_len = floor_len;
         sel.trace_all = ctx->prm.trace_all;
         sel.R = R;
+        sel.span_slack = ctx->span_slack;
         sel.cand = (Cand *)s.cand.p;
         sel.cap = (uint32_t)n;
         sel.bucket_n = (uint32_t *)s.sel_counters.p;
@@ -528,6 +530,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         ctx->use_packed = strcmp(kv, "int32") != 0;
         ctx->two_pass = strcmp(kv, "twopass") == 0;
     }
+    if (const char *kv = getenv("FADEHIP_SPAN_SLACK")) ctx->span_slack = atoi(kv);
     uint8_t table[256];
     fill_ascii_table(table);
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_ascii_code), table, 256) != hipSuccess) {

@@ -938,6 +938,7 @@ struct SelArgs {
     int32_t floor_len;
     int32_t trace_all;
     int32_t R;
+    int32_t span_slack;     // columns added to the expected path span (24; tests shrink it to force re-runs)
     Cand *cand;             // [NUM_BUCKETS][cap]
     uint32_t cap;
     uint32_t *bucket_n;     // [NUM_BUCKETS]
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
             // sweep steps the path is expected to span: a cell (i, j) is computed at step j + i / R.  Columns:
             // score/2 for clean matches, a quarter more for mismatches, + slack; rows ~ columns.  Any value is
             // correct (a path that leaves the traced steps is re-run from step 0), this one is cheap.
-            const int span_cols = f.score / 2 + f.score / 8 + 24;
+            const int span_cols = a.span_slack >= 0 ? f.score / 2 + f.score / 8 + a.span_slack : 1;
             const int span = span_cols + span_cols / a.R + 2;
             const int t_end = f.end_r + f.end_q / a.R;
             int c0 = t_end + 1 - span;

@@ -180,3 +180,42 @@ def test_limits_fail_loudly(ctx):
     empty = synth.take(ok, np.arange(0))
     rs, aln, stats = ctx.annotate(empty, 5, 100)
     assert len(rs) == 0 and len(aln) == 0 and int(stats[0]) == 0
+
+
+@pytest.mark.parametrize("slack", ["-1", "0"])
+def test_two_pass_rerun_paths(oracle, slack, monkeypatch):
+    """The pass-2 range is a heuristic; correctness must not depend on it.  With the slack removed most paths
+    leave their traced steps and go through the re-run rounds (4 snapshots back, then from step 0)."""
+    monkeypatch.setenv("FADEHIP_SPAN_SLACK", slack)
+    monkeypatch.setenv("FADEHIP_DEBUG", "1")
+    c = fade_amd.Context(device=0)
+    try:
+        for name, n in (("C2", 6000), ("C3", 2500)):
+            cfg, g, b = synth.make_config(name, n, contig_len=300_000)
+            _compare(c, oracle, g.names, [a.tobytes().decode() for a in g.ascii_contigs()], b, cfg["floor_len"], cfg["window"])
+        # level 1: every pair is traced; long related pairs make long paths
+        from helpers import concat, make_pairs
+        rng = np.random.default_rng(5)
+        qs, rs_ = make_pairs(rng, 700, kinds=("related", "planted", "tandem", "random"))
+        qc, qo = concat(qs)
+        rc, ro = concat(rs_)
+        got = c.sw_batch_packed(qc, qo, rc, ro)
+        exp, exp_ops = oracle.sw_batch(qc, qo, rc, ro, threads=8, max_ops=16, striped=True)
+        for k in range(len(qs)):
+            assert tuple(int(got[k][f]) for f in ("score", "end_query", "end_ref", "beg_query", "beg_ref", "n_ops")) == tuple(int(x) for x in exp[k]), k
+            m = min(int(exp[k][5]), 16)
+            assert list(got[k]["ops"][:m]) == list(exp_ops[k][:m]), k
+    finally:
+        c.close()
+
+
+def test_single_pass_kernels_agree(oracle, monkeypatch):
+    """FADEHIP_KERNEL=pk / int32 (the single-pass kernels kept for A/B runs) give the same answers."""
+    cfg, g, b = synth.make_config("C2", 5000, contig_len=300_000)
+    for k in ("pk", "int32", "twopass"):
+        monkeypatch.setenv("FADEHIP_KERNEL", k)
+        c = fade_amd.Context(device=0)
+        try:
+            _compare(c, oracle, g.names, [a.tobytes().decode() for a in g.ascii_contigs()], b, cfg["floor_len"], cfg["window"])
+        finally:
+            c.close()
