@@ -469,6 +469,122 @@ static int annotate_main(const std::string &cl, const Opts &o) {
     return 0;
 }
 
+static void print_extract_help() {
+    fprintf(stderr,
+            "%s\nextract: extracts artifacts into a mapped SAM/BAM (used after annotate)\n"
+            "usage: fade extract [options] <annotated BAM/SAM> \n\n"
+            "-t --threads extra threads for parsing the bam file\n"
+            "-b     --bam output bam\n"
+            "-u    --ubam output uncompressed bam\n"
+            "-h    --help This help information.\n\n",
+            kHeader);
+}
+
+static bool parse_cigar_string(const std::string &s, std::vector<uint32_t> &ops) {
+    uint64_t num = 0;
+    bool have = false;
+    for (char c : s) {
+        if (c >= '0' && c <= '9') { num = num * 10 + (uint64_t)(c - '0'); have = true; }
+        else {
+            const char *o = strchr(CIGAR_STR, c);
+            if (!o || !have) return false;
+            ops.push_back((uint32_t)(num << 4) | (uint32_t)(o - CIGAR_STR));
+            num = 0;
+            have = false;
+        }
+    }
+    return !have;
+}
+
+// source/remap.d:11-87 — `fade extract`: one new mapped record per artifact side, built from the am tag
+// (contig, 0-based pos, CIGAR), carrying the reverse-complemented read and its reversed qualities.  Pure host
+// work: it consumes what the annotate path wrote and so validates the am grammar end to end.
+static int extract_main(const std::string &cl, const Opts &o) {
+    fprintf(stderr, "[W::fade extract] Output SAM/BAM will not be sorted\n");  // remap.d:13
+    const int nthreads = o.threads > 0 ? o.threads : 2;
+    Pool pool(nthreads), wpool(nthreads);
+    try {
+        Reader reader(o.pos[1], &pool);  // remap.d:17
+        Header hdr = reader.header();
+        hdr.add_pg("fade-extract", "fade", FADE_VERSION, cl);  // remap.d:18-26
+        const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;
+        Writer writer(stdout, fmt, hdr, &wpool);
+        static const uint8_t comp[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+        std::vector<Rec> in, out;
+        for (;;) {
+            in.clear();
+            out.clear();
+            if (reader.read_chunk(in, 65536) == 0) break;
+            for (const Rec &r : in) {
+                const size_t prs = r.aux_find("rs");  // remap.d:31-33
+                if (prs == std::string::npos) continue;
+                uint32_t rsv = 0;
+                const uint8_t ty = r.d[prs + 2];
+                if (ty == 'C' || ty == 'c') rsv = r.d[prs + 3];
+                else if (ty == 'S' || ty == 's') rsv = r.rd<uint16_t>(prs + 3);
+                else if (ty == 'I' || ty == 'i') rsv = r.rd<uint32_t>(prs + 3);
+                else continue;
+                rsv &= 0xff;
+                if (!(rsv & 6)) continue;  // remap.d:36-37
+                const size_t pam = r.aux_find("am");  // remap.d:38-40
+                if (pam == std::string::npos || r.d[pam + 2] != 'Z') continue;
+                const std::string am((const char *)r.d.data() + pam + 3);
+                const size_t semi = am.find(';');
+                const std::string sides[2] = {am.substr(0, semi), semi == std::string::npos ? std::string() : am.substr(semi + 1)};
+                for (int side = 0; side < 2; side++) {
+                    if (!(rsv & (side == 0 ? 2u : 4u))) continue;  // remap.d:43,64
+                    const std::string &f = sides[side];
+                    const size_t c1 = f.find(','), c2 = c1 == std::string::npos ? c1 : f.find(',', c1 + 1);
+                    if (c2 == std::string::npos) throw std::runtime_error("malformed am tag: " + am);
+                    const int tid = reader.header().tid_of(f.substr(0, c1));
+                    const int64_t pos = std::strtoll(f.c_str() + c1 + 1, nullptr, 10);
+                    std::vector<uint32_t> cig;
+                    if (!parse_cigar_string(f.substr(c2 + 1), cig)) throw std::runtime_error("malformed am CIGAR: " + am);
+                    const int lq = r.l_seq();
+                    const size_t lqn = (size_t)r.l_qname();
+                    Rec n;
+                    n.d.assign(32 + lqn + 4 * cig.size() + ((size_t)lq + 1) / 2 + (size_t)lq, 0);
+                    int64_t reflen = 0;
+                    for (uint32_t c : cig) {
+                        const uint32_t op = c & 15;
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += c >> 4;
+                    }
+                    n.wr<int32_t>(0, tid);                       // remap.d:49
+                    n.wr<int32_t>(4, (int32_t)pos);              // remap.d:50 (ZB: am holds a 0-based position)
+                    n.d[8] = (uint8_t)lqn;
+                    n.d[9] = 0;                                  // a fresh bam1_t: mapq 0
+                    n.wr<uint16_t>(10, (uint16_t)reg2bin(pos < 0 ? 0 : pos, (pos < 0 ? 0 : pos) + (reflen > 0 ? reflen : 1)));
+                    n.wr<uint16_t>(12, (uint16_t)cig.size());
+                    n.wr<uint16_t>(14, (uint16_t)((r.flag() & 0x10) ? 0 : 0x10));  // remap.d:51-58
+                    n.wr<int32_t>(16, lq);
+                    n.wr<int32_t>(20, 0);                        // bam_init1 zero-fills: mtid 0, mpos 0, isize 0
+                    n.wr<int32_t>(24, 0);
+                    n.wr<int32_t>(28, 0);
+                    memcpy(n.d.data() + 32, r.qname(), lqn);     // remap.d:48
+                    size_t off = 32 + lqn;
+                    if (!cig.empty()) memcpy(n.d.data() + off, cig.data(), 4 * cig.size());  // remap.d:61
+                    off += 4 * cig.size();
+                    const uint8_t *sq = r.seq(), *ql = r.qual();
+                    for (int j = 0; j < lq; j++) {               // remap.d:59 reverse_complement_sam_record
+                        const int code = (sq[j >> 1] >> ((~j & 1) << 2)) & 15;
+                        const int k = lq - 1 - j;
+                        n.d[off + (size_t)(k >> 1)] |= (uint8_t)(comp[code] << ((~k & 1) << 2));
+                    }
+                    off += ((size_t)lq + 1) / 2;
+                    for (int j = 0; j < lq; j++) n.d[off + (size_t)j] = ql[lq - 1 - j];  // remap.d:60
+                    out.push_back(std::move(n));
+                }
+            }
+            writer.write(out);
+        }
+        writer.close();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "[E::fade extract] %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     std::string cl;  // app.d:66
     for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
@@ -494,7 +610,21 @@ int main(int argc, char **argv) {
         }
         return annotate_main(cl, o);
     }
-    if (sub == "out" || sub == "extract" || sub == "stats" || sub == "stats-clip") {
+    if (sub == "extract") {  // app.d:130-153
+        Opts o;
+        std::string err;
+        if (!parse_opts(argc, argv, o, err)) {
+            fprintf(stderr, "std.getopt.GetOptException: %s\n", err.c_str());
+            return 1;
+        }
+        if (o.help || o.pos.size() < 2) { print_extract_help(); return 0; }
+        if (o.bam && o.ubam) {
+            fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");  // app.d:149 (sic)
+            return 1;
+        }
+        return extract_main(cl, o);
+    }
+    if (sub == "out" || sub == "stats" || sub == "stats-clip") {
         fprintf(stderr, "[E::fade] %s is outside the MI355X annotate hot path; run the reference fade for it\n", sub.c_str());
         return 1;
     }
