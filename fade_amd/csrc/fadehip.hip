@@ -289,16 +289,18 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
             uint32_t oct = 0;
             size_t lds2 = 0;
             int ref_stride2 = 16;
-            for (int b = 0; b < NUM_BUCKETS; b++) {
-                tab.oct_first[b] = oct;
-                if (b >= nb || !counts[b]) continue;
+            for (int k = 0; k < NUM_BUCKETS; k++) {
+                const int b = nb - 1 - k;  // longest bucket first
+                tab.oct_first[k] = oct;
+                if (b < 0 || !counts[b]) continue;
                 int nb2, rs2;
                 uint64_t st2;
                 size_t l2;
                 strides(steps_max[b], &nb2, &st2, &rs2, &l2);
-                tab.count[b] = counts[b];
-                tab.trace_base[b] = off;
-                tab.stride[b] = st2;
+                tab.count[k] = counts[b];
+                tab.bucket[k] = (uint32_t)b;
+                tab.trace_base[k] = off;
+                tab.stride[k] = st2;
                 const uint32_t octs_b = (counts[b] + 7) / 8;
                 off += (uint64_t)octs_b * st2;
                 oct += octs_b;

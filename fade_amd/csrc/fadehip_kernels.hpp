@@ -260,12 +260,14 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
 }
 
 // ---------------------------------------------------------------- forward SW with trace
-// Pass 2 runs all buckets in one launch: wave `oct` belongs to the bucket b with oct_first[b] <= oct <
-// oct_first[b+1]; its candidates are cand[b * cap + 8 * (oct - oct_first[b]) ...] and its trace scratch starts at
-// trace_base[b] + (oct - oct_first[b]) * stride[b] dwords.
+// Pass 2 runs all buckets in one launch, longest first (the dispatcher hands waves out in order, so the short
+// ones fill the tail): wave `oct` belongs to table slot k with oct_first[k] <= oct < oct_first[k+1]; its
+// candidates are cand[bucket[k] * cap + 8 * (oct - oct_first[k]) ...] and its trace scratch starts at
+// trace_base[k] + (oct - oct_first[k]) * stride[k] dwords.
 struct P2Table {
     uint32_t oct_first[NUM_BUCKETS + 1];
     uint32_t count[NUM_BUCKETS];
+    uint32_t bucket[NUM_BUCKETS];
     uint64_t trace_base[NUM_BUCKETS];
     uint64_t stride[NUM_BUCKETS];
     uint32_t cap;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         while (oct >= (int)a.tab.oct_first[b + 1]) b++;
         const int local = oct - (int)a.tab.oct_first[b];
         trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
-        const Cand *cl = a.cand + (uint64_t)b * a.tab.cap;
+        const Cand *cl = a.cand + (uint64_t)a.tab.bucket[b] * a.tab.cap;
         const int n_b = (int)a.tab.count[b];
         const int kA = local * 8 + g * 2, kB = kA + 1;
         // lane 0 feeds column T0 + tau at relative step tau: the staged "window" is columns [T0, end_ref]
@@ -777,7 +779,7 @@ __global__ void traceback_kernel(TbArgs a) {
         const int local = oct - (int)a.tab.oct_first[b];
         const int k = local * 8 + (item & 7);
         if (k >= (int)a.tab.count[b]) return;
-        const Cand c = a.cand[(uint64_t)b * a.tab.cap + k];
+        const Cand c = a.cand[(uint64_t)a.tab.bucket[b] * a.tab.cap + k];
         src = (int)c.src;
         c0 = (int)c.c0;
         trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
