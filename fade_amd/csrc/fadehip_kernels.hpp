@@ -6,12 +6,18 @@
 //   source/analysis.d:67       p.sw_striped(q_seq, ref_seq)  (libparasail, un-vendored)  sw_forward_kernel + traceback_kernel
 //   source/analysis.d:69-83,98-107  artifact gates, ReadStatus bits (readstatus.d:5-26) traceback_kernel
 //
-// Execution model: integer DP, no MFMA.  One wavefront = 4 alignments ("quad"),
-// 16 lanes each; a lane owns R consecutive query rows (16*R >= Lq) and the 16 lanes sweep the
-// reference window as an anti-diagonal wave.  Neighbour exchange is DPP row_shr:1, whose zero
-// fill at each 16-lane row boundary IS the DP boundary condition.  The reference window is staged
-// once into LDS as pre-shifted class codes; the 4-bit/cell trace leaves the wave as fully coalesced
-// 256-byte stores.
+// Execution model: integer DP, no MFMA.  A 16-lane DPP row owns one alignment (int32 kernel,
+// 4 per wave) or two packed as int16 halves (packed kernel, 8 per wave); a lane owns R consecutive query rows
+// (16*R >= Lq) and the 16 lanes sweep the reference window as an anti-diagonal wave.  Neighbour exchange is
+// DPP row_shr:1, whose zero fill at each 16-lane row boundary IS the DP boundary condition.  The reference
+// window is staged once into LDS as pre-shifted class codes; the 4-bit/cell trace leaves the wave as fully
+// coalesced 256-byte stores.
+//
+// Default pipeline (two-pass):
+//   gate_kernel -> sw_pk_kernel<R,1> (score + end cell + wave snapshots) -> select_kernel (who needs a CIGAR,
+//   from which step) -> sw_pk_kernel<R,2> (traced re-computation of those steps) -> traceback_kernel (CIGAR,
+//   FADE's gates, rs bits) -> stats_kernel.  sw_pk_kernel<R,0> and sw_forward_kernel<R> are the single-pass
+//   packed / int32 variants kept for A/B measurements (FADEHIP_KERNEL=pk|int32).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -477,7 +483,7 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
 
 constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and log2(8) + 16
 
-// MODE 0: single pass — full window, trace to memory, end cell (sw_forward_pk_kernel of round-1 v3)
+// MODE 0: single pass — full window, trace to memory, end cell
 // MODE 1: pass 1 — score and end cell only, plus a snapshot of the wave state every CK_COLS steps
 // MODE 2: pass 2 — traced re-computation of sweep steps [T0, end_ref + lane(end_query)] of a candidate,
 //         resumed from the snapshot taken after step T0-1; no end-cell tracking
@@ -744,7 +750,7 @@ struct TbArgs {
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
     int32_t packed;         // trace written by the packed kernel (octets) instead of sw_forward_kernel (quads)
-    // two-pass path: item k is candidate cand[k]; its trace starts at column c0; results go to out[src]
+    // two-pass path: thread k serves a candidate whose trace starts at sweep step c0; results go to out[src]
     const Cand *cand;
     Cand *incomplete;       // candidates whose path leaves the traced steps ...
     uint32_t *incomplete_n; // ... are listed here (with the T0 they had) and re-run from further back

@@ -151,9 +151,10 @@ int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out);
 int fadehip_sync(fadehip_ctx *ctx);
 
 /* Measurement: device time of the last run on `slot`, from hipEvents recorded on the slot's
- * stream around each kernel.  ms[0] gate, ms[1] forward SW (dominant), ms[2] traceback+gates,
- * ms[3] whole run.  counts[0] alignments, counts[1] DP cells, counts[2] trace bytes written,
- * counts[3] algorithmic bytes of the forward kernel. */
+ * stream around the kernels.  ms[0] gate, ms[1] the dominant kernel (the score pass; the single forward kernel
+ * under FADEHIP_KERNEL=pk|int32), ms[2] everything after it up to the artifact gates (selection, traced pass 2,
+ * traceback, re-runs), ms[3] whole run.  counts[0] alignments, counts[1] DP cells, counts[2] trace scratch
+ * bytes, counts[3] algorithmic bytes of the dominant kernel. */
 int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[4]);
 
 /* Sum counters over the ranks' devices with one ncclAllReduce (RCCL) — single process, one ctx
