@@ -1,0 +1,106 @@
+/// extern(C) binding of include/fadehip.h (ABI version 1) for the D host of blachlylab/fade.
+///
+/// NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no D compiler (ldc2, dmd, gdc, dub are
+/// all absent) and none of FADE's dependencies, so this file has never been compiled or run.  It mirrors
+/// include/fadehip.h declaration by declaration; the same ABI is exercised from C++ (fade_amd/csrc/host) and
+/// from Python/ctypes (fade_amd/_lib.py) by the test suite.
+module fadehip;
+
+extern (C) nothrow @nogc:
+
+enum FADEHIP_ABI_VERSION = 1;
+enum FADEHIP_MAX_OPS = 16;
+enum FADEHIP_MAX_QUERY = 512;
+enum FADEHIP_NUM_SLOTS = 2;
+
+enum : int
+{
+    FADEHIP_OK = 0,
+    FADEHIP_E_INVALID = -1,
+    FADEHIP_E_NODEVICE = -2,
+    FADEHIP_E_HIP = -3,
+    FADEHIP_E_NOMEM = -4,
+    FADEHIP_E_UNSUPPORTED = -5,
+    FADEHIP_E_STATE = -6,
+    FADEHIP_E_RESIDUE = -7,
+    FADEHIP_E_RCCL = -8
+}
+
+struct fadehip_ctx;
+
+/// Parasail("ACTGN", open, ext, match, mismatch) -- source/anno.d:36
+struct fadehip_params
+{
+    int open = 10;
+    int ext = 2;
+    int match = 2;
+    int mismatch = -3;
+    int max_ref_len = 8192;
+    int max_batch_reads = 1 << 20;
+    long trace_bytes = 0;
+    int trace_all = 0;
+    int reserved = 0;
+}
+
+/// what source/analysis.d:69-113 reads from a dparasail result
+struct fadehip_sw_result
+{
+    int score;
+    int end_query, end_ref;
+    int beg_query, beg_ref; /// beg_ref == res.position
+    int n_ops;
+    uint[FADEHIP_MAX_OPS] ops; /// BAM-encoded: castable to dhtslib CigarOp
+}
+
+struct fadehip_read_batch
+{
+    int n_reads;
+    const(int)* tid;
+    const(int)* pos;
+    const(ushort)* flag;
+    const(ubyte)* has_sa;
+    const(int)* l_seq;
+    const(uint)* cigar_off;
+    const(uint)* cigar_ops;
+    const(uint)* seq_off;
+    const(ubyte)* seq_packed;
+}
+
+struct fadehip_aln
+{
+    int read_idx;
+    int art; /// bit0 art_left, bit1 art_right
+    long win_start;
+    int win_len;
+    int clip_left, clip_right;
+    int aligned_len;
+    fadehip_sw_result sw;
+}
+
+struct fadehip_anno_out
+{
+    ubyte* rs;
+    fadehip_aln* aln;
+    int aln_cap;
+    int n_aln;
+    long[8] stats;
+}
+
+void fadehip_params_default(fadehip_params* p);
+int fadehip_abi_version();
+int fadehip_create(fadehip_ctx** out_, int device, const(fadehip_params)* params);
+void fadehip_destroy(fadehip_ctx* ctx);
+const(char)* fadehip_last_error(const(fadehip_ctx)* ctx);
+int fadehip_host_alloc(fadehip_ctx* ctx, size_t bytes, void** out_);
+int fadehip_host_free(fadehip_ctx* ctx, void* p);
+int fadehip_sw_batch(fadehip_ctx* ctx, int n, const(ubyte)* q, const(long)* q_off,
+        const(ubyte)* r, const(long)* r_off, fadehip_sw_result* out_);
+int fadehip_genome_upload(fadehip_ctx* ctx, int n_contigs, const(long)* lengths, const(ubyte*)* seqs);
+int fadehip_annotate_upload(fadehip_ctx* ctx, int slot, const(fadehip_read_batch)* batch);
+int fadehip_annotate_run(fadehip_ctx* ctx, int slot, int floor_len, int window);
+int fadehip_annotate_submit(fadehip_ctx* ctx, int slot, const(fadehip_read_batch)* batch,
+        int floor_len, int window);
+int fadehip_annotate_collect(fadehip_ctx* ctx, int slot, fadehip_anno_out* out_);
+int fadehip_sync(fadehip_ctx* ctx);
+int fadehip_last_run_profile(fadehip_ctx* ctx, int slot, float* ms4, long* counts4);
+int fadehip_stats_allreduce(fadehip_ctx** ctxs, int n_ctx, long* counters, int count);
