@@ -56,8 +56,9 @@ static void print_anno_help() {
 
 struct Opts {
     int threads = 0, floor_len = 5, window = 300, gpus = 1, batch = 262144;
-    bool bam = false, ubam = false, help = false, stats = false, timing = false;
+    bool bam = false, ubam = false, help = false, stats = false, timing = false, clip = false;
     std::vector<std::string> pos;
+    std::string seen;  // one letter per option met: t m w b u c h g(pus) B(atch) s(tats) T(iming)
 };
 
 // std.getopt with config.bundling: short flags bundle (-bu), values attach (-w100, -w 100, --window-size=100)
@@ -84,23 +85,26 @@ static bool parse_opts(int argc, char **argv, Opts &o, std::string &err) {
                 }
                 return need_int("--" + name, val.c_str(), dst);
             };
-            if (name == "threads") { if (!take(o.threads)) return false; }
-            else if (name == "min-length") { if (!take(o.floor_len)) return false; }
-            else if (name == "window-size") { if (!take(o.window)) return false; }
-            else if (name == "gpus") { if (!take(o.gpus)) return false; }
-            else if (name == "batch") { if (!take(o.batch)) return false; }
-            else if (name == "bam") o.bam = true;
-            else if (name == "ubam") o.ubam = true;
-            else if (name == "stats") o.stats = true;
-            else if (name == "timing") o.timing = true;
+            if (name == "threads") { o.seen += 't'; if (!take(o.threads)) return false; }
+            else if (name == "min-length") { o.seen += 'm'; if (!take(o.floor_len)) return false; }
+            else if (name == "window-size") { o.seen += 'w'; if (!take(o.window)) return false; }
+            else if (name == "gpus") { o.seen += 'g'; if (!take(o.gpus)) return false; }
+            else if (name == "batch") { o.seen += 'B'; if (!take(o.batch)) return false; }
+            else if (name == "bam") { o.seen += 'b'; o.bam = true; }
+            else if (name == "ubam") { o.seen += 'u'; o.ubam = true; }
+            else if (name == "stats") { o.seen += 's'; o.stats = true; }
+            else if (name == "timing") { o.seen += 'T'; o.timing = true; }
+            else if (name == "clip") { o.seen += 'c'; o.clip = true; }
             else if (name == "help") o.help = true;
             else { err = "Unrecognized option --" + name; return false; }
         } else if (a.size() > 1 && a[0] == '-' && a != "-") {
             for (size_t k = 1; k < a.size(); k++) {
                 const char c = a[k];
+                if (c != 'h') o.seen += c;
                 if (c == 'b') o.bam = true;
                 else if (c == 'u') o.ubam = true;
                 else if (c == 'h') o.help = true;
+                else if (c == 'c') o.clip = true;
                 else if (c == 't' || c == 'w') {
                     std::string val = a.substr(k + 1);
                     if (!val.empty() && val[0] == '=') val = val.substr(1);
@@ -469,6 +473,16 @@ static int annotate_main(const std::string &cl, const Opts &o) {
     return 0;
 }
 
+// std.getopt rejects an option the subcommand did not declare (app.d:76-83,104-107,132-134)
+static bool options_allowed(const Opts &o, const char *allowed) {
+    for (char c : o.seen)
+        if (!strchr(allowed, c)) {
+            fprintf(stderr, "std.getopt.GetOptException: Unrecognized option %s%c\n", "-", c);
+            return false;
+        }
+    return true;
+}
+
 static void print_extract_help() {
     fprintf(stderr,
             "%s\nextract: extracts artifacts into a mapped SAM/BAM (used after annotate)\n"
@@ -585,6 +599,275 @@ static int extract_main(const std::string &cl, const Opts &o) {
     return 0;
 }
 
+// ------------------------------------------------------------------ fade out (source/filter.d)
+static void print_out_help() {
+    fprintf(stderr,
+            "%s\nout: removes all read and mates for reads contain the artifact (used after annotate)\n"
+            "     or, with the -c flag, hard clips out artifact sequence from reads\n"
+            "     it is reccomended that the input SAM/BAM be queryname sorted\n"
+            "usage: fade out [options] <input BAM/SAM>\n\n"
+            "-c    --clip clip reads instead of filtering them\n"
+            "-t --threads extra threads for parsing the bam file\n"
+            "-b     --bam output bam\n"
+            "-u    --ubam output uncompressed bam\n"
+            "-h    --help This help information.\n\n",
+            kHeader);
+}
+
+// std.conv.parse!long on the front of s: optional sign, digits; consumes what it parsed.  false = ConvException.
+static bool d_parse_long(std::string &s, long long &v) {
+    size_t k = 0;
+    bool neg = false;
+    if (k < s.size() && (s[k] == '-' || s[k] == '+')) { neg = s[k] == '-'; k++; }
+    if (k >= s.size() || s[k] < '0' || s[k] > '9') return false;
+    long long x = 0;
+    while (k < s.size() && s[k] >= '0' && s[k] <= '9') { x = x * 10 + (s[k] - '0'); k++; }
+    v = neg ? -x : x;
+    s.erase(0, k);
+    return true;
+}
+
+// filter.d:127-167
+static int numerically_aware_cmp(std::string a, std::string b) {
+    while (!a.empty() && !b.empty()) {
+        const bool nda = a[0] > '9' || a[0] < '0', ndb = b[0] > '9' || b[0] < '0';
+        if (nda && ndb) {
+            if (a[0] == b[0]) { a.erase(0, 1); b.erase(0, 1); continue; }
+            return (unsigned char)a[0] < (unsigned char)b[0] ? -1 : 1;
+        }
+        long long ai = -1, bi = -1;
+        const bool pa = d_parse_long(a, ai), pb = d_parse_long(b, bi);
+        if (!pa && !pb) return a.size() == b.size() ? 0 : a.size() < b.size() ? -1 : 1;  // cannot happen: one side is a digit
+        if (ai == bi) continue;
+        return ai < bi ? -1 : 1;
+    }
+    return a.size() == b.size() ? 0 : a.size() < b.size() ? -1 : 1;
+}
+
+static bool rs_of(const Rec &r, uint32_t &rsv) {
+    const size_t p = r.aux_find("rs");
+    if (p == std::string::npos) return false;
+    const uint8_t ty = r.d[p + 2];
+    if (ty == 'C' || ty == 'c') rsv = r.d[p + 3];
+    else if (ty == 'S' || ty == 's') rsv = r.rd<uint16_t>(p + 3);
+    else if (ty == 'I' || ty == 'i') rsv = r.rd<uint32_t>(p + 3);
+    else return false;
+    rsv &= 0xff;
+    return true;
+}
+
+struct OutStats {  // stats.d:16-72
+    long long read_count = 0, clipped = 0, sup = 0, art_sup = 0, art = 0, art_mate = 0, aln_l = 0, aln_r = 0;
+    void parse(uint32_t v) {
+        const uint32_t sc = v & 1, al = (v >> 1) & 1, ar = (v >> 2) & 1, ml = (v >> 3) & 1, mr = (v >> 4) & 1, su = (v >> 5) & 1;
+        clipped += sc;
+        art += (al | ar);
+        sup += su;
+        art_sup += (al | ar) & su;
+        art_mate += ((al & ml) | (ar & mr));
+        aln_l += al;
+        aln_r += ar;
+    }
+    static void ratio(const char *label, long long num, long long den) {
+        if (den == 0) fprintf(stderr, "%s%s\n", label, num == 0 ? "nan" : "inf");
+        else fprintf(stderr, "%s%g\n", label, (double)((float)num / (float)den));
+    }
+    void print() const {
+        fprintf(stderr, "read count:\t%lld\n", read_count);
+        ratio("Clipped %:\t", clipped, read_count);
+        ratio("% With Supplementary alns:\t", sup, read_count);
+        ratio("Artifact rate:\t", art, read_count);
+        ratio("% With Supplementary alns and artifacts:\t", art_sup, read_count);
+        ratio("Artifact rate left only:\t", aln_l, read_count);
+        ratio("Artifact rate right only:\t", aln_r, read_count);
+    }
+};
+
+static bool q_consuming(uint32_t op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+static bool r_consuming(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+static Rec build_rec(const std::string &qname, int32_t tid, int32_t pos, int mapq, uint16_t flag, int32_t mtid, int32_t mpos,
+                     int32_t tlen, const std::vector<uint32_t> &cig, const std::vector<uint8_t> &codes,
+                     const std::vector<uint8_t> &qual, const uint8_t *aux, size_t aux_len) {
+    Rec n;
+    const size_t lqn = qname.size() + 1, lq = codes.size();
+    n.d.assign(32 + lqn + 4 * cig.size() + (lq + 1) / 2 + lq + aux_len, 0);
+    int64_t reflen = 0;
+    for (uint32_t c : cig) if (r_consuming(c & 15)) reflen += c >> 4;
+    n.wr<int32_t>(0, tid);
+    n.wr<int32_t>(4, pos);
+    n.d[8] = (uint8_t)lqn;
+    n.d[9] = (uint8_t)mapq;
+    n.wr<uint16_t>(10, (uint16_t)reg2bin(pos < 0 ? 0 : pos, (pos < 0 ? 0 : pos) + (reflen > 0 ? reflen : 1)));
+    n.wr<uint16_t>(12, (uint16_t)cig.size());
+    n.wr<uint16_t>(14, flag);
+    n.wr<int32_t>(16, (int32_t)lq);
+    n.wr<int32_t>(20, mtid);
+    n.wr<int32_t>(24, mpos);
+    n.wr<int32_t>(28, tlen);
+    memcpy(n.d.data() + 32, qname.c_str(), lqn);
+    size_t off = 32 + lqn;
+    if (!cig.empty()) memcpy(n.d.data() + off, cig.data(), 4 * cig.size());
+    off += 4 * cig.size();
+    for (size_t k = 0; k < lq; k++) n.d[off + (k >> 1)] |= (uint8_t)(codes[k] << ((~k & 1) << 2));
+    off += (lq + 1) / 2;
+    if (lq) memcpy(n.d.data() + off, qual.data(), lq);
+    off += lq;
+    if (aux_len) memcpy(n.d.data() + off, aux, aux_len);
+    return n;
+}
+
+// filter.d:15-91 clipRead
+static void clip_read(Rec &rec, uint32_t rsv) {
+    std::vector<uint32_t> cig((size_t)rec.n_cigar());
+    for (int k = 0; k < rec.n_cigar(); k++) cig[(size_t)k] = rec.cigar_op(k);
+    int64_t pos = rec.pos();
+    const int lq = rec.l_seq();
+    std::vector<uint8_t> codes((size_t)lq), qual((size_t)lq);
+    for (int j = 0; j < lq; j++) {
+        codes[(size_t)j] = (rec.seq()[j >> 1] >> ((~j & 1) << 2)) & 15;
+        qual[(size_t)j] = rec.qual()[j];
+    }
+    const std::string name = rec.qname();
+    size_t sb = 0, se = (size_t)lq;  // surviving [sb, se) of seq / qual
+    const size_t pam = rec.aux_find("am");
+    const std::string am = pam == std::string::npos ? std::string() : std::string((const char *)rec.d.data() + pam + 3);
+    const size_t semi = am.find(';');
+    const std::string sides[2] = {am.substr(0, semi), semi == std::string::npos ? std::string() : am.substr(semi + 1)};
+    auto art_ref_len = [&](int side) -> int64_t {
+        const std::string &f = sides[side];
+        const size_t c1 = f.find(','), c2 = c1 == std::string::npos ? c1 : f.find(',', c1 + 1);
+        std::vector<uint32_t> ac;
+        if (c2 == std::string::npos || !parse_cigar_string(f.substr(c2 + 1), ac)) throw std::runtime_error("malformed am tag: " + am);
+        int64_t n = 0;
+        for (uint32_t c : ac) if (r_consuming(c & 15)) n += c >> 4;
+        return n;
+    };
+    auto aligned_len = [&]() { int64_t n = 0; for (uint32_t c : cig) if (r_consuming(c & 15)) n += c >> 4; return n; };
+    auto reset = [&]() {  // filter.d:47-51 / 79-83: a fresh (zero-filled) record keeping name, sequence, qualities
+        std::vector<uint8_t> c2(codes.begin() + (long)sb, codes.begin() + (long)se), q2(qual.begin() + (long)sb, qual.begin() + (long)se);
+        rec = build_rec(name, 0, 0, 0, 0, 0, 0, 0, {}, c2, q2, nullptr, 0);
+    };
+    if (rsv & 2) {  // filter.d:22-54
+        int64_t to_trim = art_ref_len(0);
+        uint32_t hard = 0;
+        if (to_trim < aligned_len()) {
+            while (to_trim) {
+                const uint32_t op = cig[0] & 15;
+                if (q_consuming(op)) { sb++; hard++; }
+                if (r_consuming(op)) { pos++; to_trim--; }
+                cig[0] -= 16;  // length - 1
+                if ((cig[0] >> 4) == 0) cig.erase(cig.begin());
+            }
+        } else { reset(); return; }
+        cig.insert(cig.begin(), (hard << 4) | 5u);
+    }
+    if (rsv & 4) {  // filter.d:55-86
+        int64_t to_trim = art_ref_len(1);
+        uint32_t hard = 0;
+        if (to_trim < aligned_len()) {
+            while (to_trim) {
+                const uint32_t op = cig.back() & 15;
+                if (q_consuming(op)) { se--; hard++; }
+                if (r_consuming(op)) to_trim--;
+                cig.back() -= 16;
+                if ((cig.back() >> 4) == 0) cig.pop_back();
+            }
+        } else { reset(); return; }
+        cig.push_back((hard << 4) | 5u);
+    }
+    // filter.d:87-90: cigar, sequence, qscores, pos; every other field and the aux tags stay
+    std::vector<uint8_t> c2(codes.begin() + (long)sb, codes.begin() + (long)se), q2(qual.begin() + (long)sb, qual.begin() + (long)se);
+    const size_t ao = rec.aux_off();
+    std::vector<uint8_t> aux(rec.d.begin() + (long)ao, rec.d.end());
+    rec = build_rec(name, rec.tid(), (int32_t)pos, rec.mapq(), (uint16_t)rec.flag(), rec.mtid(), rec.mpos(), rec.tlen(), cig, c2, q2,
+                    aux.data(), aux.size());
+}
+
+// filter.d:169-268
+static int out_main(const std::string &cl, const Opts &o) {
+    const int nthreads = o.threads > 0 ? o.threads : 2;
+    Pool pool(nthreads), wpool(nthreads);
+    try {
+        Reader reader(o.pos[1], &pool);
+        Header hdr = reader.header();
+        hdr.add_pg("fade-extract", "fade", FADE_VERSION, cl);  // filter.d:173-180 (the reference reuses this ID)
+        const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;
+        Writer writer(stdout, fmt, hdr, &wpool);
+        OutStats stats;
+        std::vector<Rec> in, out;
+        auto next_chunk = [&]() { in.clear(); return reader.read_chunk(in, 65536) > 0; };
+        if (o.clip) {  // filter.d:184-212
+            fprintf(stderr, "[W::fade-out] Using the -c flag means the output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+            fprintf(stderr, "[W::fade-out] You also may need to fix mate information with a tool like Picard FixMateInformation\n");
+            while (next_chunk()) {
+                for (Rec &r : in) {
+                    stats.read_count++;
+                    uint32_t v;
+                    if (rs_of(r, v)) {
+                        stats.parse(v);
+                        if (v & 6) clip_read(r, v);
+                    }
+                }
+                writer.write(in);
+            }
+        } else {
+            // filter.d:216-220: the first ten records decide whether the input looks name-sorted
+            std::vector<Rec> all_first;
+            next_chunk();
+            bool sorted = true;
+            for (size_t k = 1; k < std::min<size_t>(in.size(), 10); k++)
+                if (numerically_aware_cmp(in[k].qname(), in[k - 1].qname()) < 0) sorted = false;
+            if (sorted) {  // filter.d:221-246
+                fprintf(stderr, "[W::fade-out] Output looks name-sorted, ejecting all reads with same readname if any have an artifact\n");
+                std::vector<Rec> group;
+                auto flush_group = [&]() {
+                    bool art_found = false;
+                    for (const Rec &r : group) {
+                        stats.read_count++;
+                        uint32_t v;
+                        if (!rs_of(r, v)) continue;
+                        stats.parse(v);
+                        if (v & 6) art_found = true;
+                    }
+                    if (!art_found) for (Rec &r : group) out.push_back(std::move(r));
+                    group.clear();
+                };
+                do {
+                    out.clear();
+                    for (Rec &r : in) {
+                        if (!group.empty() && strcmp(group.back().qname(), r.qname()) != 0) flush_group();
+                        group.push_back(std::move(r));
+                    }
+                    writer.write(out);
+                } while (next_chunk());
+                out.clear();
+                if (!group.empty()) flush_group();
+                writer.write(out);
+            } else {  // filter.d:247-265
+                fprintf(stderr, "[W::fade-out] Output doesn't look name-sorted, ejecting by only reads with an artifact\n");
+                do {
+                    out.clear();
+                    for (Rec &r : in) {
+                        stats.read_count++;
+                        uint32_t v;
+                        if (!rs_of(r, v)) continue;  // filter.d:254-257: records without rs are not written here
+                        stats.parse(v);
+                        if (!(v & 6)) out.push_back(std::move(r));
+                    }
+                    writer.write(out);
+                } while (next_chunk());
+            }
+        }
+        writer.close();
+        stats.print();  // filter.d:267
+    } catch (const std::exception &e) {
+        fprintf(stderr, "[E::fade out] %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     std::string cl;  // app.d:66
     for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
@@ -597,6 +880,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "std.getopt.GetOptException: %s\n", err.c_str());
             return 1;
         }
+        if (!options_allowed(o, "tmwbugBsT")) return 1;
         // app.d:84-89: helpWanted | args.length < 3 (args = prog, "annotate", positionals...)
         if (o.help || o.pos.size() < 2) { print_anno_help(); return 0; }
         if (o.pos.size() < 3) {  // the reference indexes args[2] and dies; say why instead
@@ -617,6 +901,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "std.getopt.GetOptException: %s\n", err.c_str());
             return 1;
         }
+        if (!options_allowed(o, "tbu")) return 1;
         if (o.help || o.pos.size() < 2) { print_extract_help(); return 0; }
         if (o.bam && o.ubam) {
             fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");  // app.d:149 (sic)
@@ -624,7 +909,22 @@ int main(int argc, char **argv) {
         }
         return extract_main(cl, o);
     }
-    if (sub == "out" || sub == "stats" || sub == "stats-clip") {
+    if (sub == "out") {  // app.d:102-129
+        Opts o;
+        std::string err;
+        if (!parse_opts(argc, argv, o, err)) {
+            fprintf(stderr, "std.getopt.GetOptException: %s\n", err.c_str());
+            return 1;
+        }
+        if (!options_allowed(o, "ctbu")) return 1;
+        if (o.help || o.pos.size() < 2) { print_out_help(); return 0; }
+        if (o.bam && o.ubam) {
+            fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");  // app.d:122 (sic)
+            return 1;
+        }
+        return out_main(cl, o);
+    }
+    if (sub == "stats" || sub == "stats-clip") {
         fprintf(stderr, "[E::fade] %s is outside the MI355X annotate hot path; run the reference fade for it\n", sub.c_str());
         return 1;
     }

@@ -52,6 +52,7 @@ def parse_sam(text):
             k, ty, v = t.split(":", 2)
             tags[k] = (ty, v)
         recs.append(dict(qname=f[0], flag=int(f[1]), rname=f[2], pos=int(f[3]) - 1, mapq=int(f[4]), cigar=f[5],
+                         rnext=f[6], pnext=int(f[7]), tlen=int(f[8]),
                          seq=f[9], qual=f[10], tags=tags, tag_order=[t.split(":", 1)[0] for t in f[11:]]))
     return header, recs
 

@@ -80,5 +80,5 @@ def test_extract_matches_restatement_and_reference(tmp_path, tag):
 def test_extract_cli_surface():
     assert subprocess.run([FADE, "extract"], stderr=subprocess.PIPE).returncode == 0          # help, app.d:136-141
     assert subprocess.run([FADE, "extract", "-b", "-u", "x"], stderr=subprocess.PIPE).returncode == 1  # app.d:146-151
-    p = subprocess.run([FADE, "out", "x.bam"], stderr=subprocess.PIPE)
+    p = subprocess.run([FADE, "stats", "x.bam"], stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"outside the MI355X annotate hot path" in p.stderr
