@@ -142,6 +142,20 @@ class Context:
                     cells=cnt[1], trace_bytes=cnt[2], algorithmic_bytes=cnt[3])
 
 
+def stats_allreduce(contexts, counters):
+    """Sum per-device counters with one RCCL all-reduce (single process, one Context per device).
+    counters: int64 array [n_ctx, count]; returns the reduced copy (every row = the sum)."""
+    L = _lib.load()
+    arr = np.ascontiguousarray(counters, dtype=np.int64).copy()
+    n, count = arr.shape
+    assert n == len(contexts)
+    hs = (C.c_void_p * n)(*[c._h for c in contexts])
+    rc = L.fadehip_stats_allreduce(hs, n, arr.ctypes.data, count)
+    if rc != 0:
+        raise FadeHipError(rc, L.fadehip_last_error(contexts[0]._h).decode())
+    return arr
+
+
 class SwResult:
     """What FADE reads from a dparasail result (analysis.d:69-113)."""
 

@@ -38,3 +38,12 @@ def test_annotate_matches_oracle(ctx, oracle, name, n):
               ((v >> 1) & (v >> 3) | (v >> 2) & (v >> 4)) & 1, (v >> 1) & 1, (v >> 2) & 1]
     assert list(stats) == list(c)
     assert len(tags) > 0
+
+
+def test_stats_allreduce_over_rccl(ctx):
+    """fadehip_stats_allreduce: ncclCommInitAll + ncclAllReduce(int64, sum) over the contexts' devices.  The
+    GPU box has one device, so this is the one-rank case of the call the multi-device driver makes at exit."""
+    import fade_amd
+    c = np.arange(8, dtype=np.int64).reshape(1, 8) * 1000 + 7
+    out = fade_amd.stats_allreduce([ctx], c)
+    assert np.array_equal(out, c)
