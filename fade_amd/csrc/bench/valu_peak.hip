@@ -16,8 +16,17 @@ __global__ __launch_bounds__(256) void valu_loop(int iters, int *out) {
     } else if (MODE == 1) {                                                  \
         asm volatile("v_pk_add_i16 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %1\n\tv_pk_sub_i16 %0, %0, %1\n\tv_pk_mad_u16 %0, %0, %1, %1" \
                      : "+v"(x) : "v"(c));                                  \
-    } else {                                                                 \
+    } else if (MODE == 2) {                                                  \
         asm volatile("v_max3_i32 %0, %0, %1, %1\n\tv_mad_u32_u24 %0, %0, %1, %1\n\tv_bfe_u32 %0, %0, %1, 4\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+                     : "+v"(x) : "v"(c));                                  \
+    } else if (MODE == 3) {                                                  \
+        asm volatile("v_pk_add_f16 %0, %0, %1\n\tv_pk_max_f16 %0, %0, %1\n\tv_pk_add_f16 %0, %0, %1\n\tv_pk_min_f16 %0, %0, %1" \
+                     : "+v"(x) : "v"(c));                                  \
+    } else if (MODE == 4) {                                                  \
+        asm volatile("v_add_f32 %0, %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_sub_f32 %0, %0, %1" \
+                     : "+v"(x) : "v"(c));                                  \
+    } else {                                                                 \
+        asm volatile("v_pk_fma_f16 %0, %0, %1, %1\n\tv_pk_mul_f16 %0, %0, %1\n\tv_pk_max_f16 %0, %0, %1\n\tv_pk_fma_f16 %0, %0, %1, %1" \
                      : "+v"(x) : "v"(c));                                  \
     }
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
@@ -56,5 +65,8 @@ int main() {
     run<0>("int32 add/max/sub/alignbit", p.multiProcessorCount);
     run<1>("packed i16 add/max/sub/mad ", p.multiProcessorCount);
     run<2>("max3/mad24/bfe/mov_dpp      ", p.multiProcessorCount);
+    run<3>("packed f16 add/max/add/min  ", p.multiProcessorCount);
+    run<4>("f32 add/max/fma/sub         ", p.multiProcessorCount);
+    run<5>("packed f16 fma/mul/max/fma  ", p.multiProcessorCount);
     return 0;
 }
