@@ -49,10 +49,14 @@ class Context:
             raise FadeHipError(rc, self._L.fadehip_last_error(None).decode())
         self._h = h
         self._keep = {}
+        self._out = {}
         self.contig_names = None
 
     def close(self):
         if getattr(self, "_h", None):
+            for ptr in getattr(self, "_pinned", []):
+                self._L.fadehip_host_free(self._h, ptr)
+            self._pinned = []
             self._L.fadehip_destroy(self._h)
             self._h = None
 
@@ -110,6 +114,23 @@ class Context:
                                  "seq_packed")])
         return b, keep, n
 
+    def pinned_copy(self, batch):
+        """Copy the device-facing arrays of `batch` into pinned host memory (fadehip_host_alloc) so that
+        annotate_upload runs at PCIe speed; the returned dict shares the other keys with `batch`."""
+        out = dict(batch)
+        self._pinned = getattr(self, "_pinned", [])
+        for k, dt in (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("has_sa", np.uint8),
+                      ("l_seq", np.int32), ("cigar_off", np.uint32), ("cigar_ops", np.uint32), ("seq_off", np.uint32),
+                      ("seq_packed", np.uint8)):
+            a = np.ascontiguousarray(batch[k], dtype=dt)
+            ptr = C.c_void_p()
+            self._chk(self._L.fadehip_host_alloc(self._h, max(a.nbytes, 1), C.byref(ptr)))
+            self._pinned.append(ptr)
+            view = np.frombuffer((C.c_uint8 * max(a.nbytes, 1)).from_address(ptr.value), dtype=np.uint8)[:a.nbytes].view(dt)
+            view[...] = a
+            out[k] = view
+        return out
+
     def annotate_upload(self, slot, batch):
         b, keep, n = self._c_batch(batch)
         self._keep[slot] = (keep, n)
@@ -120,11 +141,15 @@ class Context:
 
     def annotate_collect(self, slot):
         n = self._keep[slot][1]
-        rs = np.zeros(max(n, 1), dtype=np.uint8)
-        aln = np.zeros(max(n, 1), dtype=ALN_DTYPE)
-        out = _lib.AnnoOut(rs.ctypes.data, aln.ctypes.data, n, 0)
+        # result buffers are kept per slot (zero-filling 120 B x n every call costs more than the D2H copy)
+        buf = self._out.get(slot)
+        if buf is None or len(buf[0]) < max(n, 1):
+            buf = (np.empty(max(n, 1), dtype=np.uint8), np.empty(max(n, 1), dtype=ALN_DTYPE))
+            self._out[slot] = buf
+        rs, aln = buf
+        out = _lib.AnnoOut(rs.ctypes.data, aln.ctypes.data, len(aln), 0)
         self._chk(self._L.fadehip_annotate_collect(self._h, slot, C.byref(out)))
-        return rs[:n], aln[:out.n_aln].copy(), np.array(list(out.stats), dtype=np.int64)
+        return rs[:n].copy(), aln[:out.n_aln].copy(), np.array(list(out.stats), dtype=np.int64)
 
     def annotate(self, batch, floor_len=5, window=300, slot=0):
         self.annotate_upload(slot, batch)
