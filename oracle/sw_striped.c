@@ -25,6 +25,10 @@ enum { T_ZERO = 0, T_DIAG = 1, T_F = 2, T_E = 3, T_EOPEN = 4, T_FOPEN = 8 };
 enum { OP_I = 1, OP_D = 2, OP_S = 4, OP_EQ = 7, OP_X = 8 };
 #define NEG16 ((int16_t)-16384)
 
+static void *alloc32(size_t bytes) { /* aligned_alloc wants a size that is a multiple of the alignment */
+    return aligned_alloc(32, (bytes + 31) & ~(size_t)31);
+}
+
 static inline __m256i shift_in(__m256i a, int16_t fill) { /* lane l <- lane l-1, lane 0 <- fill */
     __m256i t = _mm256_permute2x128_si256(a, a, 0x08);
     __m256i r = _mm256_alignr_epi8(a, t, 14);
@@ -47,14 +51,14 @@ int fo_sw_striped(const fo_params *p, const char *q, int lq, const char *r, int 
     const int segLen = (lq + SEGW - 1) / SEGW;
     const int open = p->open, ext = p->ext;
     /* profile[k][seg] */
-    __m256i *prof = (__m256i *)aligned_alloc(32, sizeof(__m256i) * (size_t)(nalpha + 1) * segLen);
-    __m256i *H = (__m256i *)aligned_alloc(32, sizeof(__m256i) * segLen);
-    __m256i *Hprev = (__m256i *)aligned_alloc(32, sizeof(__m256i) * segLen);
-    __m256i *E = (__m256i *)aligned_alloc(32, sizeof(__m256i) * segLen);
-    __m256i *Eo = (__m256i *)aligned_alloc(32, sizeof(__m256i) * segLen); /* E-origin mask of the current column */
-    __m256i *F = (__m256i *)aligned_alloc(32, sizeof(__m256i) * segLen);
-    __m256i *Dg = (__m256i *)aligned_alloc(32, sizeof(__m256i) * segLen);
-    uint8_t *trace = (uint8_t *)aligned_alloc(32, (size_t)lr * segLen * SEGW + 32);
+    __m256i *prof = (__m256i *)alloc32(sizeof(__m256i) * (size_t)(nalpha + 1) * segLen);
+    __m256i *H = (__m256i *)alloc32(sizeof(__m256i) * segLen);
+    __m256i *Hprev = (__m256i *)alloc32(sizeof(__m256i) * segLen);
+    __m256i *E = (__m256i *)alloc32(sizeof(__m256i) * segLen);
+    __m256i *Eo = (__m256i *)alloc32(sizeof(__m256i) * segLen); /* E-origin mask of the current column */
+    __m256i *F = (__m256i *)alloc32(sizeof(__m256i) * segLen);
+    __m256i *Dg = (__m256i *)alloc32(sizeof(__m256i) * segLen);
+    uint8_t *trace = (uint8_t *)alloc32((size_t)lr * segLen * SEGW + 32);
     if (!prof || !H || !Hprev || !E || !Eo || !F || !Dg || !trace) return -1;
     for (int k = 0; k <= nalpha; k++)
         for (int s = 0; s < segLen; s++) {
