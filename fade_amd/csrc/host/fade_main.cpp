@@ -1,4 +1,5 @@
-// fade_main.cpp — `fade annotate` host driver over the fadehip C ABI.
+// fade_main.cpp — the `fade` host driver: `annotate` over the fadehip C ABI, plus the host-only consumers
+// `extract` (source/remap.d) and `out` (source/filter.d).
 //
 // Mirrors the CLI surface of the reference:
 //   source/app.d:64-101   main, getopt(annotate): -t/--threads, --min-length, -w/--window-size, -b/--bam, -u/--ubam,
@@ -7,7 +8,8 @@
 //                         annotateTask, write to stdout as SAM / uBAM / BAM (source/util.d:65-76)
 //   source/anno.d:94-107  tag order rs, am, as, ar, ab;  analysis.d:84-92,108-118 string contents
 // The loop at anno.d:44-50 becomes read-chunk -> pack (pointers into the BAM bytes) -> fadehip_annotate_*
-// -> format tags -> write, pipelined over two device slots.  Additive flags: --gpus N, --batch N, --stats.
+// -> format tags -> write: three threaded stages (reader / device+tags / writer) over two device slots.
+// Additive flags: --gpus N, --batch N, --stats, --timing.
 // There is no CPU alignment path in this program.
 #include <memory>
 #include "hts_lite.hpp"
@@ -16,7 +18,6 @@
 #include <chrono>
 #include <cstdlib>
 #include <deque>
-#include <iostream>
 
 #ifndef FADE_VERSION
 #define FADE_VERSION "v0.5.0-mi355x"
@@ -301,7 +302,6 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         const Header &h = reader.header();
         std::vector<int64_t> lens(h.names.size());
         std::vector<const uint8_t *> ptrs(h.names.size());
-        static const std::string empty;
         for (size_t k = 0; k < h.names.size(); k++) {
             size_t f = 0;
             while (f < fa.names.size() && fa.names[f] != h.names[k]) f++;
