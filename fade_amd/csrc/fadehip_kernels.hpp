@@ -558,34 +558,47 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     maxst = max(maxst, __builtin_amdgcn_readlane(mx, 48));
     const int n_blocks = (maxst + 3) >> 2;
 
-    // ---- stage both windows: 16 bits per column = classA*4 | classB*4 << 8
+    // ---- score table in LDS: wtab[c] = 8 bytes, byte q = 8 * W'(query class q, column class c).  A lane fetches
+    // the two entries of its current columns once per step; every row then needs one v_perm_b32 per alignment
+    // (selector = the row's query class) and one v_add3 for the diagonal term of the pair.
+    __shared__ uint2 wtab[8];
+    if (lane < 8) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) lo |= (((a.sc.prof[q] >> (4 * lane)) & 15u) * PK_SCALE) << (8 * q);
+#pragma unroll
+        for (int q = 4; q < 7; q++) hi |= (((a.sc.prof[q] >> (4 * lane)) & 15u) * PK_SCALE) << (8 * (q - 4));
+        wtab[lane] = make_uint2(lane < 7 ? lo : 0u, lane < 7 ? hi : 0u);
+    }
+    // ---- stage both windows: 16 bits per column = classA*8 | classB*8 << 8 (byte offsets into wtab)
     uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
     const int n_cols = n_blocks * 4;
     for (int k = lig; k < n_cols; k += 16) {
-        uint32_t ca = PAD_CLASS * 4, cb = PAD_CLASS * 4;
-        if (k < lrA) ca = lut4(CLASS_LUT, nib_at(a.r_nib, wa.r_base + (uint64_t)k)) * 4u;
-        if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k)) * 4u;
+        uint32_t ca = PAD_CLASS * 8, cb = PAD_CLASS * 8;
+        if (k < lrA) ca = lut4(CLASS_LUT, nib_at(a.r_nib, wa.r_base + (uint64_t)k)) * 8u;
+        if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k)) * 8u;
         lref[k] = (uint16_t)(ca | (cb << 8));
     }
-    uint32_t profA[R], profB[R];
+    // v_perm selectors: byte 0 (A) / byte 2 (B) picks table byte `query class`, the other bytes read as 0
+    uint32_t selA[R], selB[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int row = lig * R + r;
-        uint32_t pa = a.sc.prof[PAD_CLASS], pb = a.sc.prof[PAD_CLASS];
+        uint32_t qa = PAD_CLASS, qb = PAD_CLASS;
         if (row < lqA) {
             uint32_t code;
             if (wa.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)wa.q_base + (uint32_t)(lqA - 1 - row)));
             else code = nib_at(a.q_nib, (uint64_t)wa.q_base + (uint32_t)row);
-            pa = a.sc.prof[lut4(CLASS_LUT, code)];
+            qa = lut4(CLASS_LUT, code);
         }
         if (row < lqB) {
             uint32_t code;
             if (wb.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)(lqB - 1 - row)));
             else code = nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)row);
-            pb = a.sc.prof[lut4(CLASS_LUT, code)];
+            qb = lut4(CLASS_LUT, code);
         }
-        profA[r] = pa;
-        profB[r] = pb;
+        selA[r] = 0x0c0c0c00u | qa;
+        selB[r] = 0x0c000c0cu | (qb << 16);
     }
 
     // End-cell tracking.  MODE 0: a 32-bit key (H, 0xffff - t) per row and alignment.  MODE 1: one packed 16-bit
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
 #pragma unroll
     for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; bestA[r] = 0; bestB[r] = 0; GT[r] = 0; }
     uint32_t hu_out = 0, fu_out = 0, hu_prev = 0;
-    uint32_t rc = (PAD_CLASS * 4) | (PAD_CLASS * 4 << 8);
+    uint32_t rc = (PAD_CLASS * 8) | (PAD_CLASS * 8 << 8);
     if constexpr (MODE == 2) {
         // resume: the wave state pass 1 snapshotted after step T0-1, per half from that half's own octet
         constexpr int CKD = ck_dwords(R);
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         fu_out = pick(2 * R + 1);
         hu_prev = pick(2 * R + 2);
         // the class register holds classA | classB << 8 in its low 16 bits
-        uint32_t ra = PAD_CLASS * 4, rb = PAD_CLASS * 4;
+        uint32_t ra = PAD_CLASS * 8, rb = PAD_CLASS * 8;
         if (c0A) ra = (ckA[(2 * R + 3) * 64] >> ((srcA & 1u) ? 8 : 0)) & 0xffu;
         if (c0B) rb = (ckB[(2 * R + 3) * 64] >> ((srcB & 1u) ? 8 : 0)) & 0xffu;
         rc = ra | (rb << 8);
@@ -651,16 +664,17 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             rc = (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)rc, DPP_ROW_SHR1, 0xf, 0xf, false);
             uint32_t hu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
             uint32_t fu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
-            const uint32_t rcB = rc >> 8;
+            const uint2 tA = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(wtab) + (rc & 0xffu));
+            const uint2 tB = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(wtab) + (rc >> 8));
             const uint32_t ct = (uint32_t)(0xffff - t);
             const uint32_t tk = (uint32_t)(31 - (t & 31)) * 0x10001u;  // MODE 1: position inside the 32-step window
             uint32_t hd = hu_prev;
             hu_prev = hu;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t wA = __builtin_amdgcn_ubfe(profA[r], rc, 4);
-                const uint32_t wB = __builtin_amdgcn_ubfe(profB[r], rcB, 4);
-                const uint32_t Dp = lshl_add<19>(wB, lshl_add<3>(wA, hd));
+                const uint32_t wA = __builtin_amdgcn_perm(tA.y, tA.x, selA[r]);
+                const uint32_t wB = __builtin_amdgcn_perm(tB.y, tB.x, selB[r]);
+                const uint32_t Dp = hd + wA + wB;
                 const uint32_t hl = Hl[r];
                 const uint32_t Ee = as_u32(as_s2(Eh[r]) - as_s2(ext8));
                 const uint32_t En = as_u32(__builtin_elementwise_max(as_s2(hl), as_s2(Ee)));
