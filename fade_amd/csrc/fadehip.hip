@@ -334,6 +334,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
             t.rs = rs;
             t.floor_len = floor_len;
             t.gate = gate;
+            t.early_out = (gate && meta && !ctx->prm.trace_all) ? 1 : 0;
             t.packed = 1;
             t.cand = cand;
             t.incomplete = may_be_incomplete ? (Cand *)s.incomplete.p : nullptr;
@@ -444,6 +445,7 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         t.rs = rs;
         t.floor_len = floor_len;
         t.gate = gate;
+        t.early_out = 0;
         t.packed = packed ? 1 : 0;
         t.cand = nullptr;
         t.incomplete = nullptr;

@@ -19,6 +19,7 @@
 //   FADE's gates, rs bits) -> stats_kernel.  sw_pk_kernel<R,0> and sw_forward_kernel<R> are the single-pass
 //   packed / int32 variants kept for A/B measurements (FADEHIP_KERNEL=pk|int32).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fadehip.h"
@@ -579,8 +580,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k)) * 8u;
         lref[k] = (uint16_t)(ca | (cb << 8));
     }
-    // v_perm selectors: byte 0 (A) / byte 2 (B) picks table byte `query class`, the other bytes read as 0
-    uint32_t selA[R], selB[R];
+    // query classes per row (A | B << 16); `special` = some real row is N or a wildcard (class >= 4)
+    uint32_t qcls[R];
+    bool special = false;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int row = lig * R + r;
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             else code = nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)row);
             qb = lut4(CLASS_LUT, code);
         }
-        selA[r] = 0x0c0c0c00u | qa;
-        selB[r] = 0x0c000c0cu | (qb << 16);
+        special |= (row < lqA && qa >= 4u) || (row < lqB && qb >= 4u);
+        qcls[r] = qa | (qb << 16);
     }
 
     // End-cell tracking.  MODE 0: a 32-bit key (H, 0xffff - t) per row and alignment.  MODE 1: one packed 16-bit
@@ -645,8 +647,27 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     uint32_t *ckw = a.ckpt + (uint64_t)oct * a.ck_stride + lane;
     const uint32_t himask = __builtin_amdgcn_readfirstlane(0xffff0000u);
 
+    // The sweep exists twice.  FAST (no N / wildcard in either query of the octet, i.e. nearly always): the four
+    // A,C,G,T bytes of the two column rows sit in one register pair, so ONE v_perm_b32 yields both halves of the
+    // pair's 8*W' (pad rows select the constant 0) and the diagonal term costs 2 instructions.  General: one
+    // v_perm_b32 per alignment over the full 7-class rows plus v_add3_u32 (3 instructions).
     // MODE 1 runs the blocks in groups of 8 (= CK_COLS steps) and snapshots between groups, so that the hot
     // loop has the same shape in every mode
+    auto sweep = [&](auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    uint32_t selA[R], selB[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t qa = qcls[r] & 0xffu, qb = qcls[r] >> 16;
+        if constexpr (FAST) {
+            selA[r] = 0x0c000c00u | (qa == PAD_CLASS ? 0x0cu : qa) | ((qb == PAD_CLASS ? 0x0cu : qb + 4u) << 16);
+            selB[r] = 0;
+        } else {
+            selA[r] = 0x0c0c0c00u | qa;
+            selB[r] = 0x0c000c0cu | (qb << 16);
+        }
+    }
+    const uint8_t *wt = reinterpret_cast<const uint8_t *>(wtab);
     constexpr int GROUP = (MODE == 1) ? 8 : (1 << 30);
     for (int blk0 = 0; blk0 < n_blocks; blk0 += GROUP) {
     const int blk_end = (MODE == 1) ? min(n_blocks, blk0 + 8) : n_blocks;
@@ -664,17 +685,29 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             rc = (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)rc, DPP_ROW_SHR1, 0xf, 0xf, false);
             uint32_t hu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
             uint32_t fu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
-            const uint2 tA = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(wtab) + (rc & 0xffu));
-            const uint2 tB = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(wtab) + (rc >> 8));
+            uint2 tA, tB;
+            if constexpr (FAST) {
+                tA.x = *reinterpret_cast<const uint32_t *>(wt + (rc & 0xffu));
+                tB.x = *reinterpret_cast<const uint32_t *>(wt + (rc >> 8));
+                tA.y = tB.y = 0;
+            } else {
+                tA = *reinterpret_cast<const uint2 *>(wt + (rc & 0xffu));
+                tB = *reinterpret_cast<const uint2 *>(wt + (rc >> 8));
+            }
             const uint32_t ct = (uint32_t)(0xffff - t);
             const uint32_t tk = (uint32_t)(31 - (t & 31)) * 0x10001u;  // MODE 1: position inside the 32-step window
             uint32_t hd = hu_prev;
             hu_prev = hu;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t wA = __builtin_amdgcn_perm(tA.y, tA.x, selA[r]);
-                const uint32_t wB = __builtin_amdgcn_perm(tB.y, tB.x, selB[r]);
-                const uint32_t Dp = hd + wA + wB;
+                uint32_t Dp;
+                if constexpr (FAST) {
+                    Dp = hd + __builtin_amdgcn_perm(tB.x, tA.x, selA[r]);
+                } else {
+                    const uint32_t wA = __builtin_amdgcn_perm(tA.y, tA.x, selA[r]);
+                    const uint32_t wB = __builtin_amdgcn_perm(tB.y, tB.x, selB[r]);
+                    Dp = hd + wA + wB;
+                }
                 const uint32_t hl = Hl[r];
                 const uint32_t Ee = as_u32(as_s2(Eh[r]) - as_s2(ext8));
                 const uint32_t En = as_u32(__builtin_elementwise_max(as_s2(hl), as_s2(Ee)));
@@ -745,6 +778,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         }
     }
     }
+    };  // sweep
+    if (__any(special)) sweep(std::false_type{});
+    else sweep(std::true_type{});
 
     if constexpr (MODE == 1) {
         // (GH, GT) -> the 32-bit keys the reduction below expects: (H8 << 16) | (0xffff - t), 0 when H == 0
@@ -810,6 +846,7 @@ struct TbArgs {
     uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
+    int32_t early_out;      // 1: a path that leaves the traced steps with > 10 ops already is not re-run (see below)
     int32_t packed;         // trace written by the packed kernel (octets) instead of sw_forward_kernel (quads)
     // two-pass path: thread k serves a candidate whose trace starts at sweep step c0; results go to out[src]
     const Cand *cand;
@@ -920,6 +957,28 @@ __global__ void traceback_kernel(TbArgs a) {
         n_runs++;
     }
 
+    if (left_range && !(state == 0 && h == 0) && a.early_out && n_runs + (lq - 1 - f.end_q > 0 ? 1 : 0) > 10) {
+        // The path continues before step T0, but it already has more than 10 ops and can only gain more:
+        // analysis.d:69-70 rejects it whatever the rest looks like.  Report it like an untraced alignment.
+        fadehip_aln o;
+        o.read_idx = (int32_t)w.idx;
+        o.art = 0;
+        o.sw.score = f.score;
+        o.sw.end_query = f.end_q;
+        o.sw.end_ref = f.end_r;
+        o.sw.beg_query = o.sw.beg_ref = -1;
+        o.sw.n_ops = 0;
+#pragma unroll
+        for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+        const Meta m = a.meta[src];
+        o.win_start = m.win_start;
+        o.win_len = (int32_t)w.lr;
+        o.clip_left = m.clip_left;
+        o.clip_right = m.clip_right;
+        o.aligned_len = m.aligned_len;
+        a.out[src] = o;
+        return;
+    }
     if (left_range && !(state == 0 && h == 0)) {
         // the path continues before step T0: this candidate is re-run from the start of the sweep
         const uint32_t k = atomicAdd(a.incomplete_n, 1u);

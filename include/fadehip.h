@@ -117,7 +117,9 @@ typedef struct {
 
 /* One entry per read that was re-aligned (clip longer than min-length), in no particular order.
  * sw.score / end_query / end_ref are always set.  Unless params.trace_all, the traceback (beg_*, ops)
- * is only run when the result can still be an artifact call; otherwise sw.n_ops == 0, beg_* == -1. */
+ * is only completed when the result can still be an artifact call; otherwise sw.n_ops == 0, beg_* == -1
+ * (score or end cell already fail analysis.d:74-80 / 98-104, or the path was abandoned once it had
+ * more than 10 ops, which analysis.d:69-70 rejects). */
 typedef struct {
     int32_t read_idx;
     int32_t art;         /* bit0 art_left, bit1 art_right (analysis.d:82,106) */

@@ -67,6 +67,15 @@ def make_pairs(rng, n, lq_range=(20, 260), lr_range=(30, 900), kinds=("random", 
             r[rng.random(lr) < 0.2] = ord("N")
         elif kind == "iupac":
             q, r = rand_seq(rng, lq, IUPAC), rand_seq(rng, lr, IUPAC)
+        elif kind == "refspecial":  # N / IUPAC columns only in the reference: the query stays pure A,C,G,T
+            r = rand_seq(rng, lr)
+            a = int(rng.integers(0, max(1, lr - 10)))
+            q = mutate(rng, r[a:a + lq])
+            if len(q) == 0:
+                q = rand_seq(rng, 5)
+            m = rng.random(lr) < 0.15
+            r[m] = rand_seq(rng, int(m.sum()), IUPAC)
+            r[rng.random(lr) < 0.05] = ord("N")
         else:  # related: query is a mutated slice of the reference (gaps and mismatches)
             r = rand_seq(rng, lr)
             a = int(rng.integers(0, max(1, lr - 10)))

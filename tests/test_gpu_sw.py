@@ -40,13 +40,16 @@ def test_sw_random_families(ctx, oracle, seed):
     _compare(ctx, oracle, qs, rs)
 
 
-def test_sw_all_row_classes(ctx, oracle):
-    """Every R class of the kernel (Lq 1..512) and ragged window lengths."""
+@pytest.mark.parametrize("kinds", [("planted", "related", "random"), ("refspecial", "planted", "refspecial"),
+                                   ("nrich", "iupac", "related")], ids=["acgt", "refspecial", "qspecial"])
+def test_sw_all_row_classes(ctx, oracle, kinds):
+    """Every R class of the kernel (Lq 1..512) and ragged window lengths.  The packed kernel has two sweeps: one for
+    octets whose queries are pure A,C,G,T (ids acgt, refspecial) and one for octets with N / IUPAC query rows."""
     rng = np.random.default_rng(11)
     qs, rs = [], []
     for lq in list(range(1, 40)) + [63, 64, 65, 95, 96, 97, 127, 128, 129, 150, 159, 160, 161, 191, 192, 193, 223,
                                      224, 225, 250, 255, 256, 257, 300, 319, 320, 321, 383, 384, 385, 500, 511, 512]:
-        for kind in ("planted", "related", "random"):
+        for kind in kinds:
             q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(1, 1200), kinds=(kind,))
             qs += q
             rs += r
@@ -66,3 +69,18 @@ def test_sw_limits_fail_loudly(ctx):
         ctx.sw_batch([b"A" * 513], [b"ACGT"])
     with pytest.raises(fade_amd.FadeHipError):
         ctx.sw_batch([b"ACGT"], [b"A" * 9000])
+
+
+def test_sw_neighbour_independence(ctx, oracle):
+    """One N-bearing query switches its whole octet to the general sweep: the other seven results must not move."""
+    rng = np.random.default_rng(5)
+    qs, rs = make_pairs(rng, 64, lq_range=(150, 150), lr_range=(300, 340), kinds=("planted", "related", "random"))
+    base = ctx.sw_batch([q.tobytes() for q in qs], [r.tobytes() for r in rs])
+    qs2 = [q.copy() for q in qs]
+    for k in range(3, 64, 8):
+        qs2[k][rng.integers(0, len(qs2[k]), size=4)] = ord("N")
+    got = ctx.sw_batch([q.tobytes() for q in qs2], [r.tobytes() for r in rs])
+    for k in range(64):
+        if k % 8 != 3:
+            assert got[k].tobytes() == base[k].tobytes(), k
+    _compare(ctx, oracle, qs2, rs)
