@@ -101,7 +101,7 @@ def main():
     # Two batches are resident, one per device slot; steps alternate between them and the two slots are driven
     # by two host threads, the way the `fade` driver double-buffers: the latency-bound tail of one batch
     # (traceback of the longest alignments) overlaps the next batch's scoring pass.
-    n_slots = 2 if args.slots == 2 else 1
+    n_slots = max(1, min(int(args.slots), fade_amd._lib.NUM_SLOTS))
     batches = [synth.make_reads(genome, args.batch_reads, 100 * (k + 1) + rank, **cfg) for k in range(n_slots)]
     batch = batches[0]
     ctx = fade_amd.Context(device=local, max_batch_reads=max(args.batch_reads, 1 << 20))
@@ -126,8 +126,8 @@ def main():
         if n_slots == 1:
             run_steps(0, n_steps, prof_out)
             return
-        th = [threading.Thread(target=run_steps, args=(k, n_steps // 2 + (k < n_steps % 2), prof_out if k == 0 else None))
-              for k in range(2)]
+        th = [threading.Thread(target=run_steps, args=(k, n_steps // n_slots + (k < n_steps % n_slots),
+                                                       prof_out if k == 0 else None)) for k in range(n_slots)]
         for t_ in th:
             t_.start()
         for t_ in th:
@@ -147,8 +147,8 @@ def main():
     rs, aln, stats = ctx.annotate_collect(0)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if n_slots == 2:
-        stats = stats + ctx.annotate_collect(1)[2]
+    for k in range(1, n_slots):
+        stats = stats + ctx.annotate_collect(k)[2]
     st = torch.tensor(stats, dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -25,6 +25,8 @@
 
 using namespace htsl;
 
+// the driver double-buffers: two of the ctx's slots per device (one batch computes while the previous one is collected)
+static constexpr size_t kSlotsInUse = 2;
 static const char *kHeader = "Fragmentase Artifact Detection and Elimination\nversion: " FADE_VERSION "\n";
 
 static void print_full_help() {
@@ -403,7 +405,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         std::unique_ptr<Chunk> c;
         while (!failed && q_in.pop(c)) {
             c->dev = (int)(seq_no % (size_t)ngpu);
-            c->slot = (int)((seq_no / (size_t)ngpu) % FADEHIP_NUM_SLOTS);
+            c->slot = (int)((seq_no / (size_t)ngpu) % kSlotsInUse);
             seq_no++;
             ck_pack.start();
             pack_chunk(*c, pool);
@@ -423,7 +425,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             }
             inflight.push_back(std::move(c));
             // one batch per slot in flight: the oldest is collected while the newest computes
-            while (!failed && inflight.size() > (size_t)ngpu * (FADEHIP_NUM_SLOTS - 1)) {
+            while (!failed && inflight.size() > (size_t)ngpu * (kSlotsInUse - 1)) {
                 if (finish(std::move(inflight.front()))) failed = true;
                 inflight.pop_front();
             }
