@@ -1,0 +1,449 @@
+// deflate_fast.hpp — a DEFLATE (RFC 1951) compressor for BGZF blocks.
+//
+// once the alignment kernels run at hundreds of millions of reads per second the end-to-end
+// rate of `fade annotate` is set by the BGZF codec (the reference gets it from htslib + zlib, util.d:65-76).  A BGZF
+// block is an independent <= 64 KiB DEFLATE stream, so the compressor can be small: positions fit 16 bits, the match
+// table needs no window sliding, one dynamic-Huffman block per BGZF block.  BAM payloads are dominated by base
+// qualities and packed bases (entropy-coded, few matches), so the match finder is built to fail cheaply (see
+// `find`), a profitability filter drops the short far matches zlib takes at a loss, and the Huffman encoder is
+// table-driven.  Output is standard DEFLATE: any inflater (zlib, htslib, libdeflate) reads it.
+//
+// Not derived from zlib/libdeflate sources; follows RFC 1951 only.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+
+namespace htsl {
+
+class FastDeflate {
+public:
+    static constexpr size_t MAX_IN = 65535;
+    // worst case: a stored block (5 bytes of framing); the caller's buffer must hold n + 16 bytes
+    static constexpr size_t bound(size_t n) { return n + 16; }
+
+    // effort: 1 = greedy parse, 2 = lazy parse (default), 3 = lazy parse over 4 candidates per hash
+    explicit FastDeflate(int effort = 2) : effort_(std::max(1, std::min(3, effort))) {
+        lazy_ = effort_ >= 2;
+        init_static();
+    }
+
+    // Compresses in[0, n), n <= MAX_IN, into one final DEFLATE block at out; returns the byte count (<= bound(n)).
+    size_t compress(const uint8_t *in, size_t n, uint8_t *out) {
+        if (effort_ >= 3) parse<4, 15>(in, n);
+        else parse<1, 14>(in, n);
+        return encode(in, n, out);
+    }
+
+private:
+    // ------------------------------------------------------------------ LZ77 parse
+    // Match finder: a hash of 5 bytes selects a bucket holding the WAYS most recent positions with that hash (one
+    // 64-bit word, a FIFO by shifting).  The candidates are checked without data-dependent branches — on qualities
+    // and packed bases nearly every probe fails, and a chained search there pays a branch miss plus an exposed
+    // cache-miss chain per position (measured: 45 cycles/position against 20).  Only a 5-byte hit branches into the
+    // extension code.  Minimum match 5: shorter ones rarely pay for their distance bits.
+    // Measured on BAM payloads (selftest/deflate_selftest <file>; uniform qualities / binned qualities with runs):
+    //   1 way,  14 bits: 0.5701 / 0.4082 of the input at 70 MB/s       (efforts 1 and 2)
+    //   4 ways, 15 bits: 0.5684 / 0.40   at 29 MB/s                    (effort 3)
+    //   zlib level 6   : 0.5908 / 0.3957 at 8-14 MB/s on the same core
+    static constexpr int MIN_MATCH = 5, MAX_MATCH = 258;
+    static constexpr uint64_t MASK5 = 0xffffffffffull;
+    static inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+    template <int HB> static inline uint32_t hash5(uint64_t v5) { return (uint32_t)((v5 * 0x9E3779B185EBCA87ull) >> (64 - HB)); }
+
+    static inline int match_len(const uint8_t *a, const uint8_t *b, int maxlen) {
+        int l = 0;
+        while (l + 8 <= maxlen) {
+            const uint64_t x = load64(a + l) ^ load64(b + l);
+            if (x) return l + (__builtin_ctzll(x) >> 3);
+            l += 8;
+        }
+        while (l < maxlen && a[l] == b[l]) l++;
+        return l;
+    }
+    // a match pays for itself only if it is long enough for its distance (extra distance bits vs literal bits)
+    static inline bool worth(int len, int dist) {
+        return len >= 7 || (len == 6 && dist <= 16384) || (len == 5 && dist <= 4096) || (len == 4 && dist <= 512);
+    }
+
+    // positions p with p + 8 <= n can be hashed (the 8-byte load stays inside the block)
+    template <int HB> inline void insert(const uint8_t *in, size_t p) {
+        const uint32_t h = hash5<HB>(load64(in + p) & MASK5);
+        tab_[h] = (tab_[h] << 16) | (uint64_t)(p + 1);
+    }
+    // longest profitable match at p (which is inserted); returns length or 0
+    template <int WAYS, int HB> inline int find(const uint8_t *in, size_t n, size_t p, int &dist_out) {
+        const uint64_t v = load64(in + p) & MASK5;
+        const uint32_t h = hash5<HB>(v);
+        const uint64_t b = tab_[h];
+        tab_[h] = (b << 16) | (uint64_t)(p + 1);
+        uint32_t hits = 0;
+        size_t cpos[WAYS];
+#pragma GCC unroll 4
+        for (int w = 0; w < WAYS; w++) {
+            const uint32_t cw = (uint32_t)(b >> (16 * w)) & 0xffffu;
+            const size_t c = cw ? cw - 1 : p;  // an empty way points at p itself and is masked out below
+            cpos[w] = c;
+            const uint32_t ok = ((load64(in + c) & MASK5) == v) & (cw != 0) & (p - c <= 32768);
+            hits |= ok << w;
+        }
+        dist_out = 0;
+        if (__builtin_expect(hits == 0, 1)) return 0;
+        int best = 0;
+        const int maxlen = (int)std::min<size_t>(MAX_MATCH, n - p);
+        for (int w = 0; w < WAYS; w++) {
+            if (!(hits >> w & 1)) continue;
+            const int dist = (int)(p - cpos[w]);
+            const int l = match_len(in + cpos[w], in + p, maxlen);
+            if (l > best && worth(l, dist)) {
+                best = l;
+                dist_out = dist;
+            }
+        }
+        return best;
+    }
+
+    template <int WAYS, int HB> void parse(const uint8_t *in, size_t n) {
+        memset(tab_, 0, sizeof(uint64_t) << HB);
+        memset(lfreq_, 0, sizeof lfreq_);
+        memset(dfreq_, 0, sizeof dfreq_);
+        nsym_ = 0;
+        extra_bits_ = 0;
+        const size_t hash_end = n >= 8 ? n - 7 : 0;  // positions < hash_end can be hashed
+        size_t p = 0;
+        while (p < n) {
+            int len = 0, dist = 0;
+            if (p < hash_end) len = find<WAYS, HB>(in, n, p, dist);
+            if (len >= MIN_MATCH) {
+                bool probed = false;  // whether p + 1 is already in the table
+                if (lazy_) {
+                    // defer while the next position starts a strictly longer match
+                    while (len < 40 && p + 1 < hash_end) {
+                        int d2 = 0;
+                        const int l2 = find<WAYS, HB>(in, n, p + 1, d2);
+                        if (l2 <= len) { probed = true; break; }
+                        put_literal(in[p]);
+                        p++;
+                        len = l2;
+                        dist = d2;
+                    }
+                }
+                put_match(len, dist);
+                const size_t stop = std::min(p + (size_t)len, hash_end);
+                for (size_t q = p + 1 + (probed ? 1 : 0); q < stop; q++) insert<HB>(in, q);
+                p += (size_t)len;
+            } else {
+                put_literal(in[p]);
+                p++;
+            }
+        }
+        count_literals();
+        lfreq_[256] = 1;  // end of block
+    }
+
+    // symbol stream: a literal is its byte value; a match is 0x8000 | length followed by distance - 1.
+    // Literal frequencies are counted afterwards (count_literals), off the parser's critical path.
+    inline void put_literal(uint8_t c) { sym_[nsym_++] = c; }
+    inline void put_match(int len, int dist) {
+        sym_[nsym_++] = (uint16_t)(0x8000u | (uint32_t)len);
+        sym_[nsym_++] = (uint16_t)(dist - 1);
+        const int ls = len_sym_[len], ds = dist_sym(dist);
+        lfreq_[257 + ls]++;
+        dfreq_[ds]++;
+        extra_bits_ += len_xbits_[ls] + dist_xbits_[ds];
+    }
+    void count_literals() {
+        uint32_t h[4][256];
+        memset(h, 0, sizeof h);
+        size_t i = 0;
+        int lane = 0;
+        while (i < nsym_) {
+            const uint32_t v = sym_[i];
+            if (v & 0x8000u) { i += 2; continue; }
+            h[lane & 3][v]++;
+            lane++;
+            i++;
+        }
+        for (int c = 0; c < 256; c++) lfreq_[c] = h[0][c] + h[1][c] + h[2][c] + h[3][c];
+    }
+
+    // ------------------------------------------------------------------ Huffman code construction
+    // Code lengths (<= maxbits, complete prefix code) for freq[0, n); at least two symbols get a code.
+    static void build_lengths(const uint32_t *freq_in, int n, int maxbits, uint8_t *lens) {
+        uint32_t freq[288];
+        int order[288];
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            freq[i] = freq_in[i];
+            lens[i] = 0;
+        }
+        for (int i = 0; i < n; i++)
+            if (freq[i]) order[m++] = i;
+        // decoders reject incomplete codes (except one 1-bit code): always give two symbols a code
+        for (int i = 0; m < 2 && i < n; i++)
+            if (!freq[i]) {
+                freq[i] = 1;
+                order[m++] = i;
+            }
+        std::sort(order, order + m, [&](int a, int b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
+        // two-queue Huffman: leaves 0..m-1 (ascending), internal nodes m..2m-2 are created in ascending weight order
+        uint64_t w[576];
+        int parent[576];
+        for (int i = 0; i < m; i++) w[i] = freq[order[i]];
+        int leaf = 0, inode = m, next = m;
+        auto take = [&]() {
+            if (leaf < m && (inode >= next || w[leaf] <= w[inode])) return leaf++;
+            return inode++;
+        };
+        while (next < 2 * m - 1) {
+            const int a = take(), b = take();
+            w[next] = w[a] + w[b];
+            parent[a] = parent[b] = next;
+            next++;
+        }
+        int depth[576];
+        depth[2 * m - 2] = 0;
+        for (int i = 2 * m - 3; i >= 0; i--) depth[i] = depth[parent[i]] + 1;
+        // length limit: clamp, then repair the Kraft sum (leaf i = i-th least frequent symbol)
+        int len[288];
+        uint32_t kraft = 0;
+        const uint32_t full = 1u << maxbits;
+        for (int i = 0; i < m; i++) {
+            len[i] = std::min(depth[i], maxbits);
+            kraft += full >> len[i];
+        }
+        while (kraft > full) {  // over-subscribed: lengthen the rarest symbol that still can be
+            int i = 0;
+            while (len[i] >= maxbits) i++;
+            kraft -= full >> (len[i] + 1);
+            len[i]++;
+        }
+        while (kraft < full) {  // incomplete: shorten, most frequent first, whatever fits
+            bool moved = false;
+            for (int i = m - 1; i >= 0 && kraft < full; i--) {
+                if (len[i] > 1 && kraft + (full >> len[i]) <= full) {
+                    kraft += full >> len[i];
+                    len[i]--;
+                    moved = true;
+                }
+            }
+            if (!moved) break;
+        }
+        for (int i = 0; i < m; i++) lens[order[i]] = (uint8_t)len[i];
+    }
+
+    // canonical codes (RFC 1951 §3.2.2), stored bit-reversed for LSB-first output
+    static void assign_codes(const uint8_t *lens, int n, uint16_t *codes) {
+        int bl_count[16] = {0};
+        for (int i = 0; i < n; i++) bl_count[lens[i]]++;
+        bl_count[0] = 0;
+        uint32_t next_code[16];
+        uint32_t code = 0;
+        for (int b = 1; b <= 15; b++) {
+            code = (code + (uint32_t)bl_count[b - 1]) << 1;
+            next_code[b] = code;
+        }
+        for (int i = 0; i < n; i++) {
+            const int l = lens[i];
+            if (!l) { codes[i] = 0; continue; }
+            uint32_t c = next_code[l]++, r = 0;
+            for (int k = 0; k < l; k++) { r = (r << 1) | (c & 1); c >>= 1; }
+            codes[i] = (uint16_t)r;
+        }
+    }
+
+    // ------------------------------------------------------------------ static tables
+    void init_static() {
+        static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t LX[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const uint8_t DX[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        for (int s = 0; s < 29; s++) {
+            len_base_[s] = LBASE[s];
+            len_xbits_[s] = LX[s];
+            const int hi = s == 28 ? 258 : LBASE[s + 1] - 1;
+            for (int l = LBASE[s]; l <= hi && l <= 258; l++) len_sym_[l] = (uint8_t)s;
+        }
+        len_sym_[258] = 28;
+        for (int s = 0; s < 30; s++) {
+            dist_base_[s] = DBASE[s];
+            dist_xbits_[s] = DX[s];
+        }
+        // distance symbol lookup: d-1 < 256 direct, else by (d-1) >> 7
+        for (int d = 1; d <= 32768; d++) {
+            int s = 29;
+            while (DBASE[s] > d) s--;
+            if (d <= 256) dsym_lo_[d - 1] = (uint8_t)s;
+            else dsym_hi_[(d - 1) >> 7] = (uint8_t)s;
+        }
+        for (int i = 0; i < 288; i++) fix_llen_[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+        for (int i = 0; i < 32; i++) fix_dlen_[i] = 5;
+        assign_codes(fix_llen_, 288, fix_lcode_);
+        assign_codes(fix_dlen_, 32, fix_dcode_);
+    }
+    inline int dist_sym(int dist) const { return dist <= 256 ? dsym_lo_[dist - 1] : dsym_hi_[(dist - 1) >> 7]; }
+
+    // ------------------------------------------------------------------ bit output
+    struct Bits {
+        uint8_t *p;
+        uint64_t buf = 0;
+        int cnt = 0;
+        inline void add(uint32_t v, int n) {
+            buf |= (uint64_t)v << cnt;
+            cnt += n;
+            if (cnt >= 32) {
+                const uint32_t w = (uint32_t)buf;
+                memcpy(p, &w, 4);
+                p += 4;
+                buf >>= 32;
+                cnt -= 32;
+            }
+        }
+        inline uint8_t *finish() {
+            while (cnt > 0) {
+                *p++ = (uint8_t)buf;
+                buf >>= 8;
+                cnt -= 8;
+            }
+            cnt = 0;
+            return p;
+        }
+    };
+
+    // ------------------------------------------------------------------ block encoding
+    size_t encode(const uint8_t *in, size_t n, uint8_t *out) {
+        uint8_t llen[288], dlen[32];
+        build_lengths(lfreq_, 286, 15, llen);
+        build_lengths(dfreq_, 30, 15, dlen);
+        llen[286] = llen[287] = 0;
+        dlen[30] = dlen[31] = 0;
+        int hlit = 286, hdist = 30;
+        while (hlit > 257 && llen[hlit - 1] == 0) hlit--;
+        while (hdist > 1 && dlen[hdist - 1] == 0) hdist--;
+
+        // code-length sequence, run-length coded with 16 / 17 / 18 (RFC 1951 §3.2.7)
+        uint8_t seq[320];
+        const int nseq = hlit + hdist;
+        memcpy(seq, llen, (size_t)hlit);
+        memcpy(seq + hlit, dlen, (size_t)hdist);
+        uint8_t rl_sym[320], rl_x[320];
+        int nrl = 0;
+        uint32_t cfreq[19] = {0};
+        for (int i = 0; i < nseq;) {
+            const int v = seq[i];
+            int run = 1;
+            while (i + run < nseq && seq[i + run] == v) run++;
+            i += run;
+            if (v == 0) {
+                while (run >= 11) {
+                    const int r = std::min(run, 138);
+                    rl_sym[nrl] = 18; rl_x[nrl++] = (uint8_t)(r - 11); cfreq[18]++;
+                    run -= r;
+                }
+                if (run >= 3) {
+                    rl_sym[nrl] = 17; rl_x[nrl++] = (uint8_t)(run - 3); cfreq[17]++;
+                    run = 0;
+                }
+            } else {
+                rl_sym[nrl] = (uint8_t)v; rl_x[nrl++] = 0; cfreq[v]++;
+                run--;
+                while (run >= 3) {
+                    const int r = std::min(run, 6);
+                    rl_sym[nrl] = 16; rl_x[nrl++] = (uint8_t)(r - 3); cfreq[16]++;
+                    run -= r;
+                }
+            }
+            while (run-- > 0) {
+                rl_sym[nrl] = (uint8_t)v; rl_x[nrl++] = 0; cfreq[v]++;
+            }
+        }
+        uint8_t clen[19];
+        uint16_t ccode[19];
+        build_lengths(cfreq, 19, 7, clen);
+        assign_codes(clen, 19, ccode);
+        static const uint8_t CORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int hclen = 19;
+        while (hclen > 4 && clen[CORDER[hclen - 1]] == 0) hclen--;
+
+        // costs in bits
+        uint64_t dyn = 3 + 5 + 5 + 4 + 3 * (uint64_t)hclen + extra_bits_;
+        for (int i = 0; i < nrl; i++) dyn += clen[rl_sym[i]] + (rl_sym[i] == 16 ? 2 : rl_sym[i] == 17 ? 3 : rl_sym[i] == 18 ? 7 : 0);
+        uint64_t fix = 3 + extra_bits_;
+        for (int i = 0; i < 286; i++) {
+            dyn += (uint64_t)lfreq_[i] * llen[i];
+            fix += (uint64_t)lfreq_[i] * fix_llen_[i];
+        }
+        for (int i = 0; i < 30; i++) {
+            dyn += (uint64_t)dfreq_[i] * dlen[i];
+            fix += (uint64_t)dfreq_[i] * 5;
+        }
+        const uint64_t stored = 8 * ((uint64_t)n + 5);
+
+        if (stored <= dyn && stored <= fix) {
+            out[0] = 1;  // BFINAL = 1, BTYPE = 00, then byte-aligned LEN / NLEN
+            const uint16_t l = (uint16_t)n, nl = (uint16_t)~l;
+            memcpy(out + 1, &l, 2);
+            memcpy(out + 3, &nl, 2);
+            memcpy(out + 5, in, n);
+            return n + 5;
+        }
+        Bits bw;
+        bw.p = out;
+        const uint8_t *ll;
+        const uint16_t *lc, *dc;
+        const uint8_t *dl;
+        uint16_t lcode[288], dcode[32];
+        if (fix <= dyn) {
+            bw.add(1 | (1 << 1), 3);
+            ll = fix_llen_; lc = fix_lcode_; dl = fix_dlen_; dc = fix_dcode_;
+        } else {
+            bw.add(1 | (2 << 1), 3);
+            bw.add((uint32_t)(hlit - 257), 5);
+            bw.add((uint32_t)(hdist - 1), 5);
+            bw.add((uint32_t)(hclen - 4), 4);
+            for (int i = 0; i < hclen; i++) bw.add(clen[CORDER[i]], 3);
+            for (int i = 0; i < nrl; i++) {
+                const int s = rl_sym[i];
+                bw.add(ccode[s], clen[s]);
+                if (s == 16) bw.add(rl_x[i], 2);
+                else if (s == 17) bw.add(rl_x[i], 3);
+                else if (s == 18) bw.add(rl_x[i], 7);
+            }
+            assign_codes(llen, 288, lcode);
+            assign_codes(dlen, 32, dcode);
+            ll = llen; lc = lcode; dl = dlen; dc = dcode;
+        }
+        for (size_t i = 0; i < nsym_; i++) {
+            const uint32_t v = sym_[i];
+            if (!(v & 0x8000u)) {
+                bw.add(lc[v], ll[v]);
+            } else {
+                const int len = (int)(v & 0x7fffu), dist = (int)sym_[++i] + 1;
+                const int ls = len_sym_[len];
+                bw.add(lc[257 + ls], ll[257 + ls]);
+                if (len_xbits_[ls]) bw.add((uint32_t)(len - len_base_[ls]), len_xbits_[ls]);
+                const int ds = dist_sym(dist);
+                bw.add(dc[ds], dl[ds]);
+                if (dist_xbits_[ds]) bw.add((uint32_t)(dist - dist_base_[ds]), dist_xbits_[ds]);
+            }
+        }
+        bw.add(lc[256], ll[256]);
+        return (size_t)(bw.finish() - out);
+    }
+
+    int effort_;
+    bool lazy_;
+    uint64_t tab_[1 << 15];
+    uint16_t sym_[65536 + 8];
+    size_t nsym_ = 0;
+    uint64_t extra_bits_ = 0;
+    uint32_t lfreq_[288], dfreq_[32];
+    uint16_t len_base_[29], dist_base_[30];
+    uint8_t len_xbits_[29], dist_xbits_[30];
+    uint8_t len_sym_[259];
+    uint8_t dsym_lo_[256], dsym_hi_[256];
+    uint8_t fix_llen_[288], fix_dlen_[32];
+    uint16_t fix_lcode_[288], fix_dcode_[32];
+};
+
+}  // namespace htsl

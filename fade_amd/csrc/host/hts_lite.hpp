@@ -20,7 +20,10 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
+
+#include "deflate_fast.hpp"
 
 namespace htsl {
 
@@ -546,20 +549,40 @@ inline void sam_format(const Rec &r, const Header &h, std::string &s) {
 static const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
                                      0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+// FADE_BGZF_CODEC=zlib selects zlib level 6 (what htslib does by default) instead of deflate_fast.hpp;
+// FADE_BGZF_EFFORT=1|2|3 picks FastDeflate's effort (default 2)
+inline bool bgzf_use_zlib() {
+    static const bool z = [] {
+        const char *e = getenv("FADE_BGZF_CODEC");
+        return e && strcmp(e, "zlib") == 0;
+    }();
+    return z;
+}
+
 // compress one block of <= 0xff00 bytes into out (appended); level 0 gives stored (uBAM)
 inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::vector<uint8_t> &out) {
     uint8_t buf[0x10000 + 64];
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
-    zs.next_in = const_cast<uint8_t *>(src);
-    zs.avail_in = (uInt)n;
-    zs.next_out = buf + 18;
-    zs.avail_out = sizeof buf - 18 - 8;
-    const int rc = deflate(&zs, Z_FINISH);
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END) throw std::runtime_error("BGZF deflate overflow");
-    const size_t clen = zs.total_out;
+    size_t clen;
+    if (level > 0 && !bgzf_use_zlib()) {
+        static thread_local std::unique_ptr<FastDeflate> fd;
+        if (!fd) {
+            const char *e = getenv("FADE_BGZF_EFFORT");  // 1 fastest, 2 default, 3 closest to zlib level 6 in size
+            fd.reset(new FastDeflate(e ? atoi(e) : 2));
+        }
+        clen = fd->compress(src, n, buf + 18);
+    } else {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+        zs.next_in = const_cast<uint8_t *>(src);
+        zs.avail_in = (uInt)n;
+        zs.next_out = buf + 18;
+        zs.avail_out = sizeof buf - 18 - 8;
+        const int rc = deflate(&zs, Z_FINISH);
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) throw std::runtime_error("BGZF deflate overflow");
+        clen = zs.total_out;
+    }
     const size_t bsize = 18 + clen + 8;
     static const uint8_t hdr[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
     memcpy(buf, hdr, 16);
@@ -639,7 +662,8 @@ private:
     size_t beg_ = 0, end_ = 0;
 };
 
-// Inflates BGZF blocks in parallel batches and serves the uncompressed byte stream.
+// Inflates BGZF blocks in parallel batches and serves the uncompressed byte stream, either copied out (read) or
+// in place (data / avail / consume / more) so that the BAM reader can frame records without a per-record copy loop.
 class BgzfIn {
 public:
     BgzfIn(ByteSource *src, Pool *pool) : src_(src), pool_(pool) {}
@@ -647,7 +671,7 @@ public:
         size_t got = 0;
         while (got < n) {
             if (pos_ == out_.size()) {
-                if (!refill()) break;
+                if (!more()) break;
             }
             const size_t k = std::min(n - got, out_.size() - pos_);
             memcpy(dst + got, out_.data() + pos_, k);
@@ -656,14 +680,18 @@ public:
         }
         return got;
     }
-
-private:
-    bool refill() {
-        out_.clear();
-        pos_ = 0;
+    const uint8_t *data() const { return out_.data() + pos_; }
+    size_t avail() const { return out_.size() - pos_; }
+    void consume(size_t n) { pos_ += n; }
+    // inflate the next batch of blocks behind the unread bytes; false at end of file
+    bool more() {
+        if (pos_) {
+            out_.erase(out_.begin(), out_.begin() + (std::ptrdiff_t)pos_);
+            pos_ = 0;
+        }
         comp_.clear();
         offs_.clear();
-        const size_t kBatch = 256;
+        const size_t kBatch = 512;
         while (offs_.size() < kBatch) {
             uint8_t h[18];
             if (src_->peek(h, 18) < 18) break;
@@ -681,6 +709,7 @@ private:
             offs_.push_back({o, bsize, (size_t)xlen});
         }
         if (offs_.empty()) return false;
+        const size_t base = out_.size();
         std::vector<size_t> isz(offs_.size()), ooff(offs_.size() + 1, 0);
         for (size_t k = 0; k < offs_.size(); k++) {
             uint32_t v;
@@ -688,7 +717,7 @@ private:
             isz[k] = v;
             ooff[k + 1] = ooff[k] + v;
         }
-        out_.resize(ooff.back());
+        out_.resize(base + ooff.back());
         pool_->parallel_for(offs_.size(), [&](size_t k) {
             if (isz[k] == 0) return;
             z_stream zs;
@@ -697,7 +726,7 @@ private:
             const size_t hl = 12 + offs_[k].xlen;
             zs.next_in = comp_.data() + offs_[k].off + hl;
             zs.avail_in = (uInt)(offs_[k].size - hl - 8);
-            zs.next_out = out_.data() + ooff[k];
+            zs.next_out = out_.data() + base + ooff[k];
             zs.avail_out = (uInt)isz[k];
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
@@ -706,6 +735,8 @@ private:
         if (bad_) throw std::runtime_error("BGZF inflate failed");
         return true;
     }
+
+private:
     struct Blk { size_t off, size, xlen; };
     ByteSource *src_;
     Pool *pool_;
@@ -741,18 +772,38 @@ public:
     size_t read_chunk(std::vector<Rec> &out, size_t max_n) {
         size_t n = 0;
         if (bam_) {
+            // frame the records in the inflated buffer (serial, 4 bytes per record), copy them out in parallel
+            std::vector<size_t> off;
             while (n < max_n) {
-                uint8_t b4[4];
-                const size_t k = bgzf_->read(b4, 4);
-                if (k == 0) break;
-                if (k != 4) throw std::runtime_error("truncated BAM record");
-                uint32_t bs;
-                memcpy(&bs, b4, 4);
-                if (bs < 32) throw std::runtime_error("corrupt BAM record");
-                out.emplace_back();
-                out.back().d.resize(bs);
-                if (bgzf_->read(out.back().d.data(), bs) != bs) throw std::runtime_error("truncated BAM record");
-                n++;
+                const uint8_t *b = bgzf_->data();
+                const size_t av = bgzf_->avail();
+                off.clear();
+                size_t o = 0;
+                while (n + off.size() < max_n && o + 4 <= av) {
+                    uint32_t bs;
+                    memcpy(&bs, b + o, 4);
+                    if (bs < 32) throw std::runtime_error("corrupt BAM record");
+                    if (o + 4 + bs > av) break;
+                    off.push_back(o);
+                    o += 4 + (size_t)bs;
+                }
+                if (off.empty()) {
+                    if (bgzf_->more()) continue;
+                    if (av) throw std::runtime_error("truncated BAM record");
+                    break;
+                }
+                const size_t base = out.size();
+                out.resize(base + off.size());
+                const size_t nt = (size_t)pool_->size() * 4, cnt = off.size();
+                pool_->parallel_for(nt, [&](size_t t) {
+                    for (size_t i = cnt * t / nt; i < cnt * (t + 1) / nt; i++) {
+                        uint32_t bs;
+                        memcpy(&bs, b + off[i], 4);
+                        out[base + i].d.assign(b + off[i] + 4, b + off[i] + 4 + bs);
+                    }
+                });
+                bgzf_->consume(o);
+                n += cnt;
             }
             return n;
         }
@@ -866,11 +917,20 @@ public:
             for (auto &s : parts) fwrite(s.data(), 1, s.size(), f_);
             return;
         }
-        for (const Rec &r : recs) {
-            const uint32_t bs = (uint32_t)r.d.size();
-            raw_.insert(raw_.end(), (const uint8_t *)&bs, (const uint8_t *)&bs + 4);
-            raw_.insert(raw_.end(), r.d.begin(), r.d.end());
-        }
+        // serial prefix sum of the record sizes, parallel copy
+        const size_t n = recs.size();
+        std::vector<size_t> off(n + 1);
+        off[0] = raw_.size();
+        for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + 4 + recs[i].d.size();
+        raw_.resize(off[n]);
+        const size_t nt = (size_t)pool_->size() * 4;
+        pool_->parallel_for(nt, [&](size_t t) {
+            for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+                const uint32_t bs = (uint32_t)recs[i].d.size();
+                memcpy(raw_.data() + off[i], &bs, 4);
+                memcpy(raw_.data() + off[i] + 4, recs[i].d.data(), bs);
+            }
+        });
         flush_blocks(false);
     }
     void close() {

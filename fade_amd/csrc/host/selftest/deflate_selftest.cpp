@@ -1,0 +1,162 @@
+// Round-trip and size/speed check of deflate_fast.hpp against zlib:  deflate_selftest [file]
+// Every block is compressed by FastDeflate (all effort levels), inflated by zlib and compared; with a file argument
+// the file is cut into 0xff00-byte BGZF-sized blocks and the sizes and rates of both compressors are printed.
+#include <zlib.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+#include "../deflate_fast.hpp"
+
+using namespace htsl;
+
+static bool roundtrip(FastDeflate &fd, const uint8_t *in, size_t n, size_t *clen_out) {
+    std::vector<uint8_t> out(FastDeflate::bound(n) + 16), back(n + 1);
+    const size_t clen = fd.compress(in, n, out.data());
+    if (clen > FastDeflate::bound(n)) { fprintf(stderr, "bound exceeded: %zu > %zu\n", clen, FastDeflate::bound(n)); return false; }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    inflateInit2(&zs, -15);
+    zs.next_in = out.data();
+    zs.avail_in = (uInt)clen;
+    zs.next_out = back.data();
+    zs.avail_out = (uInt)back.size();
+    const int rc = inflate(&zs, Z_FINISH);
+    const size_t got = zs.total_out, used = zs.total_in;
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || got != n || used != clen || (n && memcmp(back.data(), in, n) != 0)) {
+        fprintf(stderr, "round trip failed: rc=%d (%s) got=%zu want=%zu used=%zu clen=%zu\n", rc, zs.msg ? zs.msg : "", got, n, used, clen);
+        return false;
+    }
+    if (clen_out) *clen_out = clen;
+    return true;
+}
+
+static size_t zlib_block(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = const_cast<uint8_t *>(in);
+    zs.avail_in = (uInt)n;
+    zs.next_out = out;
+    zs.avail_out = (uInt)cap;
+    deflate(&zs, Z_FINISH);
+    const size_t r = zs.total_out;
+    deflateEnd(&zs);
+    return r;
+}
+
+int main(int argc, char **argv) {
+    std::mt19937_64 rng(12345);
+    int fails = 0, cases = 0;
+    for (int effort = 1; effort <= 3; effort++) {
+        FastDeflate fd(effort);
+        auto check = [&](const std::vector<uint8_t> &v, const char *what) {
+            cases++;
+            if (!roundtrip(fd, v.data(), v.size(), nullptr)) { fprintf(stderr, "  case: %s, n=%zu, effort=%d\n", what, v.size(), effort); fails++; }
+        };
+        // sizes around every boundary the parser has
+        for (size_t n : {0u, 1u, 2u, 3u, 4u, 5u, 7u, 8u, 9u, 15u, 16u, 17u, 257u, 258u, 259u, 260u, 300u, 4096u, 32767u, 32768u, 32769u, 65279u, 65280u, 65535u}) {
+            std::vector<uint8_t> v(n);
+            for (auto &c : v) c = (uint8_t)rng();
+            check(v, "random bytes (stored)");
+            for (auto &c : v) c = 'A';
+            check(v, "one byte repeated (dist 1, len 258)");
+            for (size_t i = 0; i < n; i++) v[i] = "ACGT"[rng() & 3];
+            check(v, "4-letter text");
+            for (size_t i = 0; i < n; i++) v[i] = (uint8_t)(i % 251);
+            check(v, "period 251");
+            for (size_t i = 0; i < n; i++) v[i] = (uint8_t)((i * i) >> 3);
+            check(v, "quadratic");
+        }
+        // skewed alphabets: Fibonacci-like frequencies push the unrestricted Huffman depth past 15 (and past 7 for
+        // the code-length code)
+        {
+            std::vector<uint8_t> v;
+            uint64_t a = 1, b = 1;
+            for (int s = 0; s < 40 && v.size() < 60000; s++) {
+                for (uint64_t k = 0; k < a && v.size() < 60000; k++) v.push_back((uint8_t)s);
+                const uint64_t c = a + b; a = b; b = c;
+            }
+            std::shuffle(v.begin(), v.end(), rng);
+            check(v, "fibonacci literal frequencies");
+        }
+        // far matches: the same 300-byte unit at distances up to 32768 and beyond
+        for (size_t gap : {1000u, 32000u, 32468u, 32469u, 33000u}) {
+            std::vector<uint8_t> v(gap + 600);
+            for (auto &c : v) c = (uint8_t)rng();
+            memcpy(v.data() + gap + 300, v.data(), 300);
+            check(v, "far repeat");
+        }
+        // structured records (BAM-like): fixed fields that repeat, names that count up, random payload
+        for (int rep = 0; rep < 20; rep++) {
+            std::vector<uint8_t> v;
+            while (v.size() < 60000) {
+                const uint32_t pos = (uint32_t)(rng() % 100000000);
+                const uint8_t fixed[12] = {1, 0, 0, 0, 0, 0, 0, 0, 60, 0, 99, 0};
+                v.insert(v.end(), fixed, fixed + 12);
+                v.insert(v.end(), (const uint8_t *)&pos, (const uint8_t *)&pos + 4);
+                const std::string nm = "read" + std::to_string(v.size() / 300);
+                v.insert(v.end(), nm.begin(), nm.end());
+                v.push_back(0);
+                for (int k = 0; k < 75; k++) v.push_back((uint8_t)rng());
+                for (int k = 0; k < 150; k++) v.push_back((uint8_t)(20 + rng() % 21));
+            }
+            v.resize(std::min<size_t>(v.size(), 65280));
+            check(v, "record-like");
+        }
+        // random mixtures
+        for (int rep = 0; rep < 300; rep++) {
+            const size_t n = (size_t)(rng() % 65536);
+            std::vector<uint8_t> v(n);
+            const int alpha = 1 + (int)(rng() % 64);
+            const int copy_pct = (int)(rng() % 60);
+            for (size_t i = 0; i < n;) {
+                if (i > 8 && (int)(rng() % 100) < copy_pct) {
+                    const size_t d = 1 + rng() % std::min<size_t>(i, 40000), l = 3 + rng() % 300;
+                    for (size_t k = 0; k < l && i < n; k++, i++) v[i] = v[i - d];
+                } else v[i++] = (uint8_t)(rng() % alpha);
+            }
+            check(v, "mixture");
+        }
+    }
+    printf("deflate_selftest: %d cases, %d failures\n", cases, fails);
+    if (fails) return 1;
+
+    if (argc > 1) {
+        FILE *f = fopen(argv[1], "rb");
+        if (!f) { perror(argv[1]); return 2; }
+        std::vector<uint8_t> data;
+        uint8_t buf[1 << 16];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+        fclose(f);
+        const size_t B = 0xff00;
+        std::vector<uint8_t> out(B + 1024);
+        for (int mode = 0; mode < 5; mode++) {  // 0..2 FastDeflate effort 1..3, 3 = zlib 1, 4 = zlib 6
+            FastDeflate fd(std::min(mode + 1, 3));
+            size_t total = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (size_t o = 0; o < data.size(); o += B) {
+                const size_t n = std::min(B, data.size() - o);
+                if (mode < 3) {
+                    size_t c = 0;
+                    if (!roundtrip(fd, data.data() + o, n, &c)) return 1;
+                    total += c;
+                } else total += zlib_block(data.data() + o, n, mode == 3 ? 1 : 6, out.data(), out.size());
+            }
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (mode < 3) {  // time compression alone (the loop above also inflates)
+                const auto t1 = std::chrono::steady_clock::now();
+                for (size_t o = 0; o < data.size(); o += B) fd.compress(data.data() + o, std::min(B, data.size() - o), out.data());
+                dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            }
+            printf("%-22s %10zu -> %10zu bytes (%.4f)  %7.1f MB/s\n",
+                   mode < 3 ? (std::string("FastDeflate effort ") + std::to_string(mode + 1)).c_str() : (mode == 3 ? "zlib level 1" : "zlib level 6"),
+                   data.size(), total, (double)total / (double)data.size(), (double)data.size() / dt / 1e6);
+        }
+    }
+    return 0;
+}
