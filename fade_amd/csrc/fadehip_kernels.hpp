@@ -222,15 +222,18 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     // block-aggregated append: slots are first reserved in LDS, then one global atomic per block and
     // class (per-lane or even per-wave atomics on one address serialise at ~12 ns each and dominated
     // this kernel)
-    __shared__ uint32_t s_cnt[NUM_CLASSES], s_base[NUM_CLASSES], s_maxlr[NUM_CLASSES], s_err;
+    __shared__ uint32_t s_cnt[NUM_CLASSES], s_base[NUM_CLASSES], s_maxlr[NUM_CLASSES], s_err, s_items;
     __shared__ unsigned long long s_cells, s_bytes, s_ck;
+    __shared__ uint32_t s_key[GATE_BLOCK], s_rank[GATE_BLOCK];
     if (threadIdx.x < NUM_CLASSES) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; }
+    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; s_items = 0; }
     __syncthreads();
-    uint32_t local_slot = 0;
+    uint32_t compact = 0;
     if (cls >= 0) {
-        local_slot = atomicAdd(&s_cnt[cls], 1u);
+        atomicAdd(&s_cnt[cls], 1u);
         atomicMax(&s_maxlr[cls], lr_for_max);
+        compact = atomicAdd(&s_items, 1u);
+        s_key[compact] = ((uint32_t)cls << 24) | lr_for_max;  // lr <= 16000
     }
     if (__ballot(cells != 0)) {
         for (int sh = 32; sh >= 1; sh >>= 1) {
@@ -258,9 +261,23 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         }
         if (s_err) atomicOr(&a.counters[2 * NUM_CLASSES], s_err);
     }
+    // The block's items of one class are appended in order of decreasing window length: the eight alignments of
+    // a wave sweep max(lr) + 15 steps, so neighbours of equal length waste none (C2: 339 -> 323 columns per
+    // octet).  Rank = items of the same class with a longer window (ties by list position); a block holds
+    // ~100 items for 10 % clipped reads, and only threads below the item count loop.
+    if (threadIdx.x < s_items) {
+        const uint32_t me = s_key[threadIdx.x];
+        const uint32_t n = s_items;
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t o = s_key[k];
+            r += ((o ^ me) >> 24) == 0 && (o > me || (o == me && k < threadIdx.x));
+        }
+        s_rank[threadIdx.x] = r;
+    }
     __syncthreads();
     if (cls >= 0) {
-        const uint32_t slot = s_base[cls] + local_slot;
+        const uint32_t slot = s_base[cls] + s_rank[compact];
         a.work[cls][slot] = w;
         a.meta[cls][slot] = m;
     }
