@@ -807,29 +807,53 @@ public:
             }
             return n;
         }
-        // SAM: gather lines first, parse in parallel
-        std::vector<std::string> lines;
-        if (!pending_.empty()) {
-            lines.push_back(std::move(pending_));
-            pending_.clear();
-        }
-        std::string s;
-        while (lines.size() < max_n && src_->getline(s)) {
-            if (s.empty()) continue;
-            lines.push_back(s);
+        // SAM: pull text in 16 MiB pieces, frame the lines (memchr), parse them in parallel straight from the buffer
+        std::vector<std::pair<size_t, size_t>> lines;  // offset, length in text_
+        for (;;) {
+            lines.clear();
+            size_t o = text_pos_;
+            while (lines.size() < max_n) {
+                const char *b = text_.data() + o;
+                const char *nl = (const char *)memchr(b, '\n', text_.size() - o);
+                if (!nl) break;
+                size_t len = (size_t)(nl - b);
+                const size_t next = o + len + 1;
+                if (len && b[len - 1] == '\r') len--;
+                if (len) lines.push_back({o, len});
+                o = next;
+            }
+            if (lines.size() < max_n && !text_eof_) {
+                // not enough complete lines buffered: drop the consumed prefix, append more text, frame again
+                text_.erase(0, text_pos_);
+                text_pos_ = 0;
+                const size_t have = text_.size(), want = (size_t)16 << 20;
+                text_.resize(have + want);
+                const size_t got = src_->read((uint8_t *)&text_[have], want);
+                text_.resize(have + got);
+                if (got < want) {
+                    text_eof_ = true;
+                    if (!text_.empty() && text_.back() != '\n') text_.push_back('\n');
+                }
+                continue;
+            }
+            text_pos_ = o;
+            break;
         }
         const size_t base = out.size();
         out.resize(base + lines.size());
         std::atomic<bool> bad{false};
         std::string err;
         std::mutex em;
-        pool_->parallel_for(lines.size(), [&](size_t i) {
-            try {
-                sam_parse(lines[i].data(), lines[i].size(), hdr_, out[base + i]);
-            } catch (const std::exception &e) {
-                std::lock_guard<std::mutex> l(em);
-                bad = true;
-                err = e.what();
+        const size_t nt = (size_t)pool_->size() * 4, cnt = lines.size();
+        pool_->parallel_for(nt, [&](size_t t) {
+            for (size_t i = cnt * t / nt; i < cnt * (t + 1) / nt; i++) {
+                try {
+                    sam_parse(text_.data() + lines[i].first, lines[i].second, hdr_, out[base + i]);
+                } catch (const std::exception &e) {
+                    std::lock_guard<std::mutex> l(em);
+                    bad = true;
+                    err = e.what();
+                }
             }
         });
         if (bad) throw std::runtime_error(err);
@@ -842,7 +866,7 @@ private:
         while (src_->getline(s)) {
             if (!s.empty() && s[0] == '@') hdr_.text += s + "\n";
             else {
-                pending_ = s;
+                text_ = s + "\n";  // first record line: goes back in front of the text buffer
                 break;
             }
         }
@@ -876,7 +900,9 @@ private:
     std::unique_ptr<BgzfIn> bgzf_;
     bool bam_ = false;
     Header hdr_;
-    std::string pending_;
+    std::string text_;      // SAM text not yet handed out (complete lines from text_pos_ on)
+    size_t text_pos_ = 0;
+    bool text_eof_ = false;
 };
 
 // ------------------------------------------------------------------ writer: SAM / uBAM / BAM to a FILE*
