@@ -888,6 +888,26 @@ __device__ __forceinline__ uint32_t trace_nibble_pk(const uint32_t *to, int R, i
     return (wv >> (16 * half + 4 * (3 - (p & 3)))) & 15u;
 }
 
+// 8 consecutive nibbles starting at nibble index n0 of a packed sequence: the two aligned dwords that hold them
+struct Nib8 {
+    uint64_t word;
+    uint64_t byte0;  // byte index of the word's first byte
+};
+__device__ __forceinline__ Nib8 load_nib8(const uint8_t *p, uint64_t n0) {
+    Nib8 r;
+    r.byte0 = (n0 >> 1) & ~3ull;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r.byte0);
+    const uint32_t lo = q[0];
+    // 8 nibbles starting in byte (n0 >> 1) end at most 4 bytes later: the second dword is needed unless they fit
+    const uint32_t hi = (((n0 + 7) >> 1) - r.byte0 >= 4) ? q[1] : 0u;
+    r.word = (uint64_t)lo | ((uint64_t)hi << 32);
+    return r;
+}
+__device__ __forceinline__ uint32_t nib8_at(const Nib8 &w, uint64_t n) {
+    const uint32_t byte = (uint32_t)((w.word >> (8 * ((n >> 1) - w.byte0))) & 0xffu);
+    return (n & 1) ? (byte & 15u) : (byte >> 4);
+}
+
 __global__ void traceback_kernel(TbArgs a) {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     int src = item, c0 = 0;
@@ -928,34 +948,7 @@ __global__ void traceback_kernel(TbArgs a) {
     int i = f.end_q, j = f.end_r, state = 0;
     int32_t h = f.score;
     bool done = false, left_range = false;  // path ended (H reached 0) / path left the traced steps
-    while (i >= 0 && j >= 0) {
-        if (c0 > 0 && j + i / R < c0) { left_range = true; break; }  // cell (i, j) was computed at step j + i/R
-        const uint32_t nb = a.packed ? trace_nibble_pk(tq, R, g, half, i, j - c0) : trace_nibble(tq, R, g, i, j);
-        int op;
-        if (state == 0) {
-            if (h == 0) { done = true; break; }
-            if (!(nb & 8u)) {  // H == D
-                uint32_t qc = rcq ? lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)(lq - 1 - i)))
-                                  : nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)i);
-                const uint32_t rcode = nib_at(a.r_nib, w.r_base + (uint64_t)j);
-                const uint32_t cq = lut4(CLASS_LUT, qc), cr = lut4(CLASS_LUT, rcode);
-                const int32_t wsc = (cq == 5 || cr == 5) ? 0 : (cq == cr ? a.sc.match : a.sc.mismatch);
-                op = (qc == rcode && qc != 0) ? 7 : 8;  // '=' : 'X' by residue equality
-                h -= wsc;
-                i--; j--;
-            } else {
-                state = (nb & 4u) ? 1 : 2;  // H == F (query-only) has priority over E
-                continue;
-            }
-        } else if (state == 1) {  // E: consumes reference only -> 'D'
-            op = 2;
-            if (nb & 2u) { h += open; state = 0; } else h += ext;
-            j--;
-        } else {                  // F: consumes query only -> 'I'
-            op = 1;
-            if (nb & 1u) { h += open; state = 0; } else h += ext;
-            i--;
-        }
+    auto emit = [&](int op) {
         if (op == cur_op) cur_len++;
         else {
             if (cur_op >= 0) {
@@ -965,6 +958,68 @@ __global__ void traceback_kernel(TbArgs a) {
                 n_runs++;
             }
             cur_op = op; cur_len = 1;
+        }
+    };
+    auto in_range = [&](int ii, int jj) { return ii >= 0 && jj >= 0 && !(c0 > 0 && jj + ii / R < c0); };
+    auto nibble = [&](int ii, int jj) {
+        return a.packed ? trace_nibble_pk(tq, R, g, half, ii, jj - c0) : trace_nibble(tq, R, g, ii, jj);
+    };
+    constexpr int DIAG_BATCH = 8;
+    while (i >= 0 && j >= 0) {
+        if (c0 > 0 && j + i / R < c0) { left_range = true; break; }  // cell (i, j) was computed at step j + i/R
+        if (state == 0) {
+            // A path is mostly diagonal runs, and every step of this walk is a chain of dependent global loads
+            // (trace nibble, query base, window base).  Fetch the next DIAG_BATCH cells of the diagonal at once and
+            // consume them while the flags say "diagonal": one memory round trip per 8 steps instead of per step.
+            uint32_t nbk[DIAG_BATCH], qck[DIAG_BATCH], rck[DIAG_BATCH];
+            bool vk[DIAG_BATCH];
+            // the batch's 8 query and 8 window bases are 8 consecutive nibbles each: two aligned dwords per
+            // sequence instead of 8 byte loads (this kernel is bound by its scattered memory transactions)
+            const int nv = min(DIAG_BATCH, min(i, j) + 1);  // cells of the batch inside the matrix
+            const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - i) : (uint64_t)w.q_base + (uint32_t)(i - (nv - 1));
+            const uint64_t rn_lo = w.r_base + (uint64_t)(j - (nv - 1));
+            const Nib8 qw = load_nib8(a.q_nib, qn_lo), rw = load_nib8(a.r_nib, rn_lo);
+#pragma unroll
+            for (int k = 0; k < DIAG_BATCH; k++) {
+                const int ii = i - k, jj = j - k;
+                vk[k] = in_range(ii, jj);
+                nbk[k] = 0; qck[k] = 0; rck[k] = 0;
+                if (vk[k]) {
+                    nbk[k] = nibble(ii, jj);
+                    const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
+                    qck[k] = rcq ? lut4(COMP_LUT, qraw) : qraw;
+                    rck[k] = nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k));
+                }
+            }
+            bool stop = false;
+#pragma unroll
+            for (int k = 0; k < DIAG_BATCH; k++) {
+                if (stop) continue;
+                if (!vk[k]) { stop = true; continue; }          // the outer loop re-checks bounds and range
+                if (h == 0) { done = true; stop = true; continue; }
+                if (nbk[k] & 8u) {                               // H != D: H == F (query-only) has priority over E
+                    state = (nbk[k] & 4u) ? 1 : 2;
+                    stop = true;
+                    continue;
+                }
+                const uint32_t cq = lut4(CLASS_LUT, qck[k]), cr = lut4(CLASS_LUT, rck[k]);
+                const int32_t wsc = (cq == 5 || cr == 5) ? 0 : (cq == cr ? a.sc.match : a.sc.mismatch);
+                h -= wsc;
+                emit((qck[k] == rck[k] && qck[k] != 0) ? 7 : 8);  // '=' : 'X' by residue equality
+                i--; j--;
+            }
+            if (done) break;
+            continue;
+        }
+        const uint32_t nb = nibble(i, j);
+        if (state == 1) {  // E: consumes reference only -> 'D'
+            if (nb & 2u) { h += open; state = 0; } else h += ext;
+            j--;
+            emit(2);
+        } else {           // F: consumes query only -> 'I'
+            if (nb & 1u) { h += open; state = 0; } else h += ext;
+            i--;
+            emit(1);
         }
     }
     if (cur_op >= 0) {
