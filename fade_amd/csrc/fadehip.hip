@@ -26,12 +26,23 @@ struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     DevBuf tid, pos, lseq, flag, has_sa, cigar_off, cigar_ops, seq_off, seq;
-    DevBuf rs, fwd, aln, counters, counters64, stats, trace;
-    DevBuf ckpt, cand, sel_counters, incomplete;  // two-pass path
+    DevBuf rs, fwd, aln, trace;
+    DevBuf ckpt, cand, incomplete;  // two-pass path
+    // All small counters of a run live in one block so that one memset clears them and one copy reads the gate's:
+    //   [0,24) counters64 | [32,96) stats | [96,180) counters | [192 + 48 c, ...) selection counters of class c
+    DevBuf zblock;
+    static constexpr size_t ZB_C64 = 0, ZB_STATS = 32, ZB_COUNTERS = 96, ZB_GATE_BYTES = 192, ZB_SEL = 192, ZB_SEL_STRIDE = 48,
+                            ZB_BYTES = 192 + 48 * NUM_CLASSES + 32;
+    unsigned long long *d_counters64() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_C64); }
+    unsigned long long *d_stats() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_STATS); }
+    uint32_t *d_counters() const { return (uint32_t *)((uint8_t *)zblock.p + ZB_COUNTERS); }
+    uint32_t *d_sel(int cls) const { return (uint32_t *)((uint8_t *)zblock.p + ZB_SEL + ZB_SEL_STRIDE * (size_t)cls); }
+    bool sel_fresh[NUM_CLASSES] = {};  // class's selection counters were cleared by the run's memset and not used yet
     uint32_t *h_sel = nullptr;                   // pinned: NUM_BUCKETS + 1
     DevBuf work[NUM_CLASSES], meta[NUM_CLASSES];
-    uint32_t *h_counters = nullptr;            // pinned: 2*NC+1
-    unsigned long long *h_counters64 = nullptr;  // pinned: 3
+    uint8_t *h_gate = nullptr;                 // pinned: the first ZB_GATE_BYTES of zblock after the gate
+    uint32_t *h_counters = nullptr;            // view into h_gate: 2*NC+1
+    unsigned long long *h_counters64 = nullptr;  // view into h_gate: 3
     unsigned long long *h_stats = nullptr;       // pinned: 8
     int n_reads = 0;
     int state = 0;  // 0 idle, 1 uploaded, 2 ran
@@ -231,8 +242,9 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
     const int64_t chunk_oct = std::max<int64_t>(1, std::min<int64_t>(total_oct, (budget / 2) / std::max<int64_t>(ck_bytes, 1)));
     int rc;
     if ((rc = reserve(ctx, s.ckpt, (size_t)(chunk_oct * ck_bytes))) || (rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd))) ||
-        (rc = reserve(ctx, s.sel_counters, sizeof(uint32_t) * (NUM_BUCKETS + 1))))
+        (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)))
         return rc;
+    uint32_t *const sel_counters = s.d_sel(cls);
     for (int64_t o0 = 0; o0 < total_oct; o0 += chunk_oct) {
         const int octs = (int)std::min<int64_t>(chunk_oct, total_oct - o0);
         const int i0 = (int)(o0 * 8);
@@ -240,7 +252,8 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         if ((rc = reserve(ctx, s.cand, sizeof(Cand) * (size_t)NUM_BUCKETS * (size_t)n)) ||
             (rc = reserve(ctx, s.incomplete, sizeof(Cand) * (size_t)n)))
             return rc;
-        HIPCHK(ctx, hipMemsetAsync(s.sel_counters.p, 0, sizeof(uint32_t) * (NUM_BUCKETS + 1), st));
+        if (!s.sel_fresh[cls]) HIPCHK(ctx, hipMemsetAsync(sel_counters, 0, sizeof(uint32_t) * (NUM_BUCKETS + 1), st));
+        s.sel_fresh[cls] = false;
         SwArgs a;
         a.work = work + i0;
         a.n_items = n;
@@ -270,11 +283,11 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         sel.span_slack = ctx->span_slack;
         sel.cand = (Cand *)s.cand.p;
         sel.cap = (uint32_t)n;
-        sel.bucket_n = (uint32_t *)s.sel_counters.p;
+        sel.bucket_n = sel_counters;
         sel.out = out + i0;
         hipLaunchKernelGGL(select_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, sel);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(s.h_sel, s.sel_counters.p, sizeof(uint32_t) * NUM_BUCKETS, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(s.h_sel, sel_counters, sizeof(uint32_t) * NUM_BUCKETS, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         uint32_t bucket_n[NUM_BUCKETS];
         for (int b = 0; b < NUM_BUCKETS; b++) bucket_n[b] = s.h_sel[b];
@@ -338,7 +351,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
             t.packed = 1;
             t.cand = cand;
             t.incomplete = may_be_incomplete ? (Cand *)s.incomplete.p : nullptr;
-            t.incomplete_n = (uint32_t *)s.sel_counters.p + NUM_BUCKETS;
+            t.incomplete_n = sel_counters + NUM_BUCKETS;
             t.tab = tab;
             hipLaunchKernelGGL(traceback_kernel, dim3((oct * 8 + 63) / 64), dim3(64), 0, st, t);
             HIPCHK(ctx, hipGetLastError());
@@ -351,7 +364,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         // candidates whose path left the traced steps: first from 4 snapshots further back, then from step 0
         int n_inc = 0;
         for (int round = 0; round < 2; round++) {
-            HIPCHK(ctx, hipMemcpyAsync(s.h_sel + NUM_BUCKETS, (uint32_t *)s.sel_counters.p + NUM_BUCKETS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(s.h_sel + NUM_BUCKETS, sel_counters + NUM_BUCKETS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             const int m = (int)s.h_sel[NUM_BUCKETS];
             if (m == 0) break;
@@ -360,7 +373,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
             hipLaunchKernelGGL(make_cand_back_kernel, dim3((m + 255) / 256), dim3(256), 0, st, (const Cand *)s.incomplete.p, m,
                                round == 0 ? 4 * CK_COLS : (1 << 30), again);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemsetAsync((uint32_t *)s.sel_counters.p + NUM_BUCKETS, 0, sizeof(uint32_t), st));
+            HIPCHK(ctx, hipMemsetAsync(sel_counters + NUM_BUCKETS, 0, sizeof(uint32_t), st));
             const uint32_t cnt1[1] = {(uint32_t)m};
             const int st1[1] = {max_lr + 15};
             if ((rc = pass2(again, (uint32_t)m, cnt1, st1, 1, round == 0))) return rc;
@@ -541,16 +554,19 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         set_err(ctx, FADEHIP_E_HIP, "hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(FADEHIP_E_HIP);
     }
+    static_assert(sizeof(uint32_t) * (2 * NUM_CLASSES + 1) <= Slot::ZB_GATE_BYTES - Slot::ZB_COUNTERS, "gate counters overflow their slice");
+    static_assert(sizeof(uint32_t) * (NUM_BUCKETS + 1) <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_counters, sizeof(uint32_t) * (2 * NUM_CLASSES + 1)) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_counters64, sizeof(unsigned long long) * 3) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_gate, Slot::ZB_GATE_BYTES) != hipSuccess ||
             hipHostMalloc((void **)&s.h_sel, sizeof(uint32_t) * (NUM_BUCKETS + 1)) != hipSuccess ||
             hipHostMalloc((void **)&s.h_stats, sizeof(unsigned long long) * 8) != hipSuccess) {
             set_err(ctx, FADEHIP_E_HIP, "stream / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(FADEHIP_E_HIP);
         }
+        s.h_counters64 = (unsigned long long *)(s.h_gate + Slot::ZB_C64);
+        s.h_counters = (uint32_t *)(s.h_gate + Slot::ZB_COUNTERS);
     }
     *out = ctx;
     return 0;
@@ -563,16 +579,14 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
         for (DevBuf *b : {&s.tid, &s.pos, &s.lseq, &s.flag, &s.has_sa, &s.cigar_off, &s.cigar_ops, &s.seq_off, &s.seq,
-                          &s.rs, &s.fwd, &s.aln, &s.counters, &s.counters64, &s.stats, &s.trace, &s.ckpt, &s.cand,
-                          &s.sel_counters, &s.incomplete})
+                          &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.incomplete})
             release(*b);
         for (int c = 0; c < NUM_CLASSES; c++) {
             release(s.work[c]);
             release(s.meta[c]);
         }
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
-        if (s.h_counters) (void)hipHostFree(s.h_counters);
-        if (s.h_counters64) (void)hipHostFree(s.h_counters64);
+        if (s.h_gate) (void)hipHostFree(s.h_gate);
         if (s.h_sel) (void)hipHostFree(s.h_sel);
         if (s.h_stats) (void)hipHostFree(s.h_stats);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -783,9 +797,7 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         (rc = reserve(ctx, s.seq_off, 4 * ((size_t)n + 1))) || (rc = reserve(ctx, s.cigar_ops, 4 * n_cig + 4)) ||
         (rc = reserve(ctx, s.seq, n_seq + 8)) || (rc = reserve(ctx, s.rs, (size_t)n)) ||
         (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)n)) ||
-        (rc = reserve(ctx, s.counters, sizeof(uint32_t) * (2 * NUM_CLASSES + 1))) ||
-        (rc = reserve(ctx, s.counters64, sizeof(unsigned long long) * 3)) ||
-        (rc = reserve(ctx, s.stats, sizeof(unsigned long long) * 8)))
+        (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)))
         return rc;
     for (int c = 0; c < NUM_CLASSES; c++) {
         if (!present[c]) continue;
@@ -829,9 +841,8 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         s.state = 2;
         return 0;
     }
-    HIPCHK(ctx, hipMemsetAsync(s.counters.p, 0, sizeof(uint32_t) * (2 * NUM_CLASSES + 1), st));
-    HIPCHK(ctx, hipMemsetAsync(s.counters64.p, 0, sizeof(unsigned long long) * 3, st));
-    HIPCHK(ctx, hipMemsetAsync(s.stats.p, 0, sizeof(unsigned long long) * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(s.zblock.p, 0, Slot::ZB_BYTES, st));  // every counter of the run in one fill
+    for (int c = 0; c < NUM_CLASSES; c++) s.sel_fresh[c] = true;
     if ((rc = record(ctx, s, &s.ev_gate0))) return rc;
     GateArgs g;
     g.n_reads = n;
@@ -854,13 +865,12 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         g.work[c] = (Work *)s.work[c].p;
         g.meta[c] = (Meta *)s.meta[c].p;
     }
-    g.counters = (uint32_t *)s.counters.p;
-    g.counters64 = (unsigned long long *)s.counters64.p;
+    g.counters = s.d_counters();
+    g.counters64 = s.d_counters64();
     hipLaunchKernelGGL(gate_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, g);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(s.h_counters, s.counters.p, sizeof(uint32_t) * (2 * NUM_CLASSES + 1), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.h_counters64, s.counters64.p, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(s.h_gate, s.zblock.p, Slot::ZB_GATE_BYTES, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     const uint32_t errbits = s.h_counters[2 * NUM_CLASSES];
     if (errbits) {
@@ -882,7 +892,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     }
     s.n_aln = base;
     hipLaunchKernelGGL(stats_kernel, dim3(std::min(128, (n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)s.rs.p, n,
-                       (unsigned long long *)s.stats.p);
+                       s.d_stats());
     HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_end))) return rc;
     s.prof_counts[0] = base;
@@ -919,7 +929,7 @@ int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out) 
         return set_err(ctx, FADEHIP_E_INVALID, "out->aln holds %d entries, %d needed", out->aln ? out->aln_cap : 0, s.n_aln);
     HIPCHK(ctx, hipMemcpyAsync(out->rs, s.rs.p, (size_t)n, hipMemcpyDeviceToHost, st));
     if (s.n_aln) HIPCHK(ctx, hipMemcpyAsync(out->aln, s.aln.p, sizeof(fadehip_aln) * (size_t)s.n_aln, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.h_stats, s.stats.p, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(s.h_stats, s.d_stats(), sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     out->n_aln = s.n_aln;
     for (int k = 0; k < 8; k++) out->stats[k] = (int64_t)s.h_stats[k];
