@@ -29,10 +29,11 @@ struct Slot {
     DevBuf rs, fwd, aln, trace;
     DevBuf ckpt, cand, incomplete;  // two-pass path
     // All small counters of a run live in one block so that one memset clears them and one copy reads the gate's:
-    //   [0,24) counters64 | [32,96) stats | [96,180) counters | [192 + 48 c, ...) selection counters of class c
+    //   [0,24) counters64 | [32,116) counters | [128 + 48 c, ...) selection counters of class c |
+    //   [640, 1152) stats: STAT_PARTS partial sums of the 8 stats.d counters (spreads the same-address atomics)
     DevBuf zblock;
-    static constexpr size_t ZB_C64 = 0, ZB_STATS = 32, ZB_COUNTERS = 96, ZB_GATE_BYTES = 192, ZB_SEL = 192, ZB_SEL_STRIDE = 48,
-                            ZB_BYTES = 192 + 48 * NUM_CLASSES + 32;
+    static constexpr size_t ZB_C64 = 0, ZB_COUNTERS = 32, ZB_GATE_BYTES = 128, ZB_SEL = 128, ZB_SEL_STRIDE = 48,
+                            ZB_STATS = 640, ZB_BYTES = 640 + 8 * 8 * STAT_PARTS;
     unsigned long long *d_counters64() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_C64); }
     unsigned long long *d_stats() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_STATS); }
     uint32_t *d_counters() const { return (uint32_t *)((uint8_t *)zblock.p + ZB_COUNTERS); }
@@ -43,7 +44,7 @@ struct Slot {
     uint8_t *h_gate = nullptr;                 // pinned: the first ZB_GATE_BYTES of zblock after the gate
     uint32_t *h_counters = nullptr;            // view into h_gate: 2*NC+1
     unsigned long long *h_counters64 = nullptr;  // view into h_gate: 3
-    unsigned long long *h_stats = nullptr;       // pinned: 8
+    unsigned long long *h_stats = nullptr;       // pinned: 8 * STAT_PARTS partial sums
     int n_reads = 0;
     int state = 0;  // 0 idle, 1 uploaded, 2 ran
     int n_aln = 0;
@@ -345,6 +346,8 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
             t.sc = ctx->sc;
             t.out = out + i0;
             t.rs = rs;
+        t.stats = (rs && gate) ? s.d_stats() : nullptr;
+            t.stats = (rs && gate) ? s.d_stats() : nullptr;
             t.floor_len = floor_len;
             t.gate = gate;
             t.early_out = (gate && meta && !ctx->prm.trace_all) ? 1 : 0;
@@ -456,6 +459,7 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         t.sc = ctx->sc;
         t.out = out + i0;
         t.rs = rs;
+        t.stats = (rs && gate) ? s.d_stats() : nullptr;
         t.floor_len = floor_len;
         t.gate = gate;
         t.early_out = 0;
@@ -555,13 +559,14 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         return fail(FADEHIP_E_HIP);
     }
     static_assert(sizeof(uint32_t) * (2 * NUM_CLASSES + 1) <= Slot::ZB_GATE_BYTES - Slot::ZB_COUNTERS, "gate counters overflow their slice");
+    static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
     static_assert(sizeof(uint32_t) * (NUM_BUCKETS + 1) <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipHostMalloc((void **)&s.h_gate, Slot::ZB_GATE_BYTES) != hipSuccess ||
             hipHostMalloc((void **)&s.h_sel, sizeof(uint32_t) * (NUM_BUCKETS + 1)) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_stats, sizeof(unsigned long long) * 8) != hipSuccess) {
+            hipHostMalloc((void **)&s.h_stats, sizeof(unsigned long long) * 8 * STAT_PARTS) != hipSuccess) {
             set_err(ctx, FADEHIP_E_HIP, "stream / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(FADEHIP_E_HIP);
         }
@@ -836,7 +841,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     s.n_rerun = 0;
     memset(s.prof_counts, 0, sizeof s.prof_counts);
     if (n == 0) {
-        memset(s.h_stats, 0, sizeof(unsigned long long) * 8);
+        memset(s.h_stats, 0, sizeof(unsigned long long) * 8 * STAT_PARTS);
         s.ev_gate0 = s.ev_gate1 = s.ev_end = -1;
         s.state = 2;
         return 0;
@@ -865,6 +870,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         g.work[c] = (Work *)s.work[c].p;
         g.meta[c] = (Meta *)s.meta[c].p;
     }
+    g.stats = s.d_stats();
     g.counters = s.d_counters();
     g.counters64 = s.d_counters64();
     hipLaunchKernelGGL(gate_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, g);
@@ -891,9 +897,6 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         base += cnt;
     }
     s.n_aln = base;
-    hipLaunchKernelGGL(stats_kernel, dim3(std::min(128, (n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)s.rs.p, n,
-                       s.d_stats());
-    HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_end))) return rc;
     s.prof_counts[0] = base;
     s.prof_counts[1] = (int64_t)s.h_counters64[0];
@@ -929,10 +932,11 @@ int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out) 
         return set_err(ctx, FADEHIP_E_INVALID, "out->aln holds %d entries, %d needed", out->aln ? out->aln_cap : 0, s.n_aln);
     HIPCHK(ctx, hipMemcpyAsync(out->rs, s.rs.p, (size_t)n, hipMemcpyDeviceToHost, st));
     if (s.n_aln) HIPCHK(ctx, hipMemcpyAsync(out->aln, s.aln.p, sizeof(fadehip_aln) * (size_t)s.n_aln, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.h_stats, s.d_stats(), sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(s.h_stats, s.d_stats(), sizeof(unsigned long long) * 8 * STAT_PARTS, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     out->n_aln = s.n_aln;
-    for (int k = 0; k < 8; k++) out->stats[k] = (int64_t)s.h_stats[k];
+    for (int k = 0; k < 8; k++)
+        for (int q = 0; q < STAT_PARTS; q++) out->stats[k] += (int64_t)s.h_stats[8 * q + k];
     return 0;
 }
 

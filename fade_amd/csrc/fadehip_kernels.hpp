@@ -16,7 +16,8 @@
 // Default pipeline (two-pass):
 //   gate_kernel -> sw_pk_kernel<R,1> (score + end cell + wave snapshots) -> select_kernel (who needs a CIGAR,
 //   from which step) -> sw_pk_kernel<R,2> (traced re-computation of those steps) -> traceback_kernel (CIGAR,
-//   FADE's gates, rs bits) -> stats_kernel.  sw_pk_kernel<R,0> and sw_forward_kernel<R> are the single-pass
+//   FADE's gates, rs bits).  The stats.d:45-54 counters are summed on the way: gate_kernel counts reads, clipped
+//   and supplementary ones, traceback_kernel the artifact calls.  sw_pk_kernel<R,0> and sw_forward_kernel<R> are the single-pass
 //   packed / int32 variants kept for A/B measurements (FADEHIP_KERNEL=pk|int32).
 #pragma once
 #include <type_traits>
@@ -52,6 +53,7 @@ __host__ __device__ constexpr uint64_t make_comp_lut() {
 constexpr uint64_t CLASS_LUT = make_class_lut();
 constexpr uint64_t COMP_LUT = make_comp_lut();
 constexpr int PAD_CLASS = 6;
+constexpr int STAT_PARTS = 8;  // the stats.d counters are kept as this many partial sums (stats[8 * part + k])
 
 __device__ __forceinline__ uint32_t lut4(uint64_t lut, uint32_t code) { return (uint32_t)(lut >> (4 * code)) & 15u; }
 // base b of a packed array: byte b>>1, even base in the high nibble (BAM convention).
@@ -142,6 +144,7 @@ struct GateArgs {
     Meta *meta[NUM_CLASSES];
     uint32_t *counters;  // [0..NC) item counts, [NC..2NC) max lr, [2NC] error bits
     unsigned long long *counters64;  // [0] DP cells, [1] packed sequence bytes read (query + window), [2] checkpoint bytes
+    unsigned long long *stats;       // stats.d:45-54: [0] read_count, [1] clipped, [2] sup (the artifact counters come from traceback_kernel)
 };
 
 constexpr int GATE_BLOCK = 1024;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // per-thread contribution to the batch counters; reduced per wave before touching memory
     unsigned long long cells = 0, seq_bytes = 0, ck_bytes = 0;
-    uint32_t lr_for_max = 0, errbits = 0;
+    uint32_t lr_for_max = 0, errbits = 0, st_bits = 0;
     int cls = -1;
     Work w;
     Meta m;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
             want = (clipL != 0 && (int64_t)clipL > a.floor_len) || (clipR != 0 && (int64_t)clipR > a.floor_len);
         }
         a.rs[i] = rs;
+        st_bits = 4u | (rs & 1u) | ((rs >> 4) & 2u);  // bit2 read, bit0 clipped, bit1 sup
         const int32_t tid = a.tid[i];
         const int32_t lq = a.l_seq[i];
         if (want && (tid < 0 || tid >= a.n_contigs)) {
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     // this kernel)
     __shared__ uint32_t s_cnt[NUM_CLASSES], s_base[NUM_CLASSES], s_maxlr[NUM_CLASSES], s_err, s_items;
     __shared__ unsigned long long s_cells, s_bytes, s_ck;
-    __shared__ uint32_t s_key[GATE_BLOCK], s_rank[GATE_BLOCK];
+    __shared__ uint32_t s_key[GATE_BLOCK], s_rank[GATE_BLOCK], s_stat[3];
     if (threadIdx.x < NUM_CLASSES) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; s_items = 0; }
+    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; s_items = 0; s_stat[0] = s_stat[1] = s_stat[2] = 0; }
     __syncthreads();
     uint32_t compact = 0;
     if (cls >= 0) {
@@ -248,6 +252,15 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         }
     }
     if (errbits) atomicOr(&s_err, errbits);
+    {
+        // stats.d:45-54, the part known here: reads, clipped, supplementary — one LDS add per wave and counter
+        const unsigned long long m_read = __ballot(st_bits & 4u), m_sc = __ballot(st_bits & 1u), m_sup = __ballot(st_bits & 2u);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_stat[0], (uint32_t)__popcll(m_read));
+            if (m_sc) atomicAdd(&s_stat[1], (uint32_t)__popcll(m_sc));
+            if (m_sup) atomicAdd(&s_stat[2], (uint32_t)__popcll(m_sup));
+        }
+    }
     __syncthreads();
     if (threadIdx.x < NUM_CLASSES && s_cnt[threadIdx.x]) {
         s_base[threadIdx.x] = atomicAdd(&a.counters[threadIdx.x], s_cnt[threadIdx.x]);
@@ -261,6 +274,8 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         }
         if (s_err) atomicOr(&a.counters[2 * NUM_CLASSES], s_err);
     }
+    if (threadIdx.x >= 64 && threadIdx.x < 67 && a.stats && s_stat[threadIdx.x - 64])
+        atomicAdd(&a.stats[8 * (blockIdx.x % STAT_PARTS) + threadIdx.x - 64], (unsigned long long)s_stat[threadIdx.x - 64]);
     // The block's items of one class are appended in order of decreasing window length: the eight alignments of
     // a wave sweep max(lr) + 15 steps, so neighbours of equal length waste none (C2: 339 -> 323 columns per
     // octet).  Rank = items of the same class with a longer window (ties by list position); a block holds
@@ -861,6 +876,7 @@ struct TbArgs {
     ScoreTab sc;
     fadehip_aln *out;       // [n_items] at this launch's base
     uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
+    unsigned long long *stats;  // level 2: stats.d:45-54 [3] art_sup, [4] art, [6] aln_l, [7] aln_r are added here
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
     int32_t early_out;      // 1: a path that leaves the traced steps with > 10 ops already is not re-run (see below)
@@ -908,24 +924,24 @@ __device__ __forceinline__ uint32_t nib8_at(const Nib8 &w, uint64_t n) {
     return (n & 1) ? (byte & 15u) : (byte >> 4);
 }
 
-__global__ void traceback_kernel(TbArgs a) {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+// one alignment; returns the artifact bits it set (bit0 left, bit1 right) | 4 if the read is supplementary
+__device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int item) {
     int src = item, c0 = 0;
     uint64_t trace_off;
     if (a.cand) {
         const int oct = item >> 3;
         int b = 0;
-        if (oct >= (int)a.tab.oct_first[NUM_BUCKETS]) return;
+        if (oct >= (int)a.tab.oct_first[NUM_BUCKETS]) return 0u;
         while (oct >= (int)a.tab.oct_first[b + 1]) b++;
         const int local = oct - (int)a.tab.oct_first[b];
         const int k = local * 8 + (item & 7);
-        if (k >= (int)a.tab.count[b]) return;
+        if (k >= (int)a.tab.count[b]) return 0u;
         const Cand c = a.cand[(uint64_t)a.tab.bucket[b] * a.tab.cap + k];
         src = (int)c.src;
         c0 = (int)c.c0;
         trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
     } else {
-        if (item >= a.n_items) return;
+        if (item >= a.n_items) return 0u;
         trace_off = (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
     }
     const Work w = a.work[src];
@@ -1049,7 +1065,7 @@ __global__ void traceback_kernel(TbArgs a) {
         o.clip_right = m.clip_right;
         o.aligned_len = m.aligned_len;
         a.out[src] = o;
-        return;
+        return 0u;
     }
     if (left_range && !(state == 0 && h == 0)) {
         // the path continues before step T0: this candidate is re-run from the start of the sweep
@@ -1058,8 +1074,9 @@ __global__ void traceback_kernel(TbArgs a) {
         again.src = (uint32_t)src;
         again.c0 = (uint32_t)c0;
         a.incomplete[k] = again;
-        return;
+        return 0u;
     }
+    uint32_t art_ret = 0;
     fadehip_aln o;
     o.read_idx = (int32_t)w.idx;
     o.art = 0;
@@ -1114,7 +1131,11 @@ __global__ void traceback_kernel(TbArgs a) {
             if (m.clip_right != 0 && m.clip_right > a.floor_len && (first_op & 15u) == 7u &&
                 5 * (int64_t)f.score > 9 * (int64_t)m.clip_right && lead_s == 0 && trail_s != 0)
                 o.art |= 2;
-            if (o.art) a.rs[w.idx] |= (uint8_t)(o.art << 1);  // readstatus.d: bit1 art_left, bit2 art_right
+            if (o.art) {  // readstatus.d: bit1 art_left, bit2 art_right
+                const uint8_t before = a.rs[w.idx];
+                a.rs[w.idx] = before | (uint8_t)(o.art << 1);
+                art_ret = (uint32_t)o.art | ((before & 32u) ? 4u : 0u);
+            }
         }
     } else {
         o.win_start = 0;
@@ -1122,6 +1143,23 @@ __global__ void traceback_kernel(TbArgs a) {
         o.clip_left = o.clip_right = o.aligned_len = 0;
     }
     a.out[src] = o;
+    return art_ret;
+}
+
+__global__ void traceback_kernel(TbArgs a) {
+    const uint32_t r = traceback_one(a, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+    if (a.stats) {
+        // stats.d:45-54, the artifact part: per-wave popcounts, one atomic per wave and non-zero counter
+        const unsigned long long m_art = __ballot(r & 3u), m_sup = __ballot((r & 3u) && (r & 4u)), m_l = __ballot(r & 1u),
+                                 m_r = __ballot(r & 2u);
+        if ((threadIdx.x & 63) == 0 && m_art) {
+            unsigned long long *st = a.stats + 8 * (blockIdx.x % STAT_PARTS);
+            atomicAdd(&st[4], (unsigned long long)__popcll(m_art));
+            if (m_sup) atomicAdd(&st[3], (unsigned long long)__popcll(m_sup));
+            if (m_l) atomicAdd(&st[6], (unsigned long long)__popcll(m_l));
+            if (m_r) atomicAdd(&st[7], (unsigned long long)__popcll(m_r));
+        }
+    }
 }
 
 // ---------------------------------------------------------------- pass-2 selection
@@ -1206,36 +1244,6 @@ __global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
     if (threadIdx.x < NUM_BUCKETS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bucket_n[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
     if (b >= 0) a.cand[(uint64_t)b * a.cap + s_base[b] + local_slot] = c;
-}
-
-// ---------------------------------------------------------------- stats.d:45-54 over rs
-__global__ __launch_bounds__(256) void stats_kernel(const uint8_t *rs, int n, unsigned long long *counters) {
-    __shared__ unsigned long long part[4][8];
-    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t v = rs[i];
-        const uint32_t sc = v & 1, al = (v >> 1) & 1, ar = (v >> 2) & 1, ml = (v >> 3) & 1, mr = (v >> 4) & 1,
-                       sup = (v >> 5) & 1;
-        c[0] += 1;
-        c[1] += sc;
-        c[2] += sup;
-        c[3] += (al | ar) & sup;
-        c[4] += (al | ar);
-        c[5] += ((al & ml) | (ar & mr));
-        c[6] += al;
-        c[7] += ar;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        unsigned long long v = c[k];
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        if (v) atomicAdd(&counters[threadIdx.x], v);
-    }
 }
 
 }  // namespace fadehip
