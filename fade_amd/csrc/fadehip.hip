@@ -28,12 +28,14 @@ struct Slot {
     DevBuf tid, pos, lseq, flag, has_sa, cigar_off, cigar_ops, seq_off, seq;
     DevBuf rs, fwd, aln, trace;
     DevBuf ckpt, cand, incomplete;  // two-pass path
-    // All small counters of a run live in one block so that one memset clears them and one copy reads the gate's:
-    //   [0,24) counters64 | [32,116) counters | [128 + 48 c, ...) selection counters of class c |
-    //   [640, 1152) stats: STAT_PARTS partial sums of the 8 stats.d counters (spreads the same-address atomics)
+    // All small counters of a run live in one block so that one memset clears them and one copy reads the gate's.
+    // Counters that different kernels (or different atomics of one kernel) hammer sit in different 128-byte lines:
+    // same-line atomics serialise in one L2 channel (the gate kernel took 60 instead of 49 us with them packed).
+    //   [0,84) counters | [128,512) counters64, one line each | [512 + 48 c, ...) selection counters of class c |
+    //   [1024, 1536) stats: STAT_PARTS partial sums of the 8 stats.d counters
     DevBuf zblock;
-    static constexpr size_t ZB_C64 = 0, ZB_COUNTERS = 32, ZB_GATE_BYTES = 128, ZB_SEL = 128, ZB_SEL_STRIDE = 48,
-                            ZB_STATS = 640, ZB_BYTES = 640 + 8 * 8 * STAT_PARTS;
+    static constexpr size_t ZB_COUNTERS = 0, ZB_C64 = 128, ZB_GATE_BYTES = 512, ZB_SEL = 512, ZB_SEL_STRIDE = 48,
+                            ZB_STATS = 1024, ZB_BYTES = 1024 + 8 * 8 * STAT_PARTS;
     unsigned long long *d_counters64() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_C64); }
     unsigned long long *d_stats() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_STATS); }
     uint32_t *d_counters() const { return (uint32_t *)((uint8_t *)zblock.p + ZB_COUNTERS); }
@@ -558,7 +560,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         set_err(ctx, FADEHIP_E_HIP, "hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(FADEHIP_E_HIP);
     }
-    static_assert(sizeof(uint32_t) * (2 * NUM_CLASSES + 1) <= Slot::ZB_GATE_BYTES - Slot::ZB_COUNTERS, "gate counters overflow their slice");
+    static_assert(sizeof(uint32_t) * (2 * NUM_CLASSES + 1) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
     static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
     static_assert(sizeof(uint32_t) * (NUM_BUCKETS + 1) <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
@@ -899,12 +901,12 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     s.n_aln = base;
     if ((rc = record(ctx, s, &s.ev_end))) return rc;
     s.prof_counts[0] = base;
-    s.prof_counts[1] = (int64_t)s.h_counters64[0];
+    s.prof_counts[1] = (int64_t)s.h_counters64[0 * C64_STRIDE];
     // algorithmic bytes of the forward kernel: packed query + packed window +
     // 16 B descriptor + 64 B result slot + 4-bit trace cell
     // two-pass: the dominant kernel (pass 1) writes H/E checkpoints instead of the trace
-    s.prof_counts[3] = (int64_t)s.h_counters64[1] + (int64_t)base * 80 +
-                       (ctx->two_pass ? (int64_t)s.h_counters64[2] : (int64_t)(s.h_counters64[0] / 2));
+    s.prof_counts[3] = (int64_t)s.h_counters64[1 * C64_STRIDE] + (int64_t)base * 80 +
+                       (ctx->two_pass ? (int64_t)s.h_counters64[2 * C64_STRIDE] : (int64_t)(s.h_counters64[0 * C64_STRIDE] / 2));
     s.state = 2;
     return 0;
 }

@@ -53,6 +53,7 @@ __host__ __device__ constexpr uint64_t make_comp_lut() {
 constexpr uint64_t CLASS_LUT = make_class_lut();
 constexpr uint64_t COMP_LUT = make_comp_lut();
 constexpr int PAD_CLASS = 6;
+constexpr int C64_STRIDE = 16;  // the three 64-bit batch counters sit 128 bytes apart (one L2 line each)
 constexpr int STAT_PARTS = 8;  // the stats.d counters are kept as this many partial sums (stats[8 * part + k])
 
 __device__ __forceinline__ uint32_t lut4(uint64_t lut, uint32_t code) { return (uint32_t)(lut >> (4 * code)) & 15u; }
@@ -143,7 +144,7 @@ struct GateArgs {
     Work *work[NUM_CLASSES];
     Meta *meta[NUM_CLASSES];
     uint32_t *counters;  // [0..NC) item counts, [NC..2NC) max lr, [2NC] error bits
-    unsigned long long *counters64;  // [0] DP cells, [1] packed sequence bytes read (query + window), [2] checkpoint bytes
+    unsigned long long *counters64;  // [k * C64_STRIDE]: k = 0 DP cells, 1 packed sequence bytes read (query + window), 2 checkpoint bytes
     unsigned long long *stats;       // stats.d:45-54: [0] read_count, [1] clipped, [2] sup (the artifact counters come from traceback_kernel)
 };
 
@@ -268,9 +269,9 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     }
     if (threadIdx.x == 0) {
         if (s_cells) {
-            atomicAdd(&a.counters64[0], s_cells);
-            atomicAdd(&a.counters64[1], s_bytes);
-            atomicAdd(&a.counters64[2], s_ck);
+            atomicAdd(&a.counters64[0 * C64_STRIDE], s_cells);
+            atomicAdd(&a.counters64[1 * C64_STRIDE], s_bytes);
+            atomicAdd(&a.counters64[2 * C64_STRIDE], s_ck);
         }
         if (s_err) atomicOr(&a.counters[2 * NUM_CLASSES], s_err);
     }
