@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
 // advances two cells.  The scale makes every positive difference >= 8, which turns the four trace
 // flags into v_pk_min_u16(diff, weight) with weights 8,4,2,1 — a nibble per cell by plain addition.
 // One wave = 8 alignments ("octet").  Trace: [block of 4 steps][R dwords][64 lanes], each dword =
-// 4 cell-pairs, nibble (3 - p%4) of the low / high half for alignment A / B, p = s*R + r.
+// 4 cell-pairs of one diagonal (see trace_nibble_pk), low / high half for alignment A / B.
 typedef short s2v __attribute__((ext_vector_type(2)));
 typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s2v as_s2(uint32_t x) { return __builtin_bit_cast(s2v, x); }
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                     const uint32_t m2 = pk_min_k<4>(pk_sub(T, Fn));
                     const uint32_t m3 = pk_min_k<2>(pk_sub(En, Ee));
                     const uint32_t m4 = pk_min_k<1>(pk_sub(Fn, Fe));
-                    uint32_t &ac = acc[(s * R + r) >> 2];
+                    uint32_t &ac = acc[(r - s + R) % R];  // dword k of the block = the 4 cells (s, row (k + s) % R): a diagonal
                     ac = pk_shl4_add(ac, m1) + m2 + m3 + m4;
                 }
                 if constexpr (MODE == 0) {
@@ -897,12 +897,17 @@ __device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int 
     return (wv >> (28 - (k0 & 31))) & 15u;
 }
 
+// Packed trace: [block of 4 steps][R dwords][64 lanes]; dword k of a block holds, for s = 0..3, the cell of step
+// 4*blk + s in row (k + s) % R — four cells of one DP diagonal — at nibble 3 - s of the low / high half (A / B).
+// A traceback that walks a diagonal therefore stays in one dword for up to four steps.
 __device__ __forceinline__ uint32_t trace_nibble_pk(const uint32_t *to, int R, int g, int half, int i, int j) {
     const int lig = i / R, r = i - lig * R;
     const int t = j + lig;
-    const int p = (t & 3) * R + r;
-    const uint32_t wv = to[((uint64_t)(t >> 2) * R + (p >> 2)) * 64 + (g * 16 + lig)];
-    return (wv >> (16 * half + 4 * (3 - (p & 3)))) & 15u;
+    const int s = t & 3;
+    int k = r - s;
+    if (k < 0) k += R;
+    const uint32_t wv = to[((uint64_t)(t >> 2) * R + k) * 64 + (g * 16 + lig)];
+    return (wv >> (16 * half + 4 * (3 - s))) & 15u;
 }
 
 // 8 consecutive nibbles starting at nibble index n0 of a packed sequence: the two aligned dwords that hold them
