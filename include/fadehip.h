@@ -141,7 +141,9 @@ typedef struct {
 
 /* Asynchronous pipeline, slot in [0, FADEHIP_NUM_SLOTS):
  *   upload  : H2D copies of the batch arrays (hipMemcpyAsync on the slot's stream)
- *   run     : gate -> forward SW with trace -> traceback + artifact gates, all on device
+ *   run     : gate -> score pass (SW score, end cell, wave snapshots) -> selection of the alignments that can
+ *             still be artifact calls -> traced re-computation of their last steps -> traceback + artifact
+ *             gates, all on device (three small counter read-backs size the launches)
  *   collect : D2H of rs / aln / stats; blocks until the slot is done
  * submit = upload + run.  Results stay valid until the slot is uploaded again.
  * floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
