@@ -11,6 +11,7 @@ extern (C) nothrow @nogc:
 enum FADEHIP_ABI_VERSION = 1;
 enum FADEHIP_MAX_OPS = 16;
 enum FADEHIP_MAX_QUERY = 512;
+enum FADEHIP_MAX_LONG_QUERY = 32768;
 enum FADEHIP_NUM_SLOTS = 2;
 
 enum : int

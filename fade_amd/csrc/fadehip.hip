@@ -42,7 +42,8 @@ struct Slot {
     uint32_t *d_sel(int cls) const { return (uint32_t *)((uint8_t *)zblock.p + ZB_SEL + ZB_SEL_STRIDE * (size_t)cls); }
     bool sel_fresh[NUM_CLASSES] = {};  // class's selection counters were cleared by the run's memset and not used yet
     uint32_t *h_sel = nullptr;                   // pinned: NUM_BUCKETS + 1
-    DevBuf work[NUM_CLASSES], meta[NUM_CLASSES];
+    DevBuf work[NUM_LISTS], meta[NUM_LISTS];
+    DevBuf lrows;  // sw_long_kernel: previous-row H and F-hat
     uint8_t *h_gate = nullptr;                 // pinned: the first ZB_GATE_BYTES of zblock after the gate
     uint32_t *h_counters = nullptr;            // view into h_gate: 2*NC+1
     unsigned long long *h_counters64 = nullptr;  // view into h_gate: 3
@@ -482,6 +483,78 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
     return 0;
 }
 
+// Queries longer than 512 bases: sw_long_kernel (thread per alignment, full trace) + the common traceback.
+int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const Work *work, const Meta *meta, int n_items, int max_lr, int max_lq,
+             const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out, uint8_t *rs, int32_t floor_len, int gate, int64_t budget,
+             bool timed) {
+    const int lhalf = (max_lr + 1) / 2;
+    const int64_t per_item = (int64_t)max_lq * lhalf + 8 * (int64_t)max_lr;
+    const int64_t chunk = std::min<int64_t>(n_items, budget / std::max<int64_t>(per_item, 1));
+    if (chunk < 1)
+        return set_err(ctx, FADEHIP_E_UNSUPPORTED, "a %d x %d alignment needs %lld B of trace, more than trace_bytes", max_lq, max_lr,
+                       (long long)per_item);
+    int rc;
+    if ((rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd)))) return rc;
+    for (int64_t i0 = 0; i0 < n_items; i0 += chunk) {
+        const int n = (int)std::min<int64_t>(chunk, n_items - i0);
+        if ((rc = reserve(ctx, s.trace, (size_t)max_lq * (size_t)lhalf * (size_t)n)) ||
+            (rc = reserve(ctx, s.lrows, 8 * (size_t)max_lr * (size_t)n)))
+            return rc;
+        LongArgs a;
+        a.work = work + i0;
+        a.n_items = n;
+        a.q_nib = q_nib;
+        a.r_nib = r_nib;
+        a.hrow = (int32_t *)s.lrows.p;
+        a.frow = (int32_t *)s.lrows.p + (size_t)max_lr * (size_t)n;
+        a.trace = (uint8_t *)s.trace.p;
+        a.lhalf = lhalf;
+        a.max_lq = max_lq;
+        a.max_lr = max_lr;
+        a.fwd = (Fwd *)s.fwd.p + i0;
+        a.sc = ctx->sc;
+        int e0 = -1, e1 = -1, e2 = -1;
+        if (timed && (rc = record(ctx, s, &e0))) return rc;
+        hipLaunchKernelGGL(sw_long_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a);
+        HIPCHK(ctx, hipGetLastError());
+        if (timed && (rc = record(ctx, s, &e1))) return rc;
+        TbArgs t;
+        memset(&t, 0, sizeof t);
+        t.work = work + i0;
+        t.meta = meta ? meta + i0 : nullptr;
+        t.fwd = (Fwd *)s.fwd.p + i0;
+        t.n_items = n;
+        t.R = 1;
+        t.q_nib = q_nib;
+        t.r_nib = r_nib;
+        t.trace = nullptr;
+        t.quad_stride = 0;
+        t.sc = ctx->sc;
+        t.out = out + i0;
+        t.rs = rs;
+        t.stats = (rs && gate) ? s.d_stats() : nullptr;
+        t.floor_len = floor_len;
+        t.gate = gate;
+        t.early_out = 0;
+        t.packed = 2;
+        t.ltrace = (const uint8_t *)s.trace.p;
+        t.lhalf = lhalf;
+        t.cand = nullptr;
+        t.incomplete = nullptr;
+        t.incomplete_n = nullptr;
+        hipLaunchKernelGGL(traceback_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t);
+        HIPCHK(ctx, hipGetLastError());
+        if (timed) {
+            if ((rc = record(ctx, s, &e2))) return rc;
+            s.fwd_spans.push_back({e0, e1});
+            s.tb_spans.push_back({e1, e2});
+        }
+        s.prof_counts[2] += (int64_t)max_lq * lhalf * n;
+        s.n_fwd_launches++;
+    }
+    return 0;
+}
+
 int check_slot(fadehip_ctx *ctx, int slot) {
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
     if (slot < 0 || slot >= FADEHIP_NUM_SLOTS) return set_err(ctx, FADEHIP_E_INVALID, "slot %d out of range", slot);
@@ -560,7 +633,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         set_err(ctx, FADEHIP_E_HIP, "hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(FADEHIP_E_HIP);
     }
-    static_assert(sizeof(uint32_t) * (2 * NUM_CLASSES + 1) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
+    static_assert(sizeof(uint32_t) * (2 * NUM_LISTS + 2) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
     static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
     static_assert(sizeof(uint32_t) * (NUM_BUCKETS + 1) <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
@@ -588,7 +661,8 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         for (DevBuf *b : {&s.tid, &s.pos, &s.lseq, &s.flag, &s.has_sa, &s.cigar_off, &s.cigar_ops, &s.seq_off, &s.seq,
                           &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.incomplete})
             release(*b);
-        for (int c = 0; c < NUM_CLASSES; c++) {
+        release(s.lrows);
+        for (int c = 0; c < NUM_LISTS; c++) {
             release(s.work[c]);
             release(s.meta[c]);
         }
@@ -627,15 +701,17 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
     Slot &s = ctx->slots[0];
     const int64_t q_total = q_off[n], r_total = r_off[n];
     // class-partitioned work lists, built on the host from the offsets (no sequence is touched here)
-    std::vector<Work> lists[NUM_CLASSES];
-    int max_lr[NUM_CLASSES] = {0};
+    std::vector<Work> lists[NUM_LISTS];
+    int max_lr[NUM_LISTS] = {0};
+    int max_long_lq = 0;
     std::vector<int> degenerate;
     for (int k = 0; k < n; k++) {
         const int64_t lq = q_off[k + 1] - q_off[k], lr = r_off[k + 1] - r_off[k];
         if (lq < 0 || lr < 0) return set_err(ctx, FADEHIP_E_INVALID, "offsets must be non-decreasing (pair %d)", k);
         if (lq == 0 || lr == 0) { degenerate.push_back(k); continue; }
-        const int cls = class_of_len((int)std::min<int64_t>(lq, 1 << 20));
-        if (cls < 0) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "query %d has %lld bases (max %d)", k, (long long)lq, FADEHIP_MAX_QUERY);
+        const int cls = list_of_len((int)std::min<int64_t>(lq, 1 << 20));
+        if (cls < 0) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "query %d has %lld bases (max %d)", k, (long long)lq, FADEHIP_MAX_LONG_QUERY);
+        if (cls == LONG_LIST) max_long_lq = std::max(max_long_lq, (int)lq);
         if (lr > ctx->prm.max_ref_len)
             return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference %d has %lld bases (max_ref_len %d)", k, (long long)lr, ctx->prm.max_ref_len);
         Work w;
@@ -681,7 +757,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
                            (const uint8_t *)d_r.p, (uint64_t)r_total, (uint64_t)0, (uint8_t *)d_rn.p, 0, (int *)d_bad.p);
     L1CHK(hipGetLastError());
     size_t n_work = 0;
-    for (int c = 0; c < NUM_CLASSES; c++) n_work += lists[c].size();
+    for (int c = 0; c < NUM_LISTS; c++) n_work += lists[c].size();
     if ((rc = reserve(ctx, d_work, std::max<size_t>(1, n_work) * sizeof(Work)))) {
         cleanup();
         return rc;
@@ -690,12 +766,16 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
     size_t base = 0;
     s.fwd_spans.clear();
     s.tb_spans.clear();
-    for (int c = 0; c < NUM_CLASSES; c++) {
+    for (int c = 0; c < NUM_LISTS; c++) {
         if (lists[c].empty()) continue;
         Work *dw = (Work *)d_work.p + base;
         L1CHK(hipMemcpyAsync(dw, lists[c].data(), lists[c].size() * sizeof(Work), hipMemcpyHostToDevice, st));
-        rc = run_class(ctx, s, st, c, dw, nullptr, (int)lists[c].size(), max_lr[c], (const uint8_t *)d_qn.p,
-                       (const uint8_t *)d_rn.p, (fadehip_aln *)d_aln.p + base, nullptr, 0, 0, budget, false);
+        if (c == LONG_LIST)
+            rc = run_long(ctx, s, st, dw, nullptr, (int)lists[c].size(), max_lr[c], max_long_lq, (const uint8_t *)d_qn.p,
+                          (const uint8_t *)d_rn.p, (fadehip_aln *)d_aln.p + base, nullptr, 0, 0, budget, false);
+        else
+            rc = run_class(ctx, s, st, c, dw, nullptr, (int)lists[c].size(), max_lr[c], (const uint8_t *)d_qn.p,
+                           (const uint8_t *)d_rn.p, (fadehip_aln *)d_aln.p + base, nullptr, 0, 0, budget, false);
         if (rc) {
             (void)hipStreamSynchronize(st);
             cleanup();
@@ -793,9 +873,9 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
     const size_t n_cig = b->cigar_off[n], n_seq = b->seq_off[n];
     if ((uint64_t)n_seq * 2 >= ((uint64_t)1 << 32)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "packed sequence bytes per batch must stay below 2^31");
     // classes present decide which work lists exist
-    bool present[NUM_CLASSES] = {false};
+    bool present[NUM_LISTS] = {false};
     for (int i = 0; i < n; i++) {
-        const int c = class_of_len(b->l_seq[i] > 0 ? b->l_seq[i] : 1);
+        const int c = list_of_len(b->l_seq[i] > 0 ? b->l_seq[i] : 1);
         if (c >= 0) present[c] = true;
     }
     if ((rc = reserve(ctx, s.tid, 4 * (size_t)n)) || (rc = reserve(ctx, s.pos, 4 * (size_t)n)) ||
@@ -806,7 +886,7 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)n)) ||
         (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)))
         return rc;
-    for (int c = 0; c < NUM_CLASSES; c++) {
+    for (int c = 0; c < NUM_LISTS; c++) {
         if (!present[c]) continue;
         if ((rc = reserve(ctx, s.work[c], sizeof(Work) * (size_t)n)) || (rc = reserve(ctx, s.meta[c], sizeof(Meta) * (size_t)n)))
             return rc;
@@ -868,7 +948,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     g.contig_base = (const uint64_t *)ctx->contig_base.p;
     g.max_ref_len = ctx->prm.max_ref_len;
     g.rs = (uint8_t *)s.rs.p;
-    for (int c = 0; c < NUM_CLASSES; c++) {
+    for (int c = 0; c < NUM_LISTS; c++) {
         g.work[c] = (Work *)s.work[c].p;
         g.meta[c] = (Meta *)s.meta[c].p;
     }
@@ -880,10 +960,10 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(s.h_gate, s.zblock.p, Slot::ZB_GATE_BYTES, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    const uint32_t errbits = s.h_counters[2 * NUM_CLASSES];
+    const uint32_t errbits = s.h_counters[2 * NUM_LISTS];
     if (errbits) {
         s.state = 1;
-        if (errbits & 2u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a soft-clipped read longer than %d bases", FADEHIP_MAX_QUERY);
+        if (errbits & 2u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a soft-clipped read longer than %d bases", FADEHIP_MAX_LONG_QUERY);
         if (errbits & 4u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a re-alignment window longer than max_ref_len=%d", ctx->prm.max_ref_len);
         return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
     }
@@ -893,8 +973,15 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         const int cnt = (int)s.h_counters[c];
         if (!cnt) continue;
         rc = run_class(ctx, s, st, c, (const Work *)s.work[c].p, (const Meta *)s.meta[c].p, cnt,
-                       (int)s.h_counters[NUM_CLASSES + c], (const uint8_t *)s.seq.p, (const uint8_t *)ctx->genome.p,
+                       (int)s.h_counters[NUM_LISTS + c], (const uint8_t *)s.seq.p, (const uint8_t *)ctx->genome.p,
                        (fadehip_aln *)s.aln.p + base, (uint8_t *)s.rs.p, floor_len, 1, budget, true);
+        if (rc) return rc;
+        base += cnt;
+    }
+    if (const int cnt = (int)s.h_counters[LONG_LIST]) {
+        rc = run_long(ctx, s, st, (const Work *)s.work[LONG_LIST].p, (const Meta *)s.meta[LONG_LIST].p, cnt,
+                      (int)s.h_counters[NUM_LISTS + LONG_LIST], (int)s.h_counters[2 * NUM_LISTS + 1], (const uint8_t *)s.seq.p,
+                      (const uint8_t *)ctx->genome.p, (fadehip_aln *)s.aln.p + base, (uint8_t *)s.rs.p, floor_len, 1, budget, true);
         if (rc) return rc;
         base += cnt;
     }

@@ -91,6 +91,15 @@ __host__ __device__ inline int class_of_len(int lq) {
         if (16 * class_rows(c) >= lq) return c;
     return -1;
 }
+// Work lists: one per row class of the wave kernels plus one for queries longer than 16 * 32 = 512 bases, which
+// take sw_long_kernel (a thread per alignment; rare in short-read libraries, e.g. merged pairs).
+constexpr int LONG_LIST = NUM_CLASSES, NUM_LISTS = NUM_CLASSES + 1;
+constexpr int MAX_LONG_QUERY = 1 << 15;
+__host__ __device__ inline int list_of_len(int lq) {
+    const int c = class_of_len(lq);
+    if (c >= 0) return c;
+    return lq <= MAX_LONG_QUERY ? LONG_LIST : -1;
+}
 
 struct ScoreTab {
     uint32_t prof[8];  // prof[q class] : 8 x 4-bit entries (W + open) indexed by ref class*4
@@ -141,9 +150,9 @@ struct GateArgs {
     const uint64_t *contig_base;  // first base of each contig in the packed genome
     int32_t max_ref_len;
     uint8_t *rs;
-    Work *work[NUM_CLASSES];
-    Meta *meta[NUM_CLASSES];
-    uint32_t *counters;  // [0..NC) item counts, [NC..2NC) max lr, [2NC] error bits
+    Work *work[NUM_LISTS];
+    Meta *meta[NUM_LISTS];
+    uint32_t *counters;  // NL = NUM_LISTS: [0..NL) item counts, [NL..2NL) max lr, [2NL] error bits, [2NL+1] max lq of the long list
     unsigned long long *counters64;  // [k * C64_STRIDE]: k = 0 DP cells, 1 packed sequence bytes read (query + window), 2 checkpoint bytes
     unsigned long long *stats;       // stats.d:45-54: [0] read_count, [1] clipped, [2] sup (the artifact counters come from traceback_kernel)
 };
@@ -200,13 +209,13 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
             if (end > a.contig_len[tid]) end = a.contig_len[tid];
             const int64_t lr = end - start;
             if (lr > 0) {
-                cls = class_of_len(lq);
-                if (cls < 0) errbits |= 2u;  // read longer than FADEHIP_MAX_QUERY
+                cls = list_of_len(lq);
+                if (cls < 0) errbits |= 2u;  // read longer than MAX_LONG_QUERY
                 else if (lr > a.max_ref_len) { errbits |= 4u; cls = -1; }  // window longer than max_ref_len
                 else {
                     cells = (unsigned long long)lq * (unsigned long long)lr;
                     seq_bytes = (unsigned long long)((lq + 1) / 2 + (lr + 1) / 2);
-                    ck_bytes = (unsigned long long)lq * (unsigned long long)(lr >> CK_SHIFT) * 4ull;  // H + E-hat, int16 each
+                    ck_bytes = cls == LONG_LIST ? 0ull : (unsigned long long)lq * (unsigned long long)(lr >> CK_SHIFT) * 4ull;  // H + E-hat, int16 each
                     lr_for_max = (uint32_t)lr;
                     w.r_base = a.contig_base[tid] + (uint64_t)start;
                     w.q_base = a.seq_off[i] * 2u;
@@ -227,16 +236,17 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     // block-aggregated append: slots are first reserved in LDS, then one global atomic per block and
     // class (per-lane or even per-wave atomics on one address serialise at ~12 ns each and dominated
     // this kernel)
-    __shared__ uint32_t s_cnt[NUM_CLASSES], s_base[NUM_CLASSES], s_maxlr[NUM_CLASSES], s_err, s_items;
+    __shared__ uint32_t s_cnt[NUM_LISTS], s_base[NUM_LISTS], s_maxlr[NUM_LISTS], s_err, s_items, s_maxlq;
     __shared__ unsigned long long s_cells, s_bytes, s_ck;
     __shared__ uint32_t s_key[GATE_BLOCK], s_rank[GATE_BLOCK], s_stat[3];
-    if (threadIdx.x < NUM_CLASSES) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; s_items = 0; s_stat[0] = s_stat[1] = s_stat[2] = 0; }
+    if (threadIdx.x < NUM_LISTS) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { s_err = 0; s_cells = 0; s_bytes = 0; s_ck = 0; s_items = 0; s_maxlq = 0; s_stat[0] = s_stat[1] = s_stat[2] = 0; }
     __syncthreads();
     uint32_t compact = 0;
     if (cls >= 0) {
         atomicAdd(&s_cnt[cls], 1u);
         atomicMax(&s_maxlr[cls], lr_for_max);
+        if (cls == LONG_LIST) atomicMax(&s_maxlq, w.lq);
         compact = atomicAdd(&s_items, 1u);
         s_key[compact] = ((uint32_t)cls << 24) | lr_for_max;  // lr <= 16000
     }
@@ -263,9 +273,9 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         }
     }
     __syncthreads();
-    if (threadIdx.x < NUM_CLASSES && s_cnt[threadIdx.x]) {
+    if (threadIdx.x < NUM_LISTS && s_cnt[threadIdx.x]) {
         s_base[threadIdx.x] = atomicAdd(&a.counters[threadIdx.x], s_cnt[threadIdx.x]);
-        atomicMax(&a.counters[NUM_CLASSES + threadIdx.x], s_maxlr[threadIdx.x]);
+        atomicMax(&a.counters[NUM_LISTS + threadIdx.x], s_maxlr[threadIdx.x]);
     }
     if (threadIdx.x == 0) {
         if (s_cells) {
@@ -273,7 +283,8 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
             atomicAdd(&a.counters64[1 * C64_STRIDE], s_bytes);
             atomicAdd(&a.counters64[2 * C64_STRIDE], s_ck);
         }
-        if (s_err) atomicOr(&a.counters[2 * NUM_CLASSES], s_err);
+        if (s_err) atomicOr(&a.counters[2 * NUM_LISTS], s_err);
+        if (s_maxlq) atomicMax(&a.counters[2 * NUM_LISTS + 1], s_maxlq);
     }
     if (threadIdx.x >= 64 && threadIdx.x < 67 && a.stats && s_stat[threadIdx.x - 64])
         atomicAdd(&a.stats[8 * (blockIdx.x % STAT_PARTS) + threadIdx.x - 64], (unsigned long long)s_stat[threadIdx.x - 64]);
@@ -864,6 +875,84 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     }
 }
 
+// ---------------------------------------------------------------- forward SW for queries longer than 512 bases
+// A thread per alignment, row by row over the window, same recurrence, flags and tie rules as the wave kernels
+// (hat domain: E-hat = E + open, F-hat = F + open, borders 0).  The previous row's H and F-hat and the 4-bit trace
+// live in global memory, interleaved over the launch's items so that the lanes of a wave touch consecutive
+// addresses.  Not a fast path: short-read libraries put a handful of merged pairs here, if any.
+struct LongArgs {
+    const Work *work;
+    int32_t n_items;
+    const uint8_t *q_nib, *r_nib;
+    int32_t *hrow, *frow;   // [max_lr][n_items]
+    uint8_t *trace;         // [max_lq * lhalf][n_items], two cells per byte (even column in the low nibble)
+    int32_t lhalf;          // (max_lr + 1) / 2
+    int32_t max_lq, max_lr;
+    Fwd *fwd;
+    ScoreTab sc;
+};
+
+__global__ __launch_bounds__(64) void sw_long_kernel(LongArgs a) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = item < a.n_items;
+    Work w;
+    w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.pad = 0;
+    if (have) w = a.work[item];
+    const int lq = (int)w.lq, lr = (int)w.lr;
+    const uint32_t n = (uint32_t)a.n_items;
+    const int32_t open = a.sc.open, ext = a.sc.ext;
+    for (int j = 0; j < lr; j++) {
+        a.hrow[(uint64_t)j * n + item] = 0;
+        a.frow[(uint64_t)j * n + item] = 0;
+    }
+    int32_t best = 0;
+    int bi = 0, bj = 0;
+    for (int i = 0; i < lq; i++) {
+        uint32_t code;
+        if (w.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)(lq - 1 - i)));
+        else code = nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)i);
+        const uint32_t qc = lut4(CLASS_LUT, code);
+        uint32_t prof = a.sc.prof[0];
+#pragma unroll
+        for (int c = 1; c < 7; c++) prof = (qc == (uint32_t)c) ? a.sc.prof[c] : prof;
+        int32_t hl = 0, El = 0, hd = 0;
+        uint32_t pair = 0;
+        uint8_t *trow = a.trace + ((uint64_t)i * (uint32_t)a.lhalf) * n + item;
+        for (int j = 0; j < lr; j++) {
+            const uint64_t at = (uint64_t)j * n + item;
+            const int32_t hu = a.hrow[at], fu = a.frow[at];
+            const uint32_t cc = lut4(CLASS_LUT, nib_at(a.r_nib, w.r_base + (uint64_t)j));
+            const int32_t Dp = hd + (int32_t)((prof >> (4 * cc)) & 15u);
+            const int32_t Ee = El - ext;
+            const int32_t En = max(hl, Ee);
+            const int32_t Fe = fu - ext;
+            const int32_t Fn = max(hu, Fe);
+            const int32_t T = max(max(Dp, En), Fn);
+            const int32_t H = max(T - open, 0);
+            // trace nibble as in the wave kernels: 8 (D < T), 4 (F < T), 2 (E opened), 1 (F opened)
+            const uint32_t nb = (Dp < T ? 8u : 0u) | (Fn < T ? 4u : 0u) | (Ee < hl ? 2u : 0u) | (Fe < hu ? 1u : 0u);
+            if (j & 1) trow[(uint64_t)(j >> 1) * n] = (uint8_t)(pair | (nb << 4));
+            else pair = nb;
+            // end cell: max H, then smallest ref index, then smallest query index (rows are visited in order)
+            if (H > best || (H == best && H > 0 && j < bj)) { best = H; bi = i; bj = j; }
+            a.hrow[at] = H;
+            a.frow[at] = Fn;
+            hd = hu;
+            hl = H;
+            El = En;
+        }
+        if (lr & 1) trow[(uint64_t)(lr >> 1) * n] = (uint8_t)pair;
+    }
+    if (have) {
+        Fwd f;
+        f.score = best;
+        f.end_q = best ? bi : 0;
+        f.end_r = best ? bj : 0;
+        f.pad = 0;
+        a.fwd[item] = f;
+    }
+}
+
 // ---------------------------------------------------------------- traceback + artifact gates
 struct TbArgs {
     const Work *work;
@@ -881,7 +970,9 @@ struct TbArgs {
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
     int32_t early_out;      // 1: a path that leaves the traced steps with > 10 ops already is not re-run (see below)
-    int32_t packed;         // trace written by the packed kernel (octets) instead of sw_forward_kernel (quads)
+    int32_t packed;         // trace layout: 0 sw_forward_kernel (quads), 1 packed kernels (octets), 2 sw_long_kernel (per thread)
+    const uint8_t *ltrace;  // packed == 2: cell (i, j) of item k is nibble j & 1 of ltrace[(i * lhalf + j / 2) * n_items + k]
+    int32_t lhalf;          // packed == 2: bytes per trace row
     // two-pass path: thread k serves a candidate whose trace starts at sweep step c0; results go to out[src]
     const Cand *cand;
     Cand *incomplete;       // candidates whose path leaves the traced steps ...
@@ -983,7 +1074,11 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
         }
     };
     auto in_range = [&](int ii, int jj) { return ii >= 0 && jj >= 0 && !(c0 > 0 && jj + ii / R < c0); };
-    auto nibble = [&](int ii, int jj) {
+    auto nibble = [&](int ii, int jj) -> uint32_t {
+        if (a.packed == 2) {
+            const uint32_t v = a.ltrace[((uint64_t)ii * (uint32_t)a.lhalf + (uint32_t)(jj >> 1)) * (uint32_t)a.n_items + (uint32_t)item];
+            return (jj & 1) ? (v >> 4) : (v & 15u);
+        }
         return a.packed ? trace_nibble_pk(tq, R, g, half, ii, jj - c0) : trace_nibble(tq, R, g, ii, jj);
     };
     constexpr int DIAG_BATCH = 8;

@@ -35,7 +35,8 @@ extern "C" {
 
 #define FADEHIP_ABI_VERSION 1
 #define FADEHIP_MAX_OPS 16   /* ops reported per alignment (FADE rejects > 10, analysis.d:69) */
-#define FADEHIP_MAX_QUERY 512 /* longest read the wave-quad kernel handles */
+#define FADEHIP_MAX_QUERY 512 /* longest query of the wave kernels (8 alignments per wavefront) */
+#define FADEHIP_MAX_LONG_QUERY 32768 /* longer queries, up to this, take a thread-per-alignment kernel (slow path) */
 #define FADEHIP_NUM_SLOTS 2   /* double-buffered batches per ctx */
 
 enum {

@@ -105,8 +105,10 @@ def test_softmasked_and_iupac_reference(ctx, oracle):
 def test_mixed_read_lengths_and_classes(ctx, oracle):
     g = synth.Genome(2, 80_000, 5)
     parts = []
-    for k, lq in enumerate([36, 76, 101, 150, 151, 200, 250, 300, 400, 512]):
-        parts.append(synth.make_reads(g, 400, 50 + k, read_len=lq, window=120, p_sc=0.5, clip_min=6, clip_max=min(30, lq // 3)))
+    # 513+ bases: past the wave kernels, served by sw_long_kernel in the same batch
+    for k, lq in enumerate([36, 76, 101, 150, 151, 200, 250, 300, 400, 512, 513, 600, 1000]):
+        parts.append(synth.make_reads(g, 400 if lq <= 512 else 60, 50 + k, read_len=lq, window=120, p_sc=0.5, clip_min=6,
+                                      clip_max=min(30, lq // 3), insert_mu=max(350, lq + 100)))
     keys = ("tid", "pos", "flag", "has_sa", "l_seq")
     b = {k: np.concatenate([p[k] for p in parts]) for k in keys}
     for off, data in (("cigar_off", "cigar_ops"), ("seq_off", "seq_packed"), ("qual_off", "qual")):
@@ -158,10 +160,6 @@ def test_trace_chunking_and_batch_split_invariance(oracle):
 def test_limits_fail_loudly(ctx):
     g = synth.Genome(1, 50_000, 2)
     ctx.genome_upload(g.names, g.ascii_contigs())
-    long_reads = synth.make_reads(g, 50, 1, read_len=600, window=100, p_sc=1.0, clip_min=10, clip_max=20)
-    with pytest.raises(fade_amd.FadeHipError) as e:
-        ctx.annotate(long_reads, 5, 100)
-    assert e.value.code == -5 and "512" in str(e.value)
     ok = synth.make_reads(g, 50, 1, read_len=150, window=100, p_sc=1.0, clip_min=10, clip_max=20)
     with pytest.raises(fade_amd.FadeHipError) as e:
         ctx.annotate(ok, 5, 9000)  # window beyond max_ref_len

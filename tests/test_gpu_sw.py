@@ -66,9 +66,23 @@ def test_sw_empty_inputs(ctx):
 def test_sw_limits_fail_loudly(ctx):
     import fade_amd
     with pytest.raises(fade_amd.FadeHipError):
-        ctx.sw_batch([b"A" * 513], [b"ACGT"])
+        ctx.sw_batch([b"A" * 32769], [b"ACGT"])  # FADEHIP_MAX_LONG_QUERY
     with pytest.raises(fade_amd.FadeHipError):
         ctx.sw_batch([b"ACGT"], [b"A" * 9000])
+
+
+def test_sw_long_queries(ctx, oracle):
+    """Queries past the wave kernels' 512 bases take sw_long_kernel (a thread per alignment); same results."""
+    rng = np.random.default_rng(23)
+    qs, rs = [], []
+    for lq in (513, 514, 600, 777, 1024, 1500, 2049):
+        for kind in ("planted", "related", "random", "nrich", "tandem"):
+            q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(lq // 2, 2 * lq + 300), kinds=(kind,))
+            qs += q
+            rs += r
+    # mixed with short pairs in one batch: both kernels serve the same call
+    q, r = make_pairs(rng, 40, lq_range=(30, 512), lr_range=(30, 900))
+    _compare(ctx, oracle, qs + q, rs + r)
 
 
 def test_sw_neighbour_independence(ctx, oracle):
