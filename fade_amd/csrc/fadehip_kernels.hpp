@@ -916,32 +916,55 @@ __global__ __launch_bounds__(64) void sw_long_kernel(LongArgs a) {
 #pragma unroll
         for (int c = 1; c < 7; c++) prof = (qc == (uint32_t)c) ? a.sc.prof[c] : prof;
         int32_t hl = 0, El = 0, hd = 0;
-        uint32_t pair = 0;
         uint8_t *trow = a.trace + ((uint64_t)i * (uint32_t)a.lhalf) * n + item;
-        for (int j = 0; j < lr; j++) {
-            const uint64_t at = (uint64_t)j * n + item;
-            const int32_t hu = a.hrow[at], fu = a.frow[at];
-            const uint32_t cc = lut4(CLASS_LUT, nib_at(a.r_nib, w.r_base + (uint64_t)j));
-            const int32_t Dp = hd + (int32_t)((prof >> (4 * cc)) & 15u);
-            const int32_t Ee = El - ext;
-            const int32_t En = max(hl, Ee);
-            const int32_t Fe = fu - ext;
-            const int32_t Fn = max(hu, Fe);
-            const int32_t T = max(max(Dp, En), Fn);
-            const int32_t H = max(T - open, 0);
-            // trace nibble as in the wave kernels: 8 (D < T), 4 (F < T), 2 (E opened), 1 (F opened)
-            const uint32_t nb = (Dp < T ? 8u : 0u) | (Fn < T ? 4u : 0u) | (Ee < hl ? 2u : 0u) | (Fe < hu ? 1u : 0u);
-            if (j & 1) trow[(uint64_t)(j >> 1) * n] = (uint8_t)(pair | (nb << 4));
-            else pair = nb;
-            // end cell: max H, then smallest ref index, then smallest query index (rows are visited in order)
-            if (H > best || (H == best && H > 0 && j < bj)) { best = H; bi = i; bj = j; }
-            a.hrow[at] = H;
-            a.frow[at] = Fn;
-            hd = hu;
-            hl = H;
-            El = En;
+        // eight columns at a time: their loads are independent of the recurrence, so one memory round trip
+        // serves eight cells (a thread is otherwise bound by ~0.4 us of load latency per cell)
+        constexpr int CB = 8;
+        for (int j0 = 0; j0 < lr; j0 += CB) {
+            int32_t hu8[CB], fu8[CB];
+            uint32_t cc8[CB];
+#pragma unroll
+            for (int k = 0; k < CB; k++) {
+                const int j = j0 + k;
+                hu8[k] = 0; fu8[k] = 0; cc8[k] = 0;
+                if (j < lr) {
+                    const uint64_t at = (uint64_t)j * n + item;
+                    hu8[k] = a.hrow[at];
+                    fu8[k] = a.frow[at];
+                    cc8[k] = lut4(CLASS_LUT, nib_at(a.r_nib, w.r_base + (uint64_t)j));
+                }
+            }
+            uint32_t pair = 0;
+#pragma unroll
+            for (int k = 0; k < CB; k++) {
+                const int j = j0 + k;
+                if (j < lr) {
+                    const int32_t hu = hu8[k], fu = fu8[k];
+                    const int32_t Dp = hd + (int32_t)((prof >> (4 * cc8[k])) & 15u);
+                    const int32_t Ee = El - ext;
+                    const int32_t En = max(hl, Ee);
+                    const int32_t Fe = fu - ext;
+                    const int32_t Fn = max(hu, Fe);
+                    const int32_t T = max(max(Dp, En), Fn);
+                    const int32_t H = max(T - open, 0);
+                    // trace nibble as in the wave kernels: 8 (D < T), 4 (F < T), 2 (E opened), 1 (F opened)
+                    const uint32_t nb = (Dp < T ? 8u : 0u) | (Fn < T ? 4u : 0u) | (Ee < hl ? 2u : 0u) | (Fe < hu ? 1u : 0u);
+                    if (k & 1) trow[(uint64_t)(j >> 1) * n] = (uint8_t)(pair | (nb << 4));
+                    else {
+                        pair = nb;
+                        if (j == lr - 1) trow[(uint64_t)(j >> 1) * n] = (uint8_t)pair;  // odd window length: last cell alone
+                    }
+                    // end cell: max H, then smallest ref index, then smallest query index (rows are visited in order)
+                    if (H > best || (H == best && H > 0 && j < bj)) { best = H; bi = i; bj = j; }
+                    const uint64_t at = (uint64_t)j * n + item;
+                    a.hrow[at] = H;
+                    a.frow[at] = Fn;
+                    hd = hu;
+                    hl = H;
+                    El = En;
+                }
+            }
         }
-        if (lr & 1) trow[(uint64_t)(lr >> 1) * n] = (uint8_t)pair;
     }
     if (have) {
         Fwd f;
