@@ -131,6 +131,22 @@ class Context:
             out[k] = view
         return out
 
+    @staticmethod
+    def compact_sequences(batch):
+        """Drop the packed bases of records the device never reads (unmapped, or no S op in the CIGAR; anno.d:61):
+        they get an empty slice (seq_off[i+1] == seq_off[i]).  A tenth of the upload for 10 % clipped reads."""
+        co = np.asarray(batch["cigar_off"], dtype=np.int64)
+        is_s = np.concatenate([(np.asarray(batch["cigar_ops"]) & 15) == 4, [False]]).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(is_s)])
+        has_s = (cs[co[1:]] - cs[co[:-1]]) > 0
+        keep = has_s & ((np.asarray(batch["flag"]) & 4) == 0)
+        so = np.asarray(batch["seq_off"], dtype=np.int64)
+        lens = (so[1:] - so[:-1]) * keep
+        out = dict(batch)
+        out["seq_packed"] = np.asarray(batch["seq_packed"])[np.repeat(keep, so[1:] - so[:-1])]
+        out["seq_off"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        return out
+
     def annotate_upload(self, slot, batch):
         b, keep, n = self._c_batch(batch)
         self._keep[slot] = (keep, n)
@@ -139,17 +155,30 @@ class Context:
     def annotate_run(self, slot, floor_len=5, window=300):
         self._chk(self._L.fadehip_annotate_run(self._h, slot, floor_len, window))
 
-    def annotate_collect(self, slot):
+    def _pinned_array(self, count, dtype):
+        nbytes = max(count, 1) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        self._chk(self._L.fadehip_host_alloc(self._h, nbytes, C.byref(ptr)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(ptr)
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr.value), dtype=np.uint8).view(dtype)
+
+    def annotate_collect(self, slot, copy=True):
+        """rs [n], alignments [n_aln], stats [8].  The result buffers are pinned and kept per slot (D2H at PCIe speed,
+        no zero-fill of 120 B x n per call); with copy=False the returned arrays are views that the next collect on
+        this slot overwrites."""
         n = self._keep[slot][1]
-        # result buffers are kept per slot (zero-filling 120 B x n every call costs more than the D2H copy)
         buf = self._out.get(slot)
         if buf is None or len(buf[0]) < max(n, 1):
-            buf = (np.empty(max(n, 1), dtype=np.uint8), np.empty(max(n, 1), dtype=ALN_DTYPE))
+            buf = (self._pinned_array(n, np.uint8), self._pinned_array(n, ALN_DTYPE))
             self._out[slot] = buf
         rs, aln = buf
         out = _lib.AnnoOut(rs.ctypes.data, aln.ctypes.data, len(aln), 0)
         self._chk(self._L.fadehip_annotate_collect(self._h, slot, C.byref(out)))
-        return rs[:n].copy(), aln[:out.n_aln].copy(), np.array(list(out.stats), dtype=np.int64)
+        stats = np.array(list(out.stats), dtype=np.int64)
+        if copy:
+            return rs[:n].copy(), aln[:out.n_aln].copy(), stats
+        return rs[:n], aln[:out.n_aln], stats
 
     def annotate(self, batch, floor_len=5, window=300, slot=0):
         self.annotate_upload(slot, batch)

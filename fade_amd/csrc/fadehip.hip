@@ -965,6 +965,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         s.state = 1;
         if (errbits & 2u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a soft-clipped read longer than %d bases", FADEHIP_MAX_LONG_QUERY);
         if (errbits & 4u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a re-alignment window longer than max_ref_len=%d", ctx->prm.max_ref_len);
+        if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
         return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
     }
     const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)16 << 30);

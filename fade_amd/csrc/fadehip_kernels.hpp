@@ -200,6 +200,10 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
             errbits |= 1u;  // mapped record without a valid contig
             want = false;
         }
+        if (want && lq > 0 && a.seq_off[i + 1] - a.seq_off[i] < (uint32_t)(lq + 1) / 2u) {
+            errbits |= 8u;  // a record that must be re-aligned came without its bases
+            want = false;
+        }
         if (want && lq > 0) {
             // analysis.d:45-59
             const int64_t pos = a.pos[i];

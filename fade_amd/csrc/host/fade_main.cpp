@@ -176,13 +176,21 @@ static void pack_chunk(Chunk &c, Pool &pool) {
     const size_t n = c.recs.size();
     c.tid.resize(n); c.pos.resize(n); c.l_seq.resize(n); c.flag.resize(n); c.has_sa.resize(n);
     c.cigar_off.resize(n + 1); c.seq_off.resize(n + 1);
+    // The device reads a record's bases only to re-align it, which takes a mapped record with an S op (anno.d:61):
+    // every other record gets an empty slice of the sequence array — a tenth of the bytes to pack and to move over PCIe.
+    auto needs_seq = [](const Rec &r) {
+        if (r.flag() & 4) return false;
+        for (int k = 0; k < r.n_cigar(); k++)
+            if ((r.cigar_op(k) & 15u) == 4u) return true;
+        return false;
+    };
     size_t nc = 0, ns = 0;
     for (size_t i = 0; i < n; i++) {
         const Rec &r = c.recs[i];
         c.cigar_off[i] = (uint32_t)nc;
         c.seq_off[i] = (uint32_t)ns;
         nc += (size_t)r.n_cigar();
-        ns += ((size_t)r.l_seq() + 1) / 2;
+        if (needs_seq(r)) ns += ((size_t)r.l_seq() + 1) / 2;
     }
     c.cigar_off[n] = (uint32_t)nc;
     c.seq_off[n] = (uint32_t)ns;
@@ -198,7 +206,7 @@ static void pack_chunk(Chunk &c, Pool &pool) {
             c.flag[i] = (uint16_t)r.flag();
             c.has_sa[i] = r.aux_exists("SA") ? 1 : 0;  // anno.d:73
             if (r.n_cigar()) memcpy(&c.cigar_ops[c.cigar_off[i]], r.cigar_bytes(), 4 * (size_t)r.n_cigar());
-            if (r.l_seq()) memcpy(&c.seq[c.seq_off[i]], r.seq(), ((size_t)r.l_seq() + 1) / 2);
+            if (c.seq_off[i + 1] > c.seq_off[i]) memcpy(&c.seq[c.seq_off[i]], r.seq(), ((size_t)r.l_seq() + 1) / 2);
         }
     });
     c.rs.assign(n ? n : 1, 0);

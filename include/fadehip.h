@@ -113,7 +113,8 @@ typedef struct {
     const uint32_t *cigar_off; /* [n+1] index of the record's first op in cigar_ops */
     const uint32_t *cigar_ops; /* BAM-encoded ops, all records concatenated */
     const uint32_t *seq_off;   /* [n+1] byte offset of the record's packed sequence */
-    const uint8_t *seq_packed; /* BAM 4-bit sequence bytes, each record byte-aligned */
+    const uint8_t *seq_packed; /* BAM 4-bit sequence bytes, each record byte-aligned.  Only mapped records with an S op
+                                  are ever read (anno.d:61): the others may have an empty slice, seq_off[i+1] == seq_off[i] */
 } fadehip_read_batch;
 
 /* One entry per read that was re-aligned (clip longer than min-length), in no particular order.

@@ -217,3 +217,22 @@ def test_single_pass_kernels_agree(oracle, monkeypatch):
             _compare(c, oracle, g.names, [a.tobytes().decode() for a in g.ascii_contigs()], b, cfg["floor_len"], cfg["window"])
         finally:
             c.close()
+
+
+def test_compact_sequences_same_result_and_missing_bases_fail(ctx):
+    """The device reads bases only of mapped records with an S op: dropping all other slices changes nothing, and a
+    record that must be re-aligned but arrives without its bases is an error, not an out-of-bounds read."""
+    cfg, g, b = synth.make_config("C2", 20000, contig_len=400_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    rs0, aln0, st0 = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+    c = ctx.compact_sequences(b)
+    assert c["seq_packed"].nbytes < 0.25 * b["seq_packed"].nbytes
+    rs1, aln1, st1 = ctx.annotate(c, cfg["floor_len"], cfg["window"])
+    assert np.array_equal(rs0, rs1) and list(st0) == list(st1)
+    k0, k1 = np.argsort(aln0["read_idx"]), np.argsort(aln1["read_idx"])
+    assert aln0[k0].tobytes() == aln1[k1].tobytes()
+    bad = dict(b)
+    bad["seq_off"] = np.zeros_like(b["seq_off"])  # every slice empty
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(bad, cfg["floor_len"], cfg["window"])
+    assert e.value.code == -1
