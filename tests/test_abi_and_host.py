@@ -112,3 +112,23 @@ def test_format_tags_against_oracle_strings(oracle):
         aln.append(rec)
     got = format_tags(b, g.names, rs_all, np.array(aln, dtype=ALN_DTYPE))
     assert len(exp) > 50 and got == exp
+
+
+def test_compact_sequences_keeps_exactly_the_records_the_gate_reads():
+    """Context.compact_sequences: mapped records with an S op keep their packed bases, every other slice is empty."""
+    from fade_amd import synth
+    from fade_amd.api import Context
+    g = synth.Genome(1, 200_000, 3)
+    b = synth.make_reads(g, 5000, 9, read_len=101, window=100, p_sc=0.3)
+    c = Context.compact_sequences(b)
+    co, so, cs = b["cigar_off"].astype(np.int64), b["seq_off"].astype(np.int64), c["seq_off"].astype(np.int64)
+    kept = 0
+    for i in range(len(b["pos"])):
+        ops = b["cigar_ops"][co[i]:co[i + 1]]
+        need = bool(((ops & 15) == 4).any()) and not (int(b["flag"][i]) & 4)
+        ln = cs[i + 1] - cs[i]
+        assert ln == (so[i + 1] - so[i] if need else 0), i
+        if need:
+            assert np.array_equal(c["seq_packed"][cs[i]:cs[i + 1]], b["seq_packed"][so[i]:so[i + 1]])
+            kept += 1
+    assert 0 < kept < len(b["pos"]) // 2 and cs[-1] == len(c["seq_packed"])
