@@ -530,6 +530,15 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
     return d;
 }
 
+// max(a, b, c) per 16-bit half for NON-NEGATIVE int16 inputs below 0x7c00, in one instruction: gfx950's packed
+// three-input f16 maximum.  A non-negative int16 read as f16 (sign 0, denormals preserved: the kernels run with
+// float_denorm_mode_16_64 = 3) orders exactly like the integer, and 0x7c00 (Inf) is never reached: DP values are
+// 8 * score <= 8 * 2 * 512 + 8 * open.  There is no packed integer max3.
+__device__ __forceinline__ uint32_t pk_max3_nonneg(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ uint32_t pk_mad4(uint32_t h, uint32_t c) {  // 4*h + c per 16-bit half
     uint32_t d;
     asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(c));
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                 const uint32_t En = as_u32(__builtin_elementwise_max(as_s2(hl), as_s2(Ee)));
                 const uint32_t Fe = as_u32(as_s2(fu) - as_s2(ext8));
                 const uint32_t Fn = as_u32(__builtin_elementwise_max(as_s2(hu), as_s2(Fe)));
-                const uint32_t T = as_u32(__builtin_elementwise_max(__builtin_elementwise_max(as_s2(Dp), as_s2(En)), as_s2(Fn)));
+                const uint32_t T = pk_max3_nonneg(Dp, En, Fn);  // Dp = H + W' >= 0, En >= H_left >= 0, Fn >= H_up >= 0
                 const uint32_t H = as_u32(__builtin_elementwise_sub_sat(as_u2(T), as_u2(open8)));
                 if constexpr (MODE != 1) {
                     // trace nibble: 8*(H!=D) + 4*(H!=F) + 2*(E opened) + 1*(F opened)
