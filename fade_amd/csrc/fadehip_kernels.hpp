@@ -544,6 +544,11 @@ __device__ __forceinline__ uint32_t pk_mad4(uint32_t h, uint32_t c) {  // 4*h + 
     asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(c));
     return d;
 }
+__device__ __forceinline__ uint32_t pk_mad8(uint32_t h, uint32_t c) {  // 8*h + c per 16-bit half
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, 8, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(c));
+    return d;
+}
 __device__ __forceinline__ uint32_t pk_mul_ffff(uint32_t a) {  // 0/1 per half -> 0x0000/0xffff
     uint32_t d;
     asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "s"(0xffffu));
@@ -663,6 +668,10 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // End-cell tracking.  MODE 0: a 32-bit key (H, 0xffff - t) per row and alignment.  MODE 1: one packed 16-bit
     // key per row PAIR, 4*H8 + (31 - t % 32) = (32*H, position inside the current 32-step window), folded into
     // (GH, GT) = (best 32*H so far, its step) at every window end: 2 + 0.3 instructions per cell pair instead of 3.
+    // MODE 1, row classes up to 14 (scores <= 448): ONE key per pair of rows, 8*H8 + 2*(31 - t % 32) + (row even), kept
+    // with v_pk_maximum3_f16 (1.5 instead of 2 instructions per cell pair and half the fold work; the key stays below
+    // the f16 infinity pattern 0x7c00 only while 64 * score + 63 < 31744).
+    constexpr bool PAIRKEY = (MODE == 1) && (R <= 14);
     uint32_t Hl[R], Eh[R], bestA[R], bestB[R];  // MODE 1 reuses bestA as the window key and bestB as GH
     uint32_t GT[R];
 #pragma unroll
@@ -753,6 +762,8 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             }
             const uint32_t ct = (uint32_t)(0xffff - t);
             const uint32_t tk = (uint32_t)(31 - (t & 31)) * 0x10001u;  // MODE 1: position inside the 32-step window
+            const uint32_t tk_even = tk * 2u + 0x10001u, tk_odd = tk * 2u;  // PAIRKEY: ... and which row of the pair
+            uint32_t kprev = 0;
             uint32_t hd = hu_prev;
             hu_prev = hu;
 #pragma unroll
@@ -786,8 +797,13 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                     bestA[r] = max(bestA[r], (H << 16) | ct);
                     bestB[r] = max(bestB[r], and_or(H, himask, ct));
                 }
-                if constexpr (MODE == 1) {
+                if constexpr (MODE == 1 && !PAIRKEY) {
                     bestA[r] = as_u32(__builtin_elementwise_max(as_u2(bestA[r]), as_u2(pk_mad4(H, tk))));
+                }
+                if constexpr (PAIRKEY) {
+                    const uint32_t k = pk_mad8(H, (r & 1) ? tk_odd : tk_even);
+                    if (r & 1) bestA[r >> 1] = pk_max3_nonneg(bestA[r >> 1], kprev, k);
+                    else kprev = k;
                 }
                 hd = hl;
                 Hl[r] = H;
@@ -806,13 +822,16 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     }
     if constexpr (MODE == 1) {
         // fold the window's keys into (GH, GT); a later window wins only with a strictly larger H (Appendix A.3)
-        const uint32_t wbase = (uint32_t)((blk0 >> 3) * 32 + 31) * 0x10001u;
+        // PAIRKEY: GT holds 2 * t + (row odd) = (2 * (32 * window + 31) + 1) - (2 * (31 - t % 32) + (row even))
+        const uint32_t wbase = PAIRKEY ? (uint32_t)(((blk0 >> 3) * 32 + 31) * 2 + 1) * 0x10001u
+                                       : (uint32_t)((blk0 >> 3) * 32 + 31) * 0x10001u;
+        constexpr uint32_t HMASK = PAIRKEY ? 0xffc0ffc0u : 0xffe0ffe0u, PMASK = PAIRKEY ? 0x003f003fu : 0x001f001fu;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < (PAIRKEY ? R / 2 : R); r++) {
             const uint32_t wk = bestA[r];
-            const uint32_t wH = wk & 0xffe0ffe0u;
+            const uint32_t wH = wk & HMASK;
             const uint32_t imp = as_u32(__builtin_elementwise_sub_sat(as_u2(wH), as_u2(bestB[r])));
-            const uint32_t tnew = pk_sub(wbase, wk & 0x001f001fu);
+            const uint32_t tnew = pk_sub(wbase, wk & PMASK);
             const uint32_t mask = pk_mul_ffff(pk_min_k<1>(imp));
             bestB[r] = as_u32(__builtin_elementwise_max(as_u2(bestB[r]), as_u2(wH)));
             GT[r] = bfi(mask, tnew, GT[r]);
@@ -839,8 +858,13 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     if (__any(special)) sweep(std::false_type{});
     else sweep(std::true_type{});
 
-    if constexpr (MODE == 1) {
-        // (GH, GT) -> the 32-bit keys the reduction below expects: (H8 << 16) | (0xffff - t), 0 when H == 0
+    // per-lane candidates: NK 32-bit keys (H8 << 16) | (0xffff - t) per alignment and the lane-local row each belongs to
+    constexpr int NK = PAIRKEY ? R / 2 : R;
+    uint32_t rowA[R], rowB[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { rowA[r] = (uint32_t)r; rowB[r] = (uint32_t)r; }
+    if constexpr (MODE == 1 && !PAIRKEY) {
+        // (GH, GT) -> 32-bit keys, 0 when H == 0
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t gh = bestB[r], gt = GT[r];
@@ -849,15 +873,27 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             bestB[r] = hb ? ((hb << 16) | (0xffffu - (gt >> 16))) : 0u;
         }
     }
+    if constexpr (PAIRKEY) {
+#pragma unroll
+        for (int p2 = 0; p2 < NK; p2++) {
+            const uint32_t gh = bestB[p2], gt = GT[p2];
+            const uint32_t ha = (gh & 0xffffu) >> 3, hb = gh >> 19;  // 64*H = 8*H8
+            const uint32_t ta = (gt & 0xffffu) >> 1, tb = gt >> 17;
+            rowA[p2] = 2u * (uint32_t)p2 + (gt & 1u);
+            rowB[p2] = 2u * (uint32_t)p2 + ((gt >> 16) & 1u);
+            bestA[p2] = ha ? ((ha << 16) | (0xffffu - ta)) : 0u;
+            bestB[p2] = hb ? ((hb << 16) | (0xffffu - tb)) : 0u;
+        }
+    }
     if constexpr (MODE != 2) {
-        // ---- end cells (Appendix A.3) for A and B
+        // ---- end cells (Appendix A.3) for A and B: equal keys keep the earlier (smaller) row
         uint32_t bka = 0, bkb = 0;
         int browa = 0, browb = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int row = lig * R + r;
-            if (row < lqA && bestA[r] > bka) { bka = bestA[r]; browa = row; }
-            if (row < lqB && bestB[r] > bkb) { bkb = bestB[r]; browb = row; }
+        for (int r = 0; r < NK; r++) {
+            const int ra = lig * R + (int)rowA[r], rb = lig * R + (int)rowB[r];
+            if (ra < lqA && bestA[r] > bka) { bka = bestA[r]; browa = ra; }
+            if (rb < lqB && bestB[r] > bkb) { bkb = bestB[r]; browb = rb; }
         }
         uint64_t ca = (bka >> 16) ? ((((uint64_t)(bka + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browa)) : 0ull;
         uint64_t cb = (bkb >> 16) ? ((((uint64_t)(bkb + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browb)) : 0ull;
