@@ -544,9 +544,9 @@ __device__ __forceinline__ uint32_t pk_mad4(uint32_t h, uint32_t c) {  // 4*h + 
     asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(c));
     return d;
 }
-__device__ __forceinline__ uint32_t pk_mad8(uint32_t h, uint32_t c) {  // 8*h + c per 16-bit half
+__device__ __forceinline__ uint32_t pk_mad8(uint32_t h, uint32_t c) {  // 8*h + c per 16-bit half, c wave-uniform (SGPR)
     uint32_t d;
-    asm("v_pk_mad_u16 %0, %1, 8, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(c));
+    asm("v_pk_mad_u16 %0, %1, 8, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "s"(c));
     return d;
 }
 __device__ __forceinline__ uint32_t pk_mul_ffff(uint32_t a) {  // 0/1 per half -> 0x0000/0xffff
@@ -621,26 +621,34 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     maxst = max(maxst, __builtin_amdgcn_readlane(mx, 48));
     const int n_blocks = (maxst + 3) >> 2;
 
-    // ---- score table in LDS: wtab[c] = 8 bytes, byte q = 8 * W'(query class q, column class c).  A lane fetches
-    // the two entries of its current columns once per step; every row then needs one v_perm_b32 per alignment
-    // (selector = the row's query class) and one v_add3 for the diagonal term of the pair.
-    __shared__ uint2 wtab[8];
-    if (lane < 8) {
-        uint32_t lo = 0, hi = 0;
+    // ---- score table in LDS, indexed by the PAIR of column classes (cA, cB) of a lane's two alignments: entry
+    // (7 cA + cB) = 16 bytes {rowA.lo, rowB.lo, rowA.hi, rowB.hi}, row c = 8 bytes, byte q = 8 * W'(query class q,
+    // column class c).  The class word that travels along the lanes IS the entry's byte offset, so a step costs one
+    // LDS read and no address arithmetic; every row then picks its bytes with v_perm_b32 (selector = query class).
+    __shared__ uint4 wtab[49];
+    if (lane < 49) {
+        const int cA = lane / 7, cB = lane - 7 * cA;
+        uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) lo |= (((a.sc.prof[q] >> (4 * lane)) & 15u) * PK_SCALE) << (8 * q);
+        for (int q = 0; q < 4; q++) {
+            alo |= (((a.sc.prof[q] >> (4 * cA)) & 15u) * PK_SCALE) << (8 * q);
+            blo |= (((a.sc.prof[q] >> (4 * cB)) & 15u) * PK_SCALE) << (8 * q);
+        }
 #pragma unroll
-        for (int q = 4; q < 7; q++) hi |= (((a.sc.prof[q] >> (4 * lane)) & 15u) * PK_SCALE) << (8 * (q - 4));
-        wtab[lane] = make_uint2(lane < 7 ? lo : 0u, lane < 7 ? hi : 0u);
+        for (int q = 4; q < 7; q++) {
+            ahi |= (((a.sc.prof[q] >> (4 * cA)) & 15u) * PK_SCALE) << (8 * (q - 4));
+            bhi |= (((a.sc.prof[q] >> (4 * cB)) & 15u) * PK_SCALE) << (8 * (q - 4));
+        }
+        wtab[lane] = make_uint4(alo, blo, ahi, bhi);
     }
-    // ---- stage both windows: 16 bits per column = classA*8 | classB*8 << 8 (byte offsets into wtab)
+    // ---- stage both windows: 16 bits per column = (7 classA + classB) * 16, the byte offset into wtab
     uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
     const int n_cols = n_blocks * 4;
     for (int k = lig; k < n_cols; k += 16) {
-        uint32_t ca = PAD_CLASS * 8, cb = PAD_CLASS * 8;
-        if (k < lrA) ca = lut4(CLASS_LUT, nib_at(a.r_nib, wa.r_base + (uint64_t)k)) * 8u;
-        if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k)) * 8u;
-        lref[k] = (uint16_t)(ca | (cb << 8));
+        uint32_t ca = PAD_CLASS, cb = PAD_CLASS;
+        if (k < lrA) ca = lut4(CLASS_LUT, nib_at(a.r_nib, wa.r_base + (uint64_t)k));
+        if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k));
+        lref[k] = (uint16_t)((7u * ca + cb) * 16u);
     }
     // query classes per row (A | B << 16); `special` = some real row is N or a wildcard (class >= 4)
     uint32_t qcls[R];
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
 #pragma unroll
     for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; bestA[r] = 0; bestB[r] = 0; GT[r] = 0; }
     uint32_t hu_out = 0, fu_out = 0, hu_prev = 0;
-    uint32_t rc = (PAD_CLASS * 8) | (PAD_CLASS * 8 << 8);
+    uint32_t rc = (7 * PAD_CLASS + PAD_CLASS) * 16;
     if constexpr (MODE == 2) {
         // resume: the wave state pass 1 snapshotted after step T0-1, per half from that half's own octet
         constexpr int CKD = ck_dwords(R);
@@ -700,11 +708,18 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         hu_out = pick(2 * R);
         fu_out = pick(2 * R + 1);
         hu_prev = pick(2 * R + 2);
-        // the class register holds classA | classB << 8 in its low 16 bits
-        uint32_t ra = PAD_CLASS * 8, rb = PAD_CLASS * 8;
-        if (c0A) ra = (ckA[(2 * R + 3) * 64] >> ((srcA & 1u) ? 8 : 0)) & 0xffu;
-        if (c0B) rb = (ckB[(2 * R + 3) * 64] >> ((srcB & 1u) ? 8 : 0)) & 0xffu;
-        rc = ra | (rb << 8);
+        // the class register of a pass-1 octet holds (7 classA + classB) * 16 of ITS two alignments: take the one
+        // this half resumes and pair it with the other half's
+        uint32_t ra = PAD_CLASS, rb = PAD_CLASS;
+        if (c0A) {
+            const uint32_t pr = (ckA[(2 * R + 3) * 64] & 0xffffu) >> 4;
+            ra = (srcA & 1u) ? pr % 7u : pr / 7u;
+        }
+        if (c0B) {
+            const uint32_t pr = (ckB[(2 * R + 3) * 64] & 0xffffu) >> 4;
+            rb = (srcB & 1u) ? pr % 7u : pr / 7u;
+        }
+        rc = (7u * ra + rb) * 16u;
     }
     __syncthreads();
     const uint32_t ext8 = (uint32_t)(a.sc.ext * PK_SCALE) * 0x10001u;
@@ -753,12 +768,14 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             uint32_t fu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
             uint2 tA, tB;
             if constexpr (FAST) {
-                tA.x = *reinterpret_cast<const uint32_t *>(wt + (rc & 0xffu));
-                tB.x = *reinterpret_cast<const uint32_t *>(wt + (rc >> 8));
+                const uint2 e = *reinterpret_cast<const uint2 *>(wt + rc);
+                tA.x = e.x;
+                tB.x = e.y;
                 tA.y = tB.y = 0;
             } else {
-                tA = *reinterpret_cast<const uint2 *>(wt + (rc & 0xffu));
-                tB = *reinterpret_cast<const uint2 *>(wt + (rc >> 8));
+                const uint4 e = *reinterpret_cast<const uint4 *>(wt + rc);
+                tA = make_uint2(e.x, e.z);
+                tB = make_uint2(e.y, e.w);
             }
             const uint32_t ct = (uint32_t)(0xffff - t);
             const uint32_t tk = (uint32_t)(31 - (t & 31)) * 0x10001u;  // MODE 1: position inside the 32-step window
