@@ -236,3 +236,40 @@ def test_compact_sequences_same_result_and_missing_bases_fail(ctx):
     with pytest.raises(fade_amd.FadeHipError) as e:
         ctx.annotate(bad, cfg["floor_len"], cfg["window"])
     assert e.value.code == -1
+
+
+def test_trace_all_gives_every_realigned_read_its_cigar(ctx):
+    """params.trace_all = 1: level 2 reports beg_* and the CIGAR of every re-aligned read (no candidate selection, no
+    early exit); each must equal the level-1 result for (reverse complement of the read, its window)."""
+    cfg, g, b = synth.make_config("C2", 4000, contig_len=300_000)
+    all_ctx = fade_amd.Context(device=0, trace_all=True)
+    try:
+        contigs = g.ascii_contigs()
+        all_ctx.genome_upload(g.names, contigs)
+        rs, aln, stats = all_ctx.annotate(b, cfg["floor_len"], cfg["window"])
+        ctx.genome_upload(g.names, contigs)
+        rs0, aln0, stats0 = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+        assert np.array_equal(rs, rs0) and list(stats) == list(stats0) and len(aln) == len(aln0) > 100
+        assert (aln["sw"]["n_ops"] > 0).all() and (aln0["sw"]["n_ops"] == 0).any()
+        comp = np.zeros(16, dtype=np.uint8)
+        comp[[1, 2, 4, 8, 15]] = [8, 4, 2, 1, 15]
+        nt16 = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+        qs, ws = [], []
+        for a in aln:
+            i = int(a["read_idx"])
+            lq = int(b["l_seq"][i])
+            o = int(b["seq_off"][i])
+            pk = b["seq_packed"][o:o + (lq + 1) // 2]
+            codes = np.empty(2 * len(pk), dtype=np.uint8)
+            codes[0::2], codes[1::2] = pk >> 4, pk & 15
+            qs.append(nt16[comp[codes[:lq]][::-1]].tobytes())
+            s0 = int(a["win_start"])
+            ws.append(contigs[int(b["tid"][i])][s0:s0 + int(a["win_len"])].tobytes())
+        l1 = ctx.sw_batch(qs, ws)
+        for k, a in enumerate(aln):
+            for f in ("score", "end_query", "end_ref", "beg_query", "beg_ref", "n_ops"):
+                assert int(a["sw"][f]) == int(l1[k][f]), (k, f)
+            n = min(int(l1[k]["n_ops"]), 16)
+            assert list(a["sw"]["ops"][:n]) == list(l1[k]["ops"][:n]), k
+    finally:
+        all_ctx.close()
