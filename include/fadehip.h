@@ -54,7 +54,11 @@ enum {
 typedef struct fadehip_ctx fadehip_ctx;
 
 /* Parasail("ACTGN", open, ext, match, mismatch) — anno.d:36.  The alphabet is fixed to
- * A,C,T,G,N + wildcard (every other residue scores 0), as parasail_matrix_create builds it. */
+ * A,C,T,G,N + wildcard (every other residue scores 0), as parasail_matrix_create builds it.
+ * Accepted: 0 < ext <= open, and 0 <= score + open <= 15 for score in {match, mismatch, 0} (4-bit profile
+ * entries).  FADE's 10/2/2/-3 and any match <= 2 run the two-pass path; larger match scores exceed the 16-bit
+ * ranges of its score pass and take the single-pass packed kernel (match <= 7) or the int32 kernel: same results,
+ * lower rate. */
 typedef struct {
     int32_t open;      /* 10: cost of the first gap base */
     int32_t ext;       /* 2 : cost of each further gap base */

@@ -98,3 +98,43 @@ def test_sw_neighbour_independence(ctx, oracle):
         if k % 8 != 3:
             assert got[k].tobytes() == base[k].tobytes(), k
     _compare(ctx, oracle, qs2, rs)
+
+
+@pytest.mark.parametrize("open_,ext,match,mismatch", [(6, 1, 1, -4), (4, 4, 2, -4), (12, 3, 3, -2), (5, 1, 8, -4), (9, 2, 5, -9)])
+def test_sw_other_scoring_schemes(oracle, open_, ext, match, mismatch):
+    """fadehip_params is not tied to FADE's 10/2/2/-3.  match <= 2 keeps the two-pass path; larger match scores leave
+    the 16-bit key ranges of the score pass and take the single-pass packed kernel (match <= 7) or the int32 kernel."""
+    import fade_amd
+    c = fade_amd.Context(device=0, open=open_, ext=ext, match=match, mismatch=mismatch)
+    try:
+        rng = np.random.default_rng(open_ * 100 + match)
+        qs, rs = make_pairs(rng, 700, lq_range=(1, 512), lr_range=(1, 1200))
+        # long exact matches drive the score to match * Lq, the top of the value ranges
+        for lq in (224, 300, 512):
+            r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(900, 900), kinds=("random",))[1][0]
+            qs.append(r[100:100 + lq].copy())
+            rs.append(r)
+        qc, qo = concat(qs)
+        rc, ro = concat(rs)
+        p = oracle.default_params()
+        p.open, p.ext, p.match, p.mismatch = open_, ext, match, mismatch
+        got = c.sw_batch_packed(qc, qo, rc, ro)
+        exp, exp_ops = oracle.sw_batch(qc, qo, rc, ro, threads=8, max_ops=16, params=p)
+        for k in range(len(qs)):
+            g = got[k]
+            tup = tuple(int(g[f]) for f in ("score", "end_query", "end_ref", "beg_query", "beg_ref", "n_ops"))
+            assert tup == tuple(int(x) for x in exp[k]), (k, tup, exp[k])
+            n = min(tup[5], 16)
+            assert list(g["ops"][:n]) == list(exp_ops[k][:n]), k
+    finally:
+        c.close()
+
+
+def test_sw_scoring_outside_the_profile_range_is_rejected():
+    import fade_amd
+    with pytest.raises(fade_amd.FadeHipError):
+        fade_amd.Context(device=0, open=10, ext=2, match=6, mismatch=-3)   # match + open > 15
+    with pytest.raises(fade_amd.FadeHipError):
+        fade_amd.Context(device=0, open=4, ext=1, match=2, mismatch=-5)    # mismatch + open < 0
+    with pytest.raises(fade_amd.FadeHipError):
+        fade_amd.Context(device=0, open=2, ext=3, match=2, mismatch=-1)    # ext > open
