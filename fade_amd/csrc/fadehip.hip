@@ -607,8 +607,8 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         fadehip_destroy(ctx);
         return code;
     };
-    if (ctx->prm.max_ref_len > 16000) {
-        set_err(ctx, FADEHIP_E_UNSUPPORTED, "max_ref_len %d exceeds the LDS staging limit of 16000", ctx->prm.max_ref_len);
+    if (ctx->prm.max_ref_len > (1 << 20)) {
+        set_err(ctx, FADEHIP_E_UNSUPPORTED, "max_ref_len %d exceeds 2^20", ctx->prm.max_ref_len);
         return fail(FADEHIP_E_UNSUPPORTED);
     }
     if ((rc = build_score_tab(ctx, ctx->prm, ctx->sc))) return fail(rc);
@@ -715,7 +715,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         const int64_t lq = q_off[k + 1] - q_off[k], lr = r_off[k + 1] - r_off[k];
         if (lq < 0 || lr < 0) return set_err(ctx, FADEHIP_E_INVALID, "offsets must be non-decreasing (pair %d)", k);
         if (lq == 0 || lr == 0) { degenerate.push_back(k); continue; }
-        const int cls = list_of_len((int)std::min<int64_t>(lq, 1 << 20));
+        const int cls = list_of_len((int)std::min<int64_t>(lq, 1 << 20), lr);
         if (cls < 0) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "query %d has %lld bases (max %d)", k, (long long)lq, FADEHIP_MAX_LONG_QUERY);
         if (cls == LONG_LIST) max_long_lq = std::max(max_long_lq, (int)lq);
         if (lr > ctx->prm.max_ref_len)
@@ -884,6 +884,8 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         const int c = list_of_len(b->l_seq[i] > 0 ? b->l_seq[i] : 1);
         if (c >= 0) present[c] = true;
     }
+    // windows beyond WAVE_MAX_WINDOW send any read to the long list; they only exist with a large --window-size
+    present[LONG_LIST] = present[LONG_LIST] || ctx->prm.max_ref_len > WAVE_MAX_WINDOW;
     if ((rc = reserve(ctx, s.tid, 4 * (size_t)n)) || (rc = reserve(ctx, s.pos, 4 * (size_t)n)) ||
         (rc = reserve(ctx, s.lseq, 4 * (size_t)n)) || (rc = reserve(ctx, s.flag, 2 * (size_t)n)) ||
         (rc = reserve(ctx, s.has_sa, (size_t)n)) || (rc = reserve(ctx, s.cigar_off, 4 * ((size_t)n + 1))) ||

@@ -95,9 +95,12 @@ __host__ __device__ inline int class_of_len(int lq) {
 // take sw_long_kernel (a thread per alignment; rare in short-read libraries, e.g. merged pairs).
 constexpr int LONG_LIST = NUM_CLASSES, NUM_LISTS = NUM_CLASSES + 1;
 constexpr int MAX_LONG_QUERY = 1 << 15;
-__host__ __device__ inline int list_of_len(int lq) {
+// The wave kernels stage a group's window in LDS, 2 bytes per column for 4 groups inside the 64 KiB a workgroup may
+// ask for: windows longer than this also take sw_long_kernel.
+constexpr int WAVE_MAX_WINDOW = 8000;
+__host__ __device__ inline int list_of_len(int lq, int64_t lr = 0) {
     const int c = class_of_len(lq);
-    if (c >= 0) return c;
+    if (c >= 0) return lr > WAVE_MAX_WINDOW ? LONG_LIST : c;
     return lq <= MAX_LONG_QUERY ? LONG_LIST : -1;
 }
 
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
             if (end > a.contig_len[tid]) end = a.contig_len[tid];
             const int64_t lr = end - start;
             if (lr > 0) {
-                cls = list_of_len(lq);
+                cls = list_of_len(lq, lr);
                 if (cls < 0) errbits |= 2u;  // read longer than MAX_LONG_QUERY
                 else if (lr > a.max_ref_len) { errbits |= 4u; cls = -1; }  // window longer than max_ref_len
                 else {

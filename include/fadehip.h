@@ -64,7 +64,8 @@ typedef struct {
     int32_t ext;       /* 2 : cost of each further gap base */
     int32_t match;     /* 2 */
     int32_t mismatch;  /* -3 */
-    int32_t max_ref_len;   /* longest reference window accepted; 0 -> 8192 */
+    int32_t max_ref_len;   /* longest reference window accepted; 0 -> 8192, at most 2^20.  Windows of up to 8000 bases
+                              take the wave kernels, longer ones the thread-per-alignment kernel (slow path) */
     int32_t max_batch_reads; /* capacity of one annotate batch; 0 -> 1<<20 */
     int64_t trace_bytes;   /* device bytes reserved for trace tables / checkpoints; 0 -> sized on demand */
     int32_t trace_all;     /* 1: level 2 returns a CIGAR for every re-aligned read (default: only for reads whose

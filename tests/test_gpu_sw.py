@@ -138,3 +138,22 @@ def test_sw_scoring_outside_the_profile_range_is_rejected():
         fade_amd.Context(device=0, open=4, ext=1, match=2, mismatch=-5)    # mismatch + open < 0
     with pytest.raises(fade_amd.FadeHipError):
         fade_amd.Context(device=0, open=2, ext=3, match=2, mismatch=-1)    # ext > open
+
+
+def test_sw_long_windows(oracle):
+    """Windows longer than the 8000 columns the wave kernels can stage in LDS take the thread-per-alignment kernel."""
+    import fade_amd
+    c = fade_amd.Context(device=0, max_ref_len=20000)
+    try:
+        rng = np.random.default_rng(77)
+        qs, rs = [], []
+        for lr in (7990, 8000, 8001, 12000, 20000):
+            for lq, kind in ((50, "planted"), (150, "related"), (600, "random")):
+                q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(lr, lr), kinds=(kind,))
+                qs += q
+                rs += r
+        _compare(c, oracle, qs, rs)
+        with pytest.raises(fade_amd.FadeHipError):
+            c.sw_batch([b"ACGT"], [b"A" * 20001])
+    finally:
+        c.close()
