@@ -273,3 +273,43 @@ def test_trace_all_gives_every_realigned_read_its_cigar(ctx):
             assert list(a["sw"]["ops"][:n]) == list(l1[k]["ops"][:n]), k
     finally:
         all_ctx.close()
+
+
+def test_two_slots_driven_by_two_threads_give_the_serial_results(ctx):
+    """bench.py and the `fade` driver keep two batches in flight, one per slot, from two host threads."""
+    import threading
+    cfg, g, b0 = synth.make_config("C2", 30000, contig_len=400_000)
+    b1 = synth.make_reads(g, 30000, 99, **cfg)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    ref = [ctx.annotate(b, cfg["floor_len"], cfg["window"]) for b in (b0, b1)]
+    got = {0: [], 1: []}
+
+    def loop(slot, batch):
+        for _ in range(6):
+            ctx.annotate_upload(slot, batch)
+            ctx.annotate_run(slot, cfg["floor_len"], cfg["window"])
+            got[slot].append(ctx.annotate_collect(slot))
+
+    th = [threading.Thread(target=loop, args=(k, b)) for k, b in ((0, b0), (1, b1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for slot in (0, 1):
+        rs0, aln0, st0 = ref[slot]
+        k0 = np.argsort(aln0["read_idx"])
+        for rs, aln, st in got[slot]:
+            assert np.array_equal(rs, rs0) and list(st) == list(st0)
+            assert aln[np.argsort(aln["read_idx"])].tobytes() == aln0[k0].tobytes()
+
+
+def test_batch_larger_than_max_batch_reads_is_rejected():
+    c = fade_amd.Context(device=0, max_batch_reads=1000)
+    try:
+        cfg, g, b = synth.make_config("C2", 1001, contig_len=100_000)
+        c.genome_upload(g.names, g.ascii_contigs())
+        with pytest.raises(fade_amd.FadeHipError) as e:
+            c.annotate(b, 5, 100)
+        assert e.value.code == -1
+        rs, aln, st = c.annotate(synth.take(b, np.arange(1000)), 5, 100)
+        assert int(st[0]) == 1000
+    finally:
+        c.close()
