@@ -22,7 +22,8 @@
  *
  * Plain C: pointers and sizes only.  Every function returns 0 on success or a negative
  * FADEHIP_E_* code and never throws or aborts across the boundary; fadehip_last_error(ctx) returns
- * a sticky message.  A ctx is bound to one device and must be driven by one thread at a time.
+ * a sticky message.  A ctx is bound to one device; each of its slots may be driven by its own host thread (create,
+ * destroy, genome_upload and sw_batch by one thread while no slot is busy).
  * There is no CPU fallback: without a usable HIP device fadehip_create fails.
  */
 #ifndef FADEHIP_H
