@@ -367,9 +367,10 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         int steps_max[NUM_BUCKETS];
         for (int b = 0; b < NUM_BUCKETS; b++) steps_max[b] = std::min(bucket_cols(b), max_lr + 15);
         if ((rc = pass2((const Cand *)s.cand.p, (uint32_t)n, bucket_n, steps_max, NUM_BUCKETS, true))) return rc;
-        // candidates whose path left the traced steps: first from 4 snapshots further back, then from step 0
+        // candidates whose path left the traced steps: from one snapshot further back (a lone wave is pure latency,
+        // ~0.4 us per step, and most paths miss by a few columns), then from eight, then from step 0
         int n_inc = 0;
-        for (int round = 0; round < 2; round++) {
+        for (int round = 0; round < 3; round++) {
             HIPCHK(ctx, hipMemcpyAsync(s.h_sel + NUM_BUCKETS, sel_counters + NUM_BUCKETS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             const int m = (int)s.h_sel[NUM_BUCKETS];
@@ -377,12 +378,12 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
             n_inc += m;
             Cand *again = (Cand *)s.cand.p;  // the bucket lists are consumed, reuse their storage
             hipLaunchKernelGGL(make_cand_back_kernel, dim3((m + 255) / 256), dim3(256), 0, st, (const Cand *)s.incomplete.p, m,
-                               round == 0 ? 4 * CK_COLS : (1 << 30), again);
+                               round == 0 ? CK_COLS : (round == 1 ? 8 * CK_COLS : (1 << 30)), again);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemsetAsync(sel_counters + NUM_BUCKETS, 0, sizeof(uint32_t), st));
             const uint32_t cnt1[1] = {(uint32_t)m};
             const int st1[1] = {max_lr + 15};
-            if ((rc = pass2(again, (uint32_t)m, cnt1, st1, 1, round == 0))) return rc;
+            if ((rc = pass2(again, (uint32_t)m, cnt1, st1, 1, round < 2))) return rc;
         }
         s.n_rerun += n_inc;
         if (getenv("FADEHIP_DEBUG")) {
