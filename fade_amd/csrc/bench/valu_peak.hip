@@ -25,8 +25,11 @@ __global__ __launch_bounds__(256) void valu_loop(int iters, int *out) {
     } else if (MODE == 4) {                                                  \
         asm volatile("v_add_f32 %0, %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_sub_f32 %0, %0, %1" \
                      : "+v"(x) : "v"(c));                                  \
-    } else {                                                                 \
+    } else if (MODE == 5) {                                                  \
         asm volatile("v_pk_fma_f16 %0, %0, %1, %1\n\tv_pk_mul_f16 %0, %0, %1\n\tv_pk_max_f16 %0, %0, %1\n\tv_pk_fma_f16 %0, %0, %1, %1" \
+                     : "+v"(x) : "v"(c));                                  \
+    } else {                                                                 \
+        asm volatile("v_pk_maximum3_f16 %0, %0, %1, %1\n\tv_perm_b32 %0, %0, %1, %1\n\tv_pk_maximum3_f16 %0, %0, %1, %1\n\tv_pk_sub_u16 %0, %0, %1 clamp" \
                      : "+v"(x) : "v"(c));                                  \
     }
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
@@ -68,5 +71,6 @@ int main() {
     run<3>("packed f16 add/max/add/min  ", p.multiProcessorCount);
     run<4>("f32 add/max/fma/sub         ", p.multiProcessorCount);
     run<5>("packed f16 fma/mul/max/fma  ", p.multiProcessorCount);
+    run<6>("pk_maximum3_f16/perm/max3/sat", p.multiProcessorCount);
     return 0;
 }
