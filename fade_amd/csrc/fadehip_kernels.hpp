@@ -1374,6 +1374,12 @@ struct SelArgs {
     uint32_t cap;
     uint32_t *bucket_n;     // [NUM_BUCKETS]
     fadehip_aln *out;
+    // exact-diagonal shortcut (below): finishes a candidate here, so it needs what traceback_kernel has
+    const uint8_t *q_nib, *r_nib;
+    uint8_t *rs;
+    unsigned long long *stats;
+    int32_t gate;
+    int32_t match;          // score of a matching pair; 0 switches the shortcut off
 };
 
 __global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
@@ -1383,6 +1389,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
     __syncthreads();
     int b = -1;
     uint32_t local_slot = 0;
+    uint32_t art_ret = 0;  // artifact bits set here (bit0 left, bit1 right) | 4 if the read is supplementary
     Cand c;
     c.src = 0;
     c.c0 = 0;
@@ -1416,6 +1423,81 @@ __global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
                 a.out[item] = o;
             }
         }
+        // Exact-diagonal shortcut.  If score = match * L and the L cells of the diagonal that ends in the end cell all
+        // score `match`, the traceback is forced: H along that diagonal is at least match * (L - k) (the matches chain
+        // up from any cell >= 0) and at most that (H(end) is the given score and every step towards it adds `match`),
+        // so every cell equals its diagonal predecessor + match — the direction the traceback tries first — and the
+        // cell before the run is 0, where it stops.  CIGAR = [beg_query S] L= [tail S] with no DP re-computation;
+        // this is the planted artifact (an exact reverse-complement copy), by far the most common candidate.
+        if (cand && a.match > 0 && f.score > 0) {
+            const int L = f.score / a.match;
+            if (L * a.match == f.score && L <= f.end_q + 1 && L <= f.end_r + 1) {
+                const bool rcq = w.flags & 1u;
+                const int lq = (int)w.lq;
+                bool ok = true;
+                for (int k0 = 0; k0 < L && ok; k0 += 8) {
+                    const int nv = min(8, L - k0);
+                    const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - f.end_q + k0)
+                                               : (uint64_t)w.q_base + (uint32_t)(f.end_q - k0 - (nv - 1));
+                    const uint64_t rn_lo = w.r_base + (uint64_t)(f.end_r - k0 - (nv - 1));
+                    const Nib8 qw = load_nib8(a.q_nib, qn_lo), rw = load_nib8(a.r_nib, rn_lo);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (k < nv) {
+                            const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
+                            const uint32_t cq = lut4(CLASS_LUT, rcq ? lut4(COMP_LUT, qraw) : qraw);
+                            const uint32_t cr = lut4(CLASS_LUT, nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k)));
+                            ok = ok && cq == cr && cq < 5u;  // same letter of A,C,G,T,N: the pair scores `match`
+                        }
+                    }
+                }
+                if (ok) {
+                    cand = false;
+                    fadehip_aln o;
+                    o.read_idx = (int32_t)w.idx;
+                    o.art = 0;
+                    o.sw.score = f.score;
+                    o.sw.end_query = f.end_q;
+                    o.sw.end_ref = f.end_r;
+                    o.sw.beg_query = f.end_q - L + 1;
+                    o.sw.beg_ref = f.end_r - L + 1;
+                    for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+                    const int lead = o.sw.beg_query, tail = lq - 1 - f.end_q;
+                    int n = 0;
+                    if (lead > 0) o.sw.ops[n++] = ((uint32_t)lead << 4) | 4u;
+                    o.sw.ops[n++] = ((uint32_t)L << 4) | 7u;
+                    if (tail > 0) o.sw.ops[n++] = ((uint32_t)tail << 4) | 4u;
+                    o.sw.n_ops = n;
+                    if (a.meta) {
+                        const Meta m = a.meta[item];
+                        o.win_start = m.win_start;
+                        o.win_len = (int32_t)w.lr;
+                        o.clip_left = m.clip_left;
+                        o.clip_right = m.clip_right;
+                        o.aligned_len = m.aligned_len;
+                        if (a.gate) {
+                            // analysis.d:74-80 (last op '=', leading S only) / 98-104 (first op '=', trailing S only)
+                            if (m.clip_left != 0 && m.clip_left > a.floor_len && tail == 0 && lead > 0 &&
+                                5 * (int64_t)f.score > 9 * (int64_t)m.clip_left)
+                                o.art |= 1;
+                            if (m.clip_right != 0 && m.clip_right > a.floor_len && lead == 0 && tail > 0 &&
+                                5 * (int64_t)f.score > 9 * (int64_t)m.clip_right)
+                                o.art |= 2;
+                            if (o.art) {
+                                const uint8_t before = a.rs[w.idx];
+                                a.rs[w.idx] = before | (uint8_t)(o.art << 1);
+                                art_ret = (uint32_t)o.art | ((before & 32u) ? 4u : 0u);
+                            }
+                        }
+                    } else {
+                        o.win_start = 0;
+                        o.win_len = (int32_t)w.lr;
+                        o.clip_left = o.clip_right = o.aligned_len = 0;
+                    }
+                    a.out[item] = o;
+                }
+            }
+        }
         if (cand) {
             // sweep steps the path is expected to span: a cell (i, j) is computed at step j + i / R.  Columns:
             // score/2 for clean matches, a quarter more for mismatches, + slack; rows ~ columns.  Any value is
@@ -1437,6 +1519,18 @@ __global__ __launch_bounds__(GATE_BLOCK) void select_kernel(SelArgs a) {
     if (threadIdx.x < NUM_BUCKETS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bucket_n[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
     if (b >= 0) a.cand[(uint64_t)b * a.cap + s_base[b] + local_slot] = c;
+    if (a.stats) {
+        // stats.d:45-54 for the calls made by the shortcut (as traceback_kernel does for its own)
+        const unsigned long long m_art = __ballot(art_ret & 3u), m_sup = __ballot((art_ret & 3u) && (art_ret & 4u)),
+                                 m_l = __ballot(art_ret & 1u), m_r = __ballot(art_ret & 2u);
+        if ((threadIdx.x & 63) == 0 && m_art) {
+            unsigned long long *st = a.stats + 8 * (blockIdx.x % STAT_PARTS);
+            atomicAdd(&st[4], (unsigned long long)__popcll(m_art));
+            if (m_sup) atomicAdd(&st[3], (unsigned long long)__popcll(m_sup));
+            if (m_l) atomicAdd(&st[6], (unsigned long long)__popcll(m_l));
+            if (m_r) atomicAdd(&st[7], (unsigned long long)__popcll(m_r));
+        }
+    }
 }
 
 }  // namespace fadehip
