@@ -23,7 +23,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # int VALU issue: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured by fade_amd/csrc/bench/valu_peak.hip: one
 # wave-instruction per 4 cycles per SIMD for v_pk_*, v_add/max, v_bfe, DPP moves alike)
 VALU_PEAK_TLANE = 39.3
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v11_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v12_pmc_summary.json")
 
 
 def pmc_traffic(workload, kernel_prefix):
@@ -187,7 +187,7 @@ def main():
                 "bound": "valu_int_issue", "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s",
                 "achieved": pmc["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12,
                 "frac": pmc["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12 / VALU_PEAK_TLANE,
-                "valu_busy_frac_pmc": pmc["valu_busy_frac"], "source": "profiles/r01_v11_pmc_summary.json"},
+                "valu_busy_frac_pmc": pmc["valu_busy_frac"], "source": "profiles/r01_v12_pmc_summary.json"},
             "kernels_ms": {"gate": float(np.mean(gate_ms)), "sw_forward": fwd, "traceback": float(np.mean(tb_ms))},
             "stats": {k: int(v) for k, v in zip(
                 ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"], st.tolist())},

@@ -295,7 +295,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         sel.stats = (rs && gate) ? s.d_stats() : nullptr;
         sel.gate = gate;
         sel.match = getenv("FADEHIP_NO_SHORTCUT") ? 0 : ctx->sc.match;
-        hipLaunchKernelGGL(select_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, sel);
+        hipLaunchKernelGGL(select_kernel, dim3((n + SELECT_BLOCK - 1) / SELECT_BLOCK), dim3(SELECT_BLOCK), 0, st, sel);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(s.h_sel, sel_counters, sizeof(uint32_t) * NUM_BUCKETS, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));

@@ -313,3 +313,16 @@ def test_batch_larger_than_max_batch_reads_is_rejected():
         assert int(st[0]) == 1000
     finally:
         c.close()
+
+
+def test_exact_diagonal_shortcut_equals_the_traced_path(ctx, monkeypatch):
+    """The selection kernel finishes candidates whose score is match * L over an all-match diagonal without pass 2;
+    FADEHIP_NO_SHORTCUT=1 sends them through the traced re-computation instead: same records, byte for byte."""
+    cfg, g, b = synth.make_config("C5", 30000, contig_len=400_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    rs0, aln0, st0 = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+    monkeypatch.setenv("FADEHIP_NO_SHORTCUT", "1")
+    rs1, aln1, st1 = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+    monkeypatch.delenv("FADEHIP_NO_SHORTCUT")
+    assert np.array_equal(rs0, rs1) and list(st0) == list(st1) and int(st0[4]) > 1000
+    assert aln0[np.argsort(aln0["read_idx"])].tobytes() == aln1[np.argsort(aln1["read_idx"])].tobytes()
