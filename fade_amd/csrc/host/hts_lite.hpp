@@ -764,9 +764,13 @@ public:
             zs.avail_out = (uInt)isz[k];
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
-            if (rc != Z_STREAM_END) bad_ = true;
+            if (rc != Z_STREAM_END || zs.total_out != isz[k]) bad_ = true;
+            // the block's CRC32 (RFC 1952 trailer), as htslib checks it
+            uint32_t want;
+            memcpy(&want, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out_.data() + base + ooff[k], (uInt)isz[k]) != want) bad_ = true;
         });
-        if (bad_) throw std::runtime_error("BGZF inflate failed");
+        if (bad_) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
         return true;
     }
 

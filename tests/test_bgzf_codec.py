@@ -73,3 +73,21 @@ def test_writer_payload_is_codec_independent(tmp_path):
     q = subprocess.run([FADE, "out", "-t", "4", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     strip = lambda t: [l for l in t.decode().splitlines() if not l.startswith("@PG")]
     assert p.returncode == 0 and strip(p.stdout) == strip(q.stdout)
+
+
+def test_reader_rejects_a_corrupt_block(tmp_path):
+    """A flipped payload byte must not pass silently: the reader checks ISIZE and the CRC32 of every BGZF block."""
+    sam = tmp_path / "in.sam"
+    _sam(sam, 3000, 5)
+    p = subprocess.run([FADE, "out", "-b", "-t", "2", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0
+    good = bytearray(p.stdout)
+    bam = tmp_path / "bad.bam"
+    for pos in (len(good) // 2, len(good) // 3):
+        bad = bytearray(good)
+        bad[pos] ^= 0x5a
+        bam.write_bytes(bytes(bad))
+        q = subprocess.run([FADE, "out", "-t", "2", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert q.returncode != 0, "corruption at byte %d went unnoticed" % pos
+    bam.write_bytes(bytes(good))
+    assert subprocess.run([FADE, "out", "-t", "2", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300).returncode == 0
