@@ -71,6 +71,7 @@ struct fadehip_ctx {
     Slot slots[FADEHIP_NUM_SLOTS];
     // genome
     DevBuf genome, contig_len, contig_base;
+    DevBuf l1_q, l1_r, l1_qn, l1_rn, l1_bad, l1_work, l1_aln;  // level 1 (fadehip_sw_batch): kept between calls, grow only
     int n_contigs = 0;
     std::vector<int64_t> h_contig_len;
     std::vector<uint64_t> h_contig_base;
@@ -686,6 +687,7 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     release(ctx->genome);
+    for (DevBuf *b : {&ctx->l1_q, &ctx->l1_r, &ctx->l1_qn, &ctx->l1_rn, &ctx->l1_bad, &ctx->l1_work, &ctx->l1_aln}) release(*b);
     release(ctx->contig_len);
     release(ctx->contig_base);
     delete ctx;
@@ -739,11 +741,10 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         max_lr[cls] = std::max(max_lr[cls], (int)lr);
     }
     if (q_total >= (int64_t)1 << 32) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "query bases per batch must stay below 2^32");
-    DevBuf d_q, d_r, d_qn, d_rn, d_bad, d_work, d_aln;
+    DevBuf &d_q = ctx->l1_q, &d_r = ctx->l1_r, &d_qn = ctx->l1_qn, &d_rn = ctx->l1_rn, &d_bad = ctx->l1_bad,
+           &d_work = ctx->l1_work, &d_aln = ctx->l1_aln;
     int rc = 0;
-    auto cleanup = [&]() {
-        for (DevBuf *b : {&d_q, &d_r, &d_qn, &d_rn, &d_bad, &d_work, &d_aln}) release(*b);
-    };
+    auto cleanup = [&]() {};  // the buffers stay with the ctx (hipMalloc / hipFree per call cost more than small batches)
 #define L1CHK(call)                                                                                        \
     do {                                                                                                   \
         hipError_t e_ = (call);                                                                            \
