@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "deflate_fast.hpp"
+#include "inflate_fast.hpp"
 
 namespace htsl {
 
@@ -551,7 +552,8 @@ inline void sam_format(const Rec &r, const Header &h, std::string &s) {
 static const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
                                      0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-// FADE_BGZF_CODEC=zlib selects zlib level 6 (what htslib does by default) instead of deflate_fast.hpp;
+// FADE_BGZF_CODEC=zlib selects zlib (level 6 deflate, what htslib does by default, and zlib's inflate) instead of
+// deflate_fast.hpp / inflate_fast.hpp;
 // FADE_BGZF_EFFORT=1|2|3 picks FastDeflate's effort (default 2)
 inline bool bgzf_use_zlib() {
     static const bool z = [] {
@@ -754,17 +756,25 @@ public:
         out_.resize(base + ooff.back());
         pool_->parallel_for(offs_.size(), [&](size_t k) {
             if (isz[k] == 0) return;
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
             const size_t hl = 12 + offs_[k].xlen;
-            zs.next_in = comp_.data() + offs_[k].off + hl;
-            zs.avail_in = (uInt)(offs_[k].size - hl - 8);
-            zs.next_out = out_.data() + base + ooff[k];
-            zs.avail_out = (uInt)isz[k];
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.total_out != isz[k]) bad_ = true;
+            if (offs_[k].size < hl + 8) { bad_ = true; return; }
+            if (!bgzf_use_zlib()) {
+                static thread_local std::unique_ptr<FastInflate> fi;
+                if (!fi) fi.reset(new FastInflate());
+                if (!fi->inflate(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, out_.data() + base + ooff[k], isz[k]))
+                    bad_ = true;
+            } else {
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
+                zs.next_in = comp_.data() + offs_[k].off + hl;
+                zs.avail_in = (uInt)(offs_[k].size - hl - 8);
+                zs.next_out = out_.data() + base + ooff[k];
+                zs.avail_out = (uInt)isz[k];
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.total_out != isz[k]) bad_ = true;
+            }
             // the block's CRC32 (RFC 1952 trailer), as htslib checks it
             uint32_t want;
             memcpy(&want, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);

@@ -1,4 +1,4 @@
-// Round-trip and size/speed check of deflate_fast.hpp against zlib:  deflate_selftest [file]
+// Round-trip and size/speed check of deflate_fast.hpp and inflate_fast.hpp against zlib:  deflate_selftest [file]
 // Every block is compressed by FastDeflate (all effort levels), inflated by zlib and compared; with a file argument
 // the file is cut into 0xff00-byte BGZF-sized blocks and the sizes and rates of both compressors are printed.
 #include <zlib.h>
@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "../deflate_fast.hpp"
+#include "../inflate_fast.hpp"
 
 using namespace htsl;
 
@@ -31,6 +32,46 @@ static bool roundtrip(FastDeflate &fd, const uint8_t *in, size_t n, size_t *clen
         return false;
     }
     if (clen_out) *clen_out = clen;
+    // the same stream, and zlib's own streams at several settings, through FastInflate
+    static FastInflate fi;
+    std::vector<uint8_t> mine(n + 1);
+    if (!fi.inflate(out.data(), clen, mine.data(), n) || (n && memcmp(mine.data(), in, n) != 0)) {
+        fprintf(stderr, "FastInflate failed on a FastDeflate stream (n=%zu clen=%zu)\n", n, clen);
+        return false;
+    }
+    static const int settings[][2] = {{0, Z_DEFAULT_STRATEGY}, {1, Z_DEFAULT_STRATEGY}, {6, Z_DEFAULT_STRATEGY}, {9, Z_DEFAULT_STRATEGY},
+                                      {6, Z_FIXED}, {6, Z_HUFFMAN_ONLY}, {6, Z_RLE}};
+    std::vector<uint8_t> zbuf(n + n / 8 + 1024);
+    for (const auto &st : settings) {
+        z_stream z2;
+        memset(&z2, 0, sizeof z2);
+        deflateInit2(&z2, st[0], Z_DEFLATED, -15, 8, st[1]);
+        z2.next_in = const_cast<uint8_t *>(in);
+        z2.avail_in = (uInt)n;
+        z2.next_out = zbuf.data();
+        z2.avail_out = (uInt)zbuf.size();
+        const int r2 = deflate(&z2, Z_FINISH);
+        const size_t zl = z2.total_out;
+        deflateEnd(&z2);
+        if (r2 != Z_STREAM_END) { fprintf(stderr, "zlib deflate failed\n"); return false; }
+        std::fill(mine.begin(), mine.end(), 0xa5);
+        if (!fi.inflate(zbuf.data(), zl, mine.data(), n) || (n && memcmp(mine.data(), in, n) != 0) || mine[n] != 0xa5) {
+            fprintf(stderr, "FastInflate failed on a zlib stream (level %d strategy %d, n=%zu)\n", st[0], st[1], n);
+            return false;
+        }
+        // wrong sizes and damaged streams must be refused or at least stay inside the buffers (ASan watches)
+        if (n && fi.inflate(zbuf.data(), zl, mine.data(), n - 1)) { fprintf(stderr, "short output accepted\n"); return false; }
+        if (zl > 4) {
+            std::vector<uint8_t> bad(zbuf.begin(), zbuf.begin() + (std::ptrdiff_t)zl);
+            static uint64_t lcg = 88172645463325252ull;
+            for (int rep = 0; rep < 3; rep++) {
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                bad[(size_t)(lcg >> 33) % zl] ^= (uint8_t)(1u << ((lcg >> 20) & 7));
+                (void)fi.inflate(bad.data(), zl, mine.data(), n);
+                (void)fi.inflate(bad.data(), zl / 2, mine.data(), n);
+            }
+        }
+    }
     return true;
 }
 
@@ -156,6 +197,47 @@ int main(int argc, char **argv) {
             printf("%-22s %10zu -> %10zu bytes (%.4f)  %7.1f MB/s\n",
                    mode < 3 ? (std::string("FastDeflate effort ") + std::to_string(mode + 1)).c_str() : (mode == 3 ? "zlib level 1" : "zlib level 6"),
                    data.size(), total, (double)total / (double)data.size(), (double)data.size() / dt / 1e6);
+        }
+    }
+    if (argc > 1) {
+        FILE *f = fopen(argv[1], "rb");
+        std::vector<uint8_t> data;
+        uint8_t buf[1 << 16];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+        fclose(f);
+        const size_t B = 0xff00;
+        FastDeflate fd(2);
+        FastInflate fi;
+        std::vector<std::vector<uint8_t>> blocks;
+        std::vector<size_t> sizes;
+        for (size_t o = 0; o < data.size(); o += B) {
+            const size_t n = std::min(B, data.size() - o);
+            std::vector<uint8_t> c(FastDeflate::bound(n) + 8);
+            c.resize(fd.compress(data.data() + o, n, c.data()) + 8);
+            blocks.push_back(c);
+            sizes.push_back(n);
+        }
+        std::vector<uint8_t> out(B + 16);
+        for (int mode = 0; mode < 2; mode++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (size_t b = 0; b < blocks.size(); b++) {
+                if (mode == 0) {
+                    if (!fi.inflate(blocks[b].data(), blocks[b].size() - 8, out.data(), sizes[b])) return 1;
+                } else {
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    inflateInit2(&zs, -15);
+                    zs.next_in = blocks[b].data();
+                    zs.avail_in = (uInt)(blocks[b].size() - 8);
+                    zs.next_out = out.data();
+                    zs.avail_out = (uInt)sizes[b];
+                    inflate(&zs, Z_FINISH);
+                    inflateEnd(&zs);
+                }
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("%-22s %7.1f MB/s (output bytes)\n", mode == 0 ? "FastInflate" : "zlib inflate", (double)data.size() / dt / 1e6);
         }
     }
     return 0;

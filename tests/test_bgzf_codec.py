@@ -1,5 +1,6 @@
 """Host BGZF codec: fade_amd/csrc/host/deflate_fast.hpp must emit standard DEFLATE that zlib
-inflates back bit-exactly, and the `fade` writer's BAM output must carry the same payload with either codec."""
+inflates back bit-exactly, inflate_fast.hpp must decode zlib's and its sibling's streams, and the `fade` reader / writer
+must carry the same payload with either codec."""
 import gzip
 import os
 import struct
@@ -73,6 +74,13 @@ def test_writer_payload_is_codec_independent(tmp_path):
     q = subprocess.run([FADE, "out", "-t", "4", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     strip = lambda t: [l for l in t.decode().splitlines() if not l.startswith("@PG")]
     assert p.returncode == 0 and strip(p.stdout) == strip(q.stdout)
+    # both inflaters (inflate_fast.hpp, zlib) read both deflaters' output to the same records
+    for writer in ("fast", "zlib"):
+        bam.write_bytes(outs[writer])
+        for reader in ("fast", "zlib"):
+            r = subprocess.run([FADE, "out", "-t", "4", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                               env=dict(os.environ, FADE_BGZF_CODEC=reader))
+            assert r.returncode == 0 and strip(r.stdout) == strip(q.stdout), (writer, reader)
 
 
 def test_reader_rejects_a_corrupt_block(tmp_path):
