@@ -126,8 +126,19 @@ def main():
         if n_slots == 1:
             run_steps(0, n_steps, prof_out)
             return
-        th = [threading.Thread(target=run_steps, args=(k, n_steps // n_slots + (k < n_steps % n_slots),
-                                                       prof_out if k == 0 else None)) for k in range(n_slots)]
+        # the slot threads draw steps from one counter, so an odd or small step count still keeps every slot busy to the end
+        left = [n_steps]
+        lock = threading.Lock()
+
+        def worker(slot):
+            while True:
+                with lock:
+                    if left[0] == 0:
+                        return
+                    left[0] -= 1
+                run_steps(slot, 1, prof_out if slot == 0 else None)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n_slots)]
         for t_ in th:
             t_.start()
         for t_ in th:
