@@ -205,6 +205,8 @@ struct Rec {
     size_t qual_off() const { return seq_off() + ((size_t)l_seq() + 1) / 2; }
     const uint8_t *qual() const { return d.data() + qual_off(); }
     size_t aux_off() const { return qual_off() + (size_t)l_seq(); }
+    // the fixed fields must describe a layout that fits the record (a corrupt length would send every accessor out of bounds)
+    bool layout_ok() const { return d.size() >= 32 && l_seq() >= 0 && l_qname() >= 1 && aux_off() <= d.size(); }
 
     // size in bytes of the aux field whose type byte is at p (p points at the type), 0 on corruption
     size_t aux_field_size(size_t p) const {
@@ -848,8 +850,10 @@ public:
                         uint32_t bs;
                         memcpy(&bs, b + off[i], 4);
                         out[base + i].d.assign(b + off[i] + 4, b + off[i] + 4 + bs);
+                        if (!out[base + i].layout_ok()) bad_layout_ = true;
                     }
                 });
+                if (bad_layout_) throw std::runtime_error("corrupt BAM record (field lengths exceed the record)");
                 bgzf_->consume(o);
                 n += cnt;
             }
@@ -948,6 +952,7 @@ private:
     std::unique_ptr<BgzfIn> bgzf_;
     bool bam_ = false;
     Header hdr_;
+    std::atomic<bool> bad_layout_{false};
     std::string text_;      // SAM text not yet handed out (complete lines from text_pos_ on)
     size_t text_pos_ = 0;
     bool text_eof_ = false;

@@ -99,3 +99,37 @@ def test_reader_rejects_a_corrupt_block(tmp_path):
         assert q.returncode != 0, "corruption at byte %d went unnoticed" % pos
     bam.write_bytes(bytes(good))
     assert subprocess.run([FADE, "out", "-t", "2", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300).returncode == 0
+
+
+def test_reader_rejects_a_record_whose_fields_overrun_it(tmp_path):
+    """A well-formed BGZF stream can still carry a BAM record whose l_read_name / n_cigar_op / l_seq point past its end."""
+    sam = tmp_path / "in.sam"
+    _sam(sam, 50, 8)
+    p = subprocess.run([FADE, "out", "-u", "-t", "1", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0
+    payload = bytearray(b"".join(_bgzf_blocks(p.stdout)))
+    # header: magic, l_text, text, n_ref, then per reference l_name, name, l_ref
+    o = 4
+    l_text = struct.unpack_from("<i", payload, o)[0]
+    o += 4 + l_text
+    n_ref = struct.unpack_from("<i", payload, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", payload, o)[0]
+        o += 4 + l_name + 4
+    struct.pack_into("<i", payload, o + 4 + 16, 1 << 20)  # l_seq of the first record: far beyond its block_size
+
+    def bgzf(data):
+        out = bytearray()
+        for k in range(0, len(data), 0xff00):
+            chunk = bytes(data[k:k + 0xff00])
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = c.compress(chunk) + c.flush()
+            out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body
+            out += struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+        return bytes(out) + p.stdout[-28:]
+
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(bgzf(payload))
+    q = subprocess.run([FADE, "out", "-t", "1", str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode != 0 and b"corrupt BAM record" in q.stderr
