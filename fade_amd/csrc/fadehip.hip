@@ -885,6 +885,11 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         (b->cigar_off[n] && !b->cigar_ops) || (b->seq_off[n] && !b->seq_packed))
         return set_err(ctx, FADEHIP_E_INVALID, "batch has NULL arrays");
     const size_t n_cig = b->cigar_off[n], n_seq = b->seq_off[n];
+    // the kernels index with these: offsets must be non-decreasing, lengths non-negative (one pass, ~1 ms per million)
+    for (int i = 0; i < n; i++) {
+        if (b->cigar_off[i] > b->cigar_off[i + 1] || b->seq_off[i] > b->seq_off[i + 1] || b->l_seq[i] < 0)
+            return set_err(ctx, FADEHIP_E_INVALID, "record %d: cigar_off / seq_off must be non-decreasing and l_seq >= 0", i);
+    }
     if ((uint64_t)n_seq * 2 >= ((uint64_t)1 << 32)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "packed sequence bytes per batch must stay below 2^31");
     // classes present decide which work lists exist
     bool present[NUM_LISTS] = {false};

@@ -326,3 +326,24 @@ def test_exact_diagonal_shortcut_equals_the_traced_path(ctx, monkeypatch):
     monkeypatch.delenv("FADEHIP_NO_SHORTCUT")
     assert np.array_equal(rs0, rs1) and list(st0) == list(st1) and int(st0[4]) > 1000
     assert aln0[np.argsort(aln0["read_idx"])].tobytes() == aln1[np.argsort(aln1["read_idx"])].tobytes()
+
+
+def test_malformed_offsets_are_rejected_before_any_launch(ctx):
+    cfg, g, b = synth.make_config("C2", 2000, contig_len=100_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    for key in ("cigar_off", "seq_off"):
+        bad = dict(b)
+        arr = b[key].copy()
+        arr[500], arr[501] = arr[501], arr[500] + 7  # decreasing pair
+        arr[500] = arr[502] + 1
+        bad[key] = arr
+        with pytest.raises(fade_amd.FadeHipError) as e:
+            ctx.annotate(bad, 5, 100)
+        assert e.value.code == -1
+    bad = dict(b)
+    bad["l_seq"] = b["l_seq"].copy()
+    bad["l_seq"][7] = -3
+    with pytest.raises(fade_amd.FadeHipError):
+        ctx.annotate(bad, 5, 100)
+    rs, aln, st = ctx.annotate(b, 5, 100)
+    assert int(st[0]) == 2000
