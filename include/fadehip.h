@@ -153,7 +153,9 @@ typedef struct {
  *             still be artifact calls -> traced re-computation of their last steps -> traceback + artifact
  *             gates, all on device (three small counter read-backs size the launches)
  *   collect : D2H of rs / aln / stats; blocks until the slot is done
- * submit = upload + run.  Results stay valid until the slot is uploaded again.
+ * submit = upload + run.  Results stay valid until the slot is uploaded again.  The batch arrays handed to upload /
+ * submit must stay valid and unchanged until the slot's run has returned (the copies from pinned memory are
+ * asynchronous; run synchronises the stream when it reads the gate's counters back).
  * floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
 int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch);
 int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t window);
