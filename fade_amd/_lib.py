@@ -12,13 +12,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfadehip.so")
 
 MAX_OPS = 16
-NUM_SLOTS = 2
+NUM_SLOTS = 4
+ABI_VERSION = 2
+RULES_DEFAULT = 0x7f
 
 # every symbol include/fadehip.h declares
 EXPORTS = [
     "fadehip_params_default", "fadehip_abi_version", "fadehip_create", "fadehip_destroy", "fadehip_last_error",
-    "fadehip_host_alloc", "fadehip_host_free", "fadehip_sw_batch", "fadehip_genome_upload",
-    "fadehip_annotate_upload", "fadehip_annotate_run", "fadehip_annotate_submit", "fadehip_annotate_collect",
+    "fadehip_host_alloc", "fadehip_host_free", "fadehip_batch_bytes", "fadehip_batch_bind", "fadehip_sw_batch",
+    "fadehip_genome_upload", "fadehip_annotate_upload", "fadehip_annotate_run", "fadehip_annotate_submit",
+    "fadehip_annotate_results", "fadehip_annotate_collect",
     "fadehip_sync", "fadehip_last_run_profile", "fadehip_stats_allreduce",
 ]
 
@@ -26,7 +29,7 @@ EXPORTS = [
 class Params(C.Structure):
     _fields_ = [("open", C.c_int32), ("ext", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
                 ("max_ref_len", C.c_int32), ("max_batch_reads", C.c_int32), ("trace_bytes", C.c_int64),
-                ("trace_all", C.c_int32), ("reserved", C.c_int32)]
+                ("trace_all", C.c_int32), ("rules", C.c_uint32)]
 
 
 class SwResult(C.Structure):
@@ -50,12 +53,18 @@ assert ALN_DTYPE.itemsize == C.sizeof(Aln)
 class ReadBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p),
                 ("has_sa", C.c_void_p), ("l_seq", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar_ops", C.c_void_p),
-                ("seq_off", C.c_void_p), ("seq_packed", C.c_void_p)]
+                ("seq_off", C.c_void_p), ("seq_packed", C.c_void_p), ("n_skipped", C.c_int32),
+                ("ref_span_bound", C.c_int32)]
 
 
 class AnnoOut(C.Structure):
     _fields_ = [("rs", C.c_void_p), ("aln", C.c_void_p), ("aln_cap", C.c_int32), ("n_aln", C.c_int32),
-                ("stats", C.c_int64 * 8)]
+                ("stats", C.c_int64 * 8), ("n_oversize", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AnnoView(C.Structure):
+    _fields_ = [("rs", C.c_void_p), ("aln", C.c_void_p), ("n_reads", C.c_int32), ("n_aln", C.c_int32),
+                ("stats", C.c_int64 * 8), ("n_oversize", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FadeHipError(RuntimeError):
@@ -87,6 +96,10 @@ def load():
     L.fadehip_last_error.restype = C.c_char_p
     L.fadehip_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.fadehip_host_free.argtypes = [vp, vp]
+    L.fadehip_batch_bytes.argtypes = [i32, i64, i64]
+    L.fadehip_batch_bytes.restype = C.c_size_t
+    L.fadehip_batch_bind.argtypes = [vp, i32, i64, i64, C.POINTER(ReadBatch)]
+    L.fadehip_annotate_results.argtypes = [vp, C.c_int, C.POINTER(AnnoView)]
     L.fadehip_sw_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.fadehip_genome_upload.argtypes = [vp, i32, vp, vp]
     L.fadehip_annotate_upload.argtypes = [vp, C.c_int, C.POINTER(ReadBatch)]

@@ -32,7 +32,7 @@ class Context:
     """One fadehip_ctx (one GPU)."""
 
     def __init__(self, device=-1, open=10, ext=2, match=2, mismatch=-3, max_ref_len=0, max_batch_reads=0,
-                 trace_bytes=0, trace_all=False):
+                 trace_bytes=0, trace_all=False, rules=None):
         self._L = _lib.load()
         p = _lib.Params()
         self._L.fadehip_params_default(C.byref(p))
@@ -43,6 +43,8 @@ class Context:
             p.max_batch_reads = max_batch_reads
         p.trace_bytes = trace_bytes
         p.trace_all = 1 if trace_all else 0
+        if rules is not None:
+            p.rules = rules
         h = C.c_void_p()
         rc = self._L.fadehip_create(C.byref(h), device, C.byref(p))
         if rc != 0:
@@ -104,32 +106,64 @@ class Context:
         self._chk(self._L.fadehip_genome_upload(self._h, n, C.cast(lens, C.c_void_p), C.cast(ptrs, C.c_void_p)))
         self.contig_names = [x.decode() if isinstance(x, bytes) else x for x in names]
 
+    _ARRAYS = (("tid", np.int32), ("pos", np.int32), ("l_seq", np.int32), ("cigar_off", np.uint32), ("seq_off", np.uint32),
+               ("flag", np.uint16), ("has_sa", np.uint8), ("cigar_ops", np.uint32), ("seq_packed", np.uint8))
+
     def _c_batch(self, batch):
-        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in
-                (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("has_sa", np.uint8), ("l_seq", np.int32),
-                 ("cigar_off", np.uint32), ("cigar_ops", np.uint32), ("seq_off", np.uint32), ("seq_packed", np.uint8))}
+        keep = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in self._ARRAYS}
         n = len(keep["pos"])
-        b = _lib.ReadBatch(n, *[keep[k].ctypes.data for k in
-                                ("tid", "pos", "flag", "has_sa", "l_seq", "cigar_off", "cigar_ops", "seq_off",
-                                 "seq_packed")])
+        b = _lib.ReadBatch()
+        b.n_reads = n
+        for k, _ in self._ARRAYS:
+            setattr(b, k, keep[k].ctypes.data)
+        b.n_skipped = int(batch.get("n_skipped", 0))
+        b.ref_span_bound = int(batch.get("ref_span_bound", 0))
         return b, keep, n
 
-    def pinned_copy(self, batch):
-        """Copy the device-facing arrays of `batch` into pinned host memory (fadehip_host_alloc) so that
-        annotate_upload runs at PCIe speed; the returned dict shares the other keys with `batch`."""
-        out = dict(batch)
+    def pinned_batch(self, batch):
+        """The batch as ONE pinned block in the canonical layout (fadehip_batch_bytes / fadehip_batch_bind), what a
+        reader thread would fill in place: annotate_upload of the returned object is a single hipMemcpyAsync.
+        `n_skipped` / `ref_span_bound` of the dict travel along (see clipped_only)."""
+        arrs = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in self._ARRAYS}
+        n = len(arrs["pos"])
+        n_cig, n_seq = int(arrs["cigar_off"][n]) if n else 0, int(arrs["seq_off"][n]) if n else 0
+        nbytes = self._L.fadehip_batch_bytes(n, n_cig, n_seq)
+        ptr = C.c_void_p()
+        self._chk(self._L.fadehip_host_alloc(self._h, nbytes, C.byref(ptr)))
         self._pinned = getattr(self, "_pinned", [])
-        for k, dt in (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("has_sa", np.uint8),
-                      ("l_seq", np.int32), ("cigar_off", np.uint32), ("cigar_ops", np.uint32), ("seq_off", np.uint32),
-                      ("seq_packed", np.uint8)):
-            a = np.ascontiguousarray(batch[k], dtype=dt)
-            ptr = C.c_void_p()
-            self._chk(self._L.fadehip_host_alloc(self._h, max(a.nbytes, 1), C.byref(ptr)))
-            self._pinned.append(ptr)
-            view = np.frombuffer((C.c_uint8 * max(a.nbytes, 1)).from_address(ptr.value), dtype=np.uint8)[:a.nbytes].view(dt)
-            view[...] = a
-            out[k] = view
-        return out
+        self._pinned.append(ptr)
+        b = _lib.ReadBatch()
+        self._chk(self._L.fadehip_batch_bind(ptr, n, n_cig, n_seq, C.byref(b)))
+        for k, dt in self._ARRAYS:
+            a = arrs[k]
+            if a.nbytes:
+                C.memmove(getattr(b, k), a.ctypes.data, a.nbytes)
+        b.n_skipped = int(batch.get("n_skipped", 0))
+        b.ref_span_bound = int(batch.get("ref_span_bound", 0))
+        return PinnedBatch(b, n, ptr, nbytes)
+
+    @staticmethod
+    def clipped_only(batch, ref_span_bound=True):
+        """anno.d:61-65 gives an unmapped record, or one without an S op, rs = 0 before anything else is looked at:
+        such records need not be sent.  Returns (sub_batch, sent_idx): the records that must be sent, with
+        `n_skipped` (counted into read_count by the device path) and, optionally, `ref_span_bound` (max
+        cigar.alignedLength, which a reader knows from parsing); rs / read_idx of the results index sent_idx."""
+        from . import synth
+        co = np.asarray(batch["cigar_off"], dtype=np.int64)
+        ops = np.asarray(batch["cigar_ops"])
+        is_s = np.concatenate([(ops & 15) == 4, [False]]).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(is_s)])
+        has_s = (cs[co[1:]] - cs[co[:-1]]) > 0
+        keep = has_s & ((np.asarray(batch["flag"]) & 4) == 0)
+        idx = np.nonzero(keep)[0]
+        sub = synth.take(batch, idx)
+        sub["n_skipped"] = int(len(keep) - len(idx))
+        if ref_span_bound:
+            ref = np.isin(ops & 15, (0, 2, 3, 7, 8)) * (ops >> 4).astype(np.int64)
+            cr = np.concatenate([[0], np.cumsum(ref)])
+            al = cr[co[1:]] - cr[co[:-1]]
+            sub["ref_span_bound"] = int(al[idx].max()) if len(idx) else 1
+        return sub, idx
 
     @staticmethod
     def compact_sequences(batch):
@@ -148,37 +182,38 @@ class Context:
         return out
 
     def annotate_upload(self, slot, batch):
+        """batch: a dict of numpy arrays (gathered into the slot's staging block) or a PinnedBatch (one DMA)."""
+        if isinstance(batch, PinnedBatch):
+            self._keep[slot] = (batch, batch.n)
+            self._chk(self._L.fadehip_annotate_upload(self._h, slot, C.byref(batch.c)))
+            return
         b, keep, n = self._c_batch(batch)
         self._keep[slot] = (keep, n)
         self._chk(self._L.fadehip_annotate_upload(self._h, slot, C.byref(b)))
 
     def annotate_run(self, slot, floor_len=5, window=300):
+        """Enqueues the whole device path of the slot's batch and returns (errors of the batch surface at results)."""
         self._chk(self._L.fadehip_annotate_run(self._h, slot, floor_len, window))
 
-    def _pinned_array(self, count, dtype):
-        nbytes = max(count, 1) * np.dtype(dtype).itemsize
-        ptr = C.c_void_p()
-        self._chk(self._L.fadehip_host_alloc(self._h, nbytes, C.byref(ptr)))
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(ptr)
-        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr.value), dtype=np.uint8).view(dtype)
+    def annotate_results(self, slot):
+        """Waits for the slot; rs [n], alignments [n_aln], stats [8] as views into the slot's pinned result block
+        (valid until the slot is uploaded again), plus n_oversize."""
+        v = _lib.AnnoView()
+        self._chk(self._L.fadehip_annotate_results(self._h, slot, C.byref(v)))
+        n, n_aln = v.n_reads, v.n_aln
+        rs = np.frombuffer((C.c_uint8 * n).from_address(v.rs), dtype=np.uint8) if n else np.zeros(0, np.uint8)
+        aln = (np.frombuffer((C.c_uint8 * (n_aln * ALN_DTYPE.itemsize)).from_address(v.aln), dtype=ALN_DTYPE)
+               if n_aln else np.zeros(0, ALN_DTYPE))
+        self.last_oversize = int(v.n_oversize)
+        return rs, aln, np.array(list(v.stats), dtype=np.int64)
 
     def annotate_collect(self, slot, copy=True):
-        """rs [n], alignments [n_aln], stats [8].  The result buffers are pinned and kept per slot (D2H at PCIe speed,
-        no zero-fill of 120 B x n per call); with copy=False the returned arrays are views that the next collect on
-        this slot overwrites."""
-        n = self._keep[slot][1]
-        buf = self._out.get(slot)
-        if buf is None or len(buf[0]) < max(n, 1):
-            buf = (self._pinned_array(n, np.uint8), self._pinned_array(n, ALN_DTYPE))
-            self._out[slot] = buf
-        rs, aln = buf
-        out = _lib.AnnoOut(rs.ctypes.data, aln.ctypes.data, len(aln), 0)
-        self._chk(self._L.fadehip_annotate_collect(self._h, slot, C.byref(out)))
-        stats = np.array(list(out.stats), dtype=np.int64)
+        """rs [n], alignments [n_aln], stats [8]; with copy=False the arrays are views that the slot's next upload
+        invalidates."""
+        rs, aln, stats = self.annotate_results(slot)
         if copy:
-            return rs[:n].copy(), aln[:out.n_aln].copy(), stats
-        return rs[:n], aln[:out.n_aln], stats
+            return rs.copy(), aln.copy(), stats
+        return rs, aln, stats
 
     def annotate(self, batch, floor_len=5, window=300, slot=0):
         self.annotate_upload(slot, batch)
@@ -194,6 +229,15 @@ class Context:
         self._chk(self._L.fadehip_last_run_profile(self._h, slot, C.byref(ms), C.byref(cnt)))
         return dict(gate_ms=ms[0], forward_ms=ms[1], traceback_ms=ms[2], total_ms=ms[3], alignments=cnt[0],
                     cells=cnt[1], trace_bytes=cnt[2], algorithmic_bytes=cnt[3])
+
+
+class PinnedBatch:
+    """A batch in one pinned block (Context.pinned_batch): `c` is the bound fadehip_read_batch."""
+
+    __slots__ = ("c", "n", "ptr", "nbytes")
+
+    def __init__(self, c, n, ptr, nbytes):
+        self.c, self.n, self.ptr, self.nbytes = c, n, ptr, nbytes
 
 
 def stats_allreduce(contexts, counters):

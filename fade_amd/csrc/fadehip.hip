@@ -1,6 +1,11 @@
 // fadehip.hip — C ABI (include/fadehip.h) over the gfx950 kernels in fadehip_kernels.hpp.
 // Host side of the drop-in boundary for source/anno.d:44-50 / source/analysis.d:67.
 // No CPU fallback lives here: every entry point either runs the HIP path or returns an error.
+//
+// Level 2 is an asynchronous pipeline: upload is one hipMemcpyAsync of a pinned batch block, run
+// enqueues every kernel and the D2H of the results without reading anything back — launches are sized from host-side
+// bounds, the real counts stay on the device, persistent waves draw the traced re-computation's work from a table a
+// planning kernel builds — and results / collect waits for the slot.
 #include "fadehip_kernels.hpp"
 #include <rccl/rccl.h>
 #include <algorithm>
@@ -8,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -17,48 +24,91 @@ using namespace fadehip;
 namespace {
 
 thread_local std::string g_err = "";
+thread_local const fadehip_ctx *g_err_ctx = nullptr;
 
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
+struct PinBuf {  // hipHostMalloc
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+};
+
+// Canonical layout of a batch block (fadehip_batch_bind): nine arrays, 256-byte aligned, in this order.
+enum { A_TID, A_POS, A_LSEQ, A_CIGOFF, A_SEQOFF, A_FLAG, A_SA, A_CIG, A_SEQ, N_ARR };
+struct Layout {
+    size_t off[N_ARR], bytes[N_ARR], total;
+};
+Layout batch_layout(int64_t n, int64_t n_cig, int64_t n_seq) {
+    Layout L;
+    const size_t b[N_ARR] = {4 * (size_t)n, 4 * (size_t)n, 4 * (size_t)n, 4 * ((size_t)n + 1), 4 * ((size_t)n + 1),
+                             2 * (size_t)n, (size_t)n,     4 * (size_t)n_cig, (size_t)n_seq};
+    size_t at = 0;
+    for (int k = 0; k < N_ARR; k++) {
+        L.off[k] = at;
+        L.bytes[k] = b[k];
+        at += (b[k] + 8 + 255) & ~(size_t)255;  // + 8: the kernels read packed sequences as aligned dwords
+    }
+    L.total = at;
+    return L;
+}
 
 struct Slot {
     hipStream_t stream = nullptr;
-    DevBuf tid, pos, lseq, flag, has_sa, cigar_off, cigar_ops, seq_off, seq;
+    DevBuf in;                       // device mirror of the batch block
+    Layout L;                        // layout of the batch in flight
+    PinBuf stage;                    // staging for batches that do not come as one canonical block
+    const uint8_t *h_base = nullptr; // host block of the batch in flight (the caller's or `stage`)
     DevBuf rs, fwd, aln, trace;
-    DevBuf ckpt, cand, incomplete;  // two-pass path
-    // All small counters of a run live in one block so that one memset clears them and one copy reads the gate's.
+    DevBuf ckpt, cand, incomplete, p2tab;  // two-pass path
+    // All small counters of a run live in one block so that one memset clears them and one copy brings them to the host.
     // Counters that different kernels (or different atomics of one kernel) hammer sit in different 128-byte lines:
     // same-line atomics serialise in one L2 channel (the gate kernel took 60 instead of 49 us with them packed).
-    //   [0,84) counters | [128,512) counters64, one line each | [512 + 48 c, ...) selection counters of class c |
-    //   [1024, 1536) stats: STAT_PARTS partial sums of the 8 stats.d counters
+    //   [0,128) gate counters | [128,512) counters64, one line each | [512 + 48 c, ...) selection counters of class c |
+    //   [1024, 1536) stats: STAT_PARTS partial sums of the 8 stats.d counters | [1536, 2560) tickets of the persistent
+    //   launches | [2560, ...) PlanOut
     DevBuf zblock;
-    static constexpr size_t ZB_COUNTERS = 0, ZB_C64 = 128, ZB_GATE_BYTES = 512, ZB_SEL = 512, ZB_SEL_STRIDE = 48,
-                            ZB_STATS = 1024, ZB_BYTES = 1024 + 8 * 8 * STAT_PARTS;
+    static constexpr size_t ZB_COUNTERS = 0, ZB_C64 = 128, ZB_SEL = 512, ZB_SEL_STRIDE = 48, ZB_STATS = 1024,
+                            ZB_TICKETS = 1024 + 8 * 8 * STAT_PARTS, N_TICKETS = 256, ZB_PLAN = ZB_TICKETS + 4 * N_TICKETS,
+                            ZB_BYTES = ZB_PLAN + 128;
     unsigned long long *d_counters64() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_C64); }
     unsigned long long *d_stats() const { return (unsigned long long *)((uint8_t *)zblock.p + ZB_STATS); }
     uint32_t *d_counters() const { return (uint32_t *)((uint8_t *)zblock.p + ZB_COUNTERS); }
     uint32_t *d_sel(int cls) const { return (uint32_t *)((uint8_t *)zblock.p + ZB_SEL + ZB_SEL_STRIDE * (size_t)cls); }
+    uint32_t *d_ticket(int k) const { return (uint32_t *)((uint8_t *)zblock.p + ZB_TICKETS) + k; }
+    PlanOut *d_plan() const { return (PlanOut *)((uint8_t *)zblock.p + ZB_PLAN); }
     bool sel_fresh[NUM_CLASSES] = {};  // class's selection counters were cleared by the run's memset and not used yet
-    uint32_t *h_sel = nullptr;                   // pinned: NUM_BUCKETS + 1
+    int tickets_used = 0;
     DevBuf work[NUM_LISTS], meta[NUM_LISTS];
     DevBuf lrows;  // sw_long_kernel: previous-row H and F-hat
-    uint8_t *h_gate = nullptr;                 // pinned: the first ZB_GATE_BYTES of zblock after the gate
-    uint32_t *h_counters = nullptr;            // view into h_gate: 2*NC+1
-    unsigned long long *h_counters64 = nullptr;  // view into h_gate: 3
-    unsigned long long *h_stats = nullptr;       // pinned: 8 * STAT_PARTS partial sums
-    int n_reads = 0;
-    int state = 0;  // 0 idle, 1 uploaded, 2 ran
-    int n_aln = 0;
+    uint8_t *h_zb = nullptr;  // pinned copy of zblock, filled by the D2H that ends a run
+    const uint32_t *h_counters() const { return (const uint32_t *)(h_zb + ZB_COUNTERS); }
+    const unsigned long long *h_counters64() const { return (const unsigned long long *)(h_zb + ZB_C64); }
+    const unsigned long long *h_stats() const { return (const unsigned long long *)(h_zb + ZB_STATS); }
+    const PlanOut *h_plan() const { return (const PlanOut *)(h_zb + ZB_PLAN); }
+    PinBuf res;               // pinned result block: rs [n_reads] | aln [sum of the class bounds]
+    size_t res_aln_off = 0;
+    // host-side bounds of the batch in flight (what the launches are sized from)
+    uint32_t bound[NUM_LISTS] = {};     // items per work list, at most
+    uint32_t aln_base[NUM_LISTS] = {};  // first result entry of each list
+    uint32_t hist[NUM_LISTS] = {};      // upload: records per read-length class (gate-passing ones when the CIGARs were scanned)
+    int64_t span_bound = 0;             // upload: max cigar.alignedLength (the caller's bound or the scan's)
+    int max_lq = 0;                     // upload: longest read
+    int wave_lr_bound = 0, long_max_lq = 0, long_max_lr = 0;
+    int floor_len = 0, window = 0;
+    int n_reads = 0, n_skipped = 0;
+    int state = 0;  // 0 idle, 1 uploaded, 2 run enqueued, 3 results on the host
+    int n_aln = 0, n_oversize = 0;
+    int64_t stats[8] = {};
     std::vector<hipEvent_t> ev;  // event pool
     int ev_used = 0;
     // (start,end) event index pairs of the last run
     std::vector<std::pair<int, int>> fwd_spans, tb_spans;
     int ev_gate0 = -1, ev_gate1 = -1, ev_end = -1;
     int64_t prof_counts[4] = {0, 0, 0, 0};
-    int n_fwd_launches = 0;
-    int64_t n_cand = 0, n_rerun = 0;  // two-pass: candidates traced / candidates re-run from column 0
+    int64_t n_cand = 0, n_rerun = 0;  // two-pass: candidates traced / candidates re-run from further back
+    int n_reruns_of_batch = 0;        // runs repeated because the trace scratch was too small
 };
 
 }  // namespace
@@ -68,6 +118,7 @@ struct fadehip_ctx {
     fadehip_params prm;
     ScoreTab sc;
     std::string err;
+    std::mutex err_mu;
     Slot slots[FADEHIP_NUM_SLOTS];
     // genome
     DevBuf genome, contig_len, contig_base;
@@ -80,6 +131,10 @@ struct fadehip_ctx {
     bool use_packed = true;
     bool two_pass = true;
     int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
+    int64_t trace_init_bytes = 0;  // FADEHIP_TRACE_INIT overrides the first size of the pass-2 trace scratch (tests: tiny -> the batch is re-run)
+    bool debug = false;
+    std::map<uint64_t, int> resident;  // (class, mode, LDS bytes) -> waves of that kernel the device holds at once
+    std::mutex resident_mu;
 };
 
 namespace {
@@ -90,8 +145,12 @@ int set_err(fadehip_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> l(ctx->err_mu);
+        ctx->err = buf;
+    }
     g_err = buf;
+    g_err_ctx = ctx;
     return code;
 }
 
@@ -117,8 +176,27 @@ int reserve(fadehip_ctx *ctx, DevBuf &b, size_t bytes) {
     return 0;
 }
 
+int reserve_pinned(fadehip_ctx *ctx, PinBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    if (b.p) {
+        HIPCHK(ctx, hipHostFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = std::max<size_t>(bytes + bytes / 8, 4096);  // some headroom: batches of a stream differ a little in size
+    want = (want + 4095) & ~(size_t)4095;
+    HIPCHK(ctx, hipHostMalloc((void **)&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
 void release(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+void release(PinBuf &b) {
+    if (b.p) (void)hipHostFree(b.p);
     b.p = nullptr;
     b.cap = 0;
 }
@@ -138,7 +216,8 @@ int build_score_tab(fadehip_ctx *ctx, const fadehip_params &p, ScoreTab &sc) {
             int w;
             if (cq >= PAD_CLASS || cr >= PAD_CLASS) w = -p.open;  // pad row/column: W' = 0
             else if (cq == 5 || cr == 5) w = 0;                   // parasail wildcard
-            else w = (cq == cr) ? p.match : p.mismatch;           // N vs N scores `match` (Appendix A.1)
+            else if (cq == 4 && cr == 4) w = (p.rules & FADEHIP_RULE_N_MATCHES_N) ? p.match : p.mismatch;  // Appendix A.1
+            else w = (cq == cr) ? p.match : p.mismatch;
             v |= (uint32_t)(w + p.open) << (4 * cr);
         }
         sc.prof[cq] = v;
@@ -147,6 +226,7 @@ int build_score_tab(fadehip_ctx *ctx, const fadehip_params &p, ScoreTab &sc) {
     sc.ext = p.ext;
     sc.match = p.match;
     sc.mismatch = p.mismatch;
+    sc.rules = p.rules;
     return 0;
 }
 
@@ -194,61 +274,94 @@ int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size
     }
 }
 
+// mode 1: score pass, 2: traced re-computation (default rules), 3: traced re-computation with rule switches
 template <int C>
-int launch_pk_mode(fadehip_ctx *ctx, int cls, int mode, const SwArgs &a, int octets, size_t lds, hipStream_t st) {
+const void *pk_kernel_ptr(int cls, int mode) {
     if constexpr (C >= NUM_CLASSES) {
-        return set_err(ctx, FADEHIP_E_INVALID, "bad class %d", cls);
+        return nullptr;
     } else {
         if (cls == C) {
             constexpr int R = class_rows(C);
-            if (mode == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 1>), dim3(octets), dim3(64), lds, st, a);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 2>), dim3(octets), dim3(64), lds, st, a);
-            HIPCHK(ctx, hipGetLastError());
-            return 0;
+            if (mode == 1) return (const void *)sw_pk_kernel<R, 1>;
+            if (mode == 2) return (const void *)sw_pk_kernel<R, 2>;
+            return (const void *)sw_pk_kernel<R, 3>;
         }
-        return launch_pk_mode<C + 1>(ctx, cls, mode, a, octets, lds, st);
+        return pk_kernel_ptr<C + 1>(cls, mode);
     }
 }
 
-__global__ void make_cand_back_kernel(const Cand *in, int n, int back, Cand *out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) {
-        Cand c = in[k];
-        c.c0 = (int)c.c0 > back ? c.c0 - (uint32_t)back : 0u;
-        out[k] = c;
-    }
+int launch_pk_mode(fadehip_ctx *ctx, int cls, int mode, const SwArgs &a, int waves, size_t lds, hipStream_t st) {
+    const void *fn = pk_kernel_ptr<0>(cls, mode);
+    if (!fn) return set_err(ctx, FADEHIP_E_INVALID, "bad class %d", cls);
+    SwArgs copy = a;
+    void *args[] = {&copy};
+    HIPCHK(ctx, hipLaunchKernel(fn, dim3((unsigned)waves), dim3(64), args, lds, st));
+    return 0;
 }
 
-// Two-pass path for one class list: pass 1 scores every alignment and leaves H/E checkpoints
-// every CK_COLS columns; the selection keeps the alignments that can still become an artifact call; pass 2
-// re-computes, with trace, only columns [c0, end_ref] of each candidate and walks the traceback; a candidate
-// whose path leaves that range on the left is re-run from column 0.
-int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *work, const Meta *meta,
-                       int n_items, int max_lr, const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out,
-                       uint8_t *rs, int floor_len, int gate, int64_t budget, bool timed) {
-    const int R = class_rows(cls);
+// waves of a pass-2 kernel the device holds at once: the size of its persistent launch
+int resident_waves(fadehip_ctx *ctx, int cls, int mode, size_t lds) {
+    const uint64_t key = ((uint64_t)cls << 40) | ((uint64_t)mode << 32) | (uint64_t)lds;
+    std::lock_guard<std::mutex> l(ctx->resident_mu);
+    auto it = ctx->resident.find(key);
+    if (it != ctx->resident.end()) return it->second;
+    int per_cu = 0;
+    const void *fn = pk_kernel_ptr<0>(cls, mode);
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    const int w = per_cu * std::max(ctx->cu_count, 1);
+    ctx->resident[key] = w;
+    return w;
+}
+
+struct ClassRun {
+    int cls;
+    const Work *work;
+    const Meta *meta;
+    int n_bound;                // items on the list, at most
+    const uint32_t *count_dev;  // where the device keeps the real count
+    int max_lr;                 // longest window, at most
+    const uint8_t *q_nib, *r_nib;
+    fadehip_aln *out;
+    uint8_t *rs;
+    int floor_len, gate;
+    int64_t budget;
+    bool timed;
+};
+
+// Two-pass path for one class list, enqueued without a read-back: pass 1 scores every alignment and
+// leaves wave snapshots every CK_COLS steps; the selection keeps the alignments that can still become an artifact call
+// and buckets them by the steps to re-compute; plan_kernel turns the bucket counts into the pass-2 table; pass 2
+// (persistent waves) re-computes those steps with trace; the traceback walks them.  A candidate whose path leaves its
+// traced steps is listed and re-run from further back (two fixed rounds, no-ops when the list is empty).
+int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c) {
+    const int cls = c.cls, R = class_rows(cls), max_lr = c.max_lr, n_items = c.n_bound;
     const int n_ck = (max_lr + 15 + CK_COLS - 1) / CK_COLS;
     const uint64_t ck_stride = (uint64_t)n_ck * ck_dwords(R) * 64;  // dwords per pass-1 octet
-    auto strides = [&](int steps, int *n_blocks, uint64_t *stride, int *ref_stride, size_t *lds) {
-        *n_blocks = (steps + 3) / 4;
-        *stride = (uint64_t)*n_blocks * R * 64;
-        *ref_stride = (((*n_blocks * 4) * 2 + 15) / 16) * 16;
-        *lds = (size_t)*ref_stride * 4;
-    };
-    int nb1, ref_stride1;
-    uint64_t stride_unused;
-    size_t lds1;
-    strides(max_lr + 15, &nb1, &stride_unused, &ref_stride1, &lds1);
+    const int n_blocks1 = (max_lr + 15 + 3) / 4;
+    const int ref_stride1 = (((n_blocks1 * 4) * 2 + 15) / 16) * 16;
+    const size_t lds1 = (size_t)ref_stride1 * 4;
     if (lds1 > 64 * 1024)
         return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, lds1);
-    // chunk so that the checkpoints of a chunk fit half the budget (the other half is pass-2 trace scratch)
+    const bool alt_rules = (ctx->sc.rules & (FADEHIP_RULE_HDIR_DIAG_F_E | FADEHIP_RULE_GAP_TIE_EXTENDS)) !=
+                           (FADEHIP_RULE_HDIR_DIAG_F_E | FADEHIP_RULE_GAP_TIE_EXTENDS);
+    const int mode2 = alt_rules ? 3 : 2;
+    // chunk so that the snapshots of a chunk fit half the budget (the other half is pass-2 trace scratch)
     const int64_t ck_bytes = (int64_t)ck_stride * 4;
     const int total_oct = (n_items + 7) / 8;
-    const int64_t chunk_oct = std::max<int64_t>(1, std::min<int64_t>(total_oct, (budget / 2) / std::max<int64_t>(ck_bytes, 1)));
+    const int64_t chunk_oct = std::max<int64_t>(1, std::min<int64_t>(total_oct, (c.budget / 2) / std::max<int64_t>(ck_bytes, 1)));
     int rc;
     if ((rc = reserve(ctx, s.ckpt, (size_t)(chunk_oct * ck_bytes))) || (rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd))) ||
-        (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)))
+        (rc = reserve(ctx, s.p2tab, sizeof(P2Table))))
         return rc;
+    // trace scratch of pass 2: what a chunk whose candidates all re-compute ~128 steps would need, unless it is already
+    // larger; a plan that needs more reports it and the batch is run again (finish_run)
+    {
+        const int64_t stride128 = (int64_t)((std::min(128, max_lr + 15) + 3) / 4) * R * 64 * 4;
+        int64_t want = ctx->trace_init_bytes > 0 ? ctx->trace_init_bytes
+                                                 : std::min<int64_t>(std::max<int64_t>(c.budget / 2, 1 << 20), (chunk_oct / 2 + NUM_BUCKETS) * stride128);
+        if ((int64_t)s.trace.cap < want && (rc = reserve(ctx, s.trace, (size_t)want))) return rc;
+    }
+    const unsigned long long trace_cap_dwords = s.trace.cap / 4;
     uint32_t *const sel_counters = s.d_sel(cls);
     for (int64_t o0 = 0; o0 < total_oct; o0 += chunk_oct) {
         const int octs = (int)std::min<int64_t>(chunk_oct, total_oct - o0);
@@ -260,10 +373,11 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         if (!s.sel_fresh[cls]) HIPCHK(ctx, hipMemsetAsync(sel_counters, 0, sizeof(uint32_t) * (NUM_BUCKETS + 1), st));
         s.sel_fresh[cls] = false;
         SwArgs a;
-        a.work = work + i0;
+        memset(&a, 0, sizeof a);
+        a.work = c.work + i0;
         a.n_items = n;
-        a.q_nib = q_nib;
-        a.r_nib = r_nib;
+        a.q_nib = c.q_nib;
+        a.r_nib = c.r_nib;
         a.trace = nullptr;
         a.quad_stride = 0;
         a.ref_stride = ref_stride1;
@@ -273,150 +387,117 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const
         a.ckpt = (uint32_t *)s.ckpt.p;
         a.ck_stride = ck_stride;
         a.n_ck = n_ck;
+        a.count_dev = c.count_dev;
+        a.item_base = (uint32_t)i0;
+        a.tab_dev = nullptr;
+        a.ticket = nullptr;
         int e0 = -1, e1 = -1, e2 = -1;
-        if (timed && (rc = record(ctx, s, &e0))) return rc;
-        if ((rc = launch_pk_mode<0>(ctx, cls, 1, a, octs, lds1, st))) return rc;
-        if (timed && (rc = record(ctx, s, &e1))) return rc;
+        if (c.timed && (rc = record(ctx, s, &e0))) return rc;
+        if ((rc = launch_pk_mode(ctx, cls, 1, a, octs, lds1, st))) return rc;
+        if (c.timed && (rc = record(ctx, s, &e1))) return rc;
         SelArgs sel;
-        sel.work = work + i0;
-        sel.meta = meta ? meta + i0 : nullptr;
+        memset(&sel, 0, sizeof sel);
+        sel.work = c.work + i0;
+        sel.meta = c.meta ? c.meta + i0 : nullptr;
         sel.fwd = (const Fwd *)s.fwd.p + i0;
         sel.n_items = n;
-        sel.floor_len = floor_len;
+        sel.floor_len = c.floor_len;
         sel.trace_all = ctx->prm.trace_all;
         sel.R = R;
         sel.span_slack = ctx->span_slack;
         sel.cand = (Cand *)s.cand.p;
         sel.cap = (uint32_t)n;
         sel.bucket_n = sel_counters;
-        sel.out = out + i0;
-        sel.q_nib = q_nib;
-        sel.r_nib = r_nib;
-        sel.rs = rs;
-        sel.stats = (rs && gate) ? s.d_stats() : nullptr;
-        sel.gate = gate;
-        sel.match = getenv("FADEHIP_NO_SHORTCUT") ? 0 : ctx->sc.match;
+        sel.out = c.out + i0;
+        sel.q_nib = c.q_nib;
+        sel.r_nib = c.r_nib;
+        sel.rs = c.rs;
+        sel.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+        sel.gate = c.gate;
+        sel.match = getenv("FADEHIP_NO_SHORTCUT") ? 0 : ctx->sc.match;  // read per run: a test flips it on a live ctx
+        sel.rules = ctx->sc.rules;
+        sel.count_dev = c.count_dev;
+        sel.item_base = (uint32_t)i0;
         hipLaunchKernelGGL(select_kernel, dim3((n + SELECT_BLOCK - 1) / SELECT_BLOCK), dim3(SELECT_BLOCK), 0, st, sel);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(s.h_sel, sel_counters, sizeof(uint32_t) * NUM_BUCKETS, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        uint32_t bucket_n[NUM_BUCKETS];
-        for (int b = 0; b < NUM_BUCKETS; b++) bucket_n[b] = s.h_sel[b];
-        // pass 2: every bucket in ONE forward launch and ONE traceback launch (separate launches per bucket
-        // each run a fraction of a wave-round and pay their own ramp and tail)
-        auto pass2 = [&](const Cand *cand, uint32_t cap, const uint32_t *counts, const int *steps_max, int nb,
-                         bool may_be_incomplete) -> int {
-            P2Table tab;
-            memset(&tab, 0, sizeof tab);
-            tab.cap = cap;
-            uint64_t off = 0;
-            uint32_t oct = 0;
-            size_t lds2 = 0;
-            int ref_stride2 = 16;
-            for (int k = 0; k < NUM_BUCKETS; k++) {
-                const int b = nb - 1 - k;  // longest bucket first
-                tab.oct_first[k] = oct;
-                if (b < 0 || !counts[b]) continue;
-                int nb2, rs2;
-                uint64_t st2;
-                size_t l2;
-                strides(steps_max[b], &nb2, &st2, &rs2, &l2);
-                tab.count[k] = counts[b];
-                tab.bucket[k] = (uint32_t)b;
-                tab.trace_base[k] = off;
-                tab.stride[k] = st2;
-                const uint32_t octs_b = (counts[b] + 7) / 8;
-                off += (uint64_t)octs_b * st2;
-                oct += octs_b;
-                lds2 = std::max(lds2, l2);
-                ref_stride2 = std::max(ref_stride2, rs2);
-            }
-            tab.oct_first[NUM_BUCKETS] = oct;
-            if (!oct) return 0;
-            int r2 = reserve(ctx, s.trace, (size_t)off * 4);
-            if (r2) return r2;
+        // pass 2: every bucket in ONE persistent forward launch and ONE traceback launch
+        auto pass2 = [&](const Cand *cand, bool rerun, int back, bool may_be_incomplete) -> int {
+            PlanArgs pa;
+            memset(&pa, 0, sizeof pa);
+            pa.bucket_n = rerun ? nullptr : sel_counters;
+            pa.incomplete_n = sel_counters + NUM_BUCKETS;
+            pa.incomplete = (const Cand *)s.incomplete.p;
+            pa.again = (Cand *)s.cand.p;  // the bucket lists are consumed by then, reuse their storage
+            pa.back = back;
+            for (int b = 0; b < NUM_BUCKETS; b++) pa.steps_max[b] = rerun ? max_lr + 15 : std::min(bucket_cols(b), max_lr + 15);
+            pa.n_buckets = rerun ? 1 : NUM_BUCKETS;
+            pa.R = R;
+            pa.cap = (uint32_t)n;
+            const uint32_t oct_bound = (uint32_t)((n + 7) / 8) + (rerun ? 0u : (uint32_t)NUM_BUCKETS);
+            pa.oct_bound = oct_bound;
+            pa.trace_cap_dwords = trace_cap_dwords;
+            pa.tab = (P2Table *)s.p2tab.p;
+            pa.plan = s.d_plan();
+            hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, st, pa);
+            HIPCHK(ctx, hipGetLastError());
+            if (s.tickets_used >= (int)Slot::N_TICKETS)
+                return set_err(ctx, FADEHIP_E_UNSUPPORTED, "more than %d pass-2 launches in one run (raise trace_bytes)", (int)Slot::N_TICKETS);
             SwArgs b2 = a;
             b2.n_items = 0;
             b2.cand = cand;
             b2.trace = (uint32_t *)s.trace.p;
-            b2.quad_stride = 0;
-            b2.ref_stride = ref_stride2;
-            b2.tab = tab;
-            if ((r2 = launch_pk_mode<0>(ctx, cls, 2, b2, (int)oct, lds2, st))) return r2;
+            b2.count_dev = nullptr;
+            b2.tab_dev = (const P2Table *)s.p2tab.p;
+            b2.ticket = s.d_ticket(s.tickets_used++);
+            // a re-run round serves the handful of paths the span estimate missed: a few waves are plenty
+            const int waves = (int)std::min<uint32_t>(oct_bound, (uint32_t)(rerun ? 2 * ctx->cu_count : resident_waves(ctx, cls, mode2, lds1)));
+            int r2 = launch_pk_mode(ctx, cls, mode2, b2, std::max(waves, 1), lds1, st);
+            if (r2) return r2;
             TbArgs t;
-            t.work = work + i0;
-            t.meta = meta ? meta + i0 : nullptr;
+            memset(&t, 0, sizeof t);
+            t.work = c.work + i0;
+            t.meta = c.meta ? c.meta + i0 : nullptr;
             t.fwd = (const Fwd *)s.fwd.p + i0;
-            t.n_items = (int)oct * 8;
+            t.n_items = (int)oct_bound * 8;
             t.R = R;
-            t.q_nib = q_nib;
-            t.r_nib = r_nib;
+            t.q_nib = c.q_nib;
+            t.r_nib = c.r_nib;
             t.trace = (const uint32_t *)s.trace.p;
             t.quad_stride = 0;
             t.sc = ctx->sc;
-            t.out = out + i0;
-            t.rs = rs;
-        t.stats = (rs && gate) ? s.d_stats() : nullptr;
-            t.stats = (rs && gate) ? s.d_stats() : nullptr;
-            t.floor_len = floor_len;
-            t.gate = gate;
-            t.early_out = (gate && meta && !ctx->prm.trace_all) ? 1 : 0;
+            t.out = c.out + i0;
+            t.rs = c.rs;
+            t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+            t.floor_len = c.floor_len;
+            t.gate = c.gate;
+            t.early_out = (c.gate && c.meta && !ctx->prm.trace_all) ? 1 : 0;
             t.packed = 1;
             t.cand = cand;
             t.incomplete = may_be_incomplete ? (Cand *)s.incomplete.p : nullptr;
             t.incomplete_n = sel_counters + NUM_BUCKETS;
-            t.tab = tab;
-            hipLaunchKernelGGL(traceback_kernel, dim3((oct * 8 + 63) / 64), dim3(64), 0, st, t);
+            t.tab_dev = (const P2Table *)s.p2tab.p;
+            hipLaunchKernelGGL(traceback_kernel, dim3((oct_bound * 8 + 63) / 64), dim3(64), 0, st, t);
             HIPCHK(ctx, hipGetLastError());
-            s.prof_counts[2] += (int64_t)off * 4;
             return 0;
         };
-        int steps_max[NUM_BUCKETS];
-        for (int b = 0; b < NUM_BUCKETS; b++) steps_max[b] = std::min(bucket_cols(b), max_lr + 15);
-        if ((rc = pass2((const Cand *)s.cand.p, (uint32_t)n, bucket_n, steps_max, NUM_BUCKETS, true))) return rc;
-        // candidates whose path left the traced steps: from one snapshot further back (a lone wave is pure latency,
-        // ~0.4 us per step, and most paths miss by a few columns), then from eight, then from step 0
-        int n_inc = 0;
-        for (int round = 0; round < 3; round++) {
-            HIPCHK(ctx, hipMemcpyAsync(s.h_sel + NUM_BUCKETS, sel_counters + NUM_BUCKETS, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            const int m = (int)s.h_sel[NUM_BUCKETS];
-            if (m == 0) break;
-            n_inc += m;
-            Cand *again = (Cand *)s.cand.p;  // the bucket lists are consumed, reuse their storage
-            hipLaunchKernelGGL(make_cand_back_kernel, dim3((m + 255) / 256), dim3(256), 0, st, (const Cand *)s.incomplete.p, m,
-                               round == 0 ? CK_COLS : (round == 1 ? 8 * CK_COLS : (1 << 30)), again);
-            HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemsetAsync(sel_counters + NUM_BUCKETS, 0, sizeof(uint32_t), st));
-            const uint32_t cnt1[1] = {(uint32_t)m};
-            const int st1[1] = {max_lr + 15};
-            if ((rc = pass2(again, (uint32_t)m, cnt1, st1, 1, round < 2))) return rc;
-        }
-        s.n_rerun += n_inc;
-        if (getenv("FADEHIP_DEBUG")) {
-            fprintf(stderr, "[fadehip] class R=%d chunk n=%d: buckets", R, n);
-            for (int b = 0; b < NUM_BUCKETS; b++) fprintf(stderr, " %u", bucket_n[b]);
-            fprintf(stderr, " | re-run from step 0: %d\n", n_inc);
-        }
-        if (timed) {
+        if ((rc = pass2((const Cand *)s.cand.p, false, 0, true))) return rc;
+        // candidates whose path left the traced steps: from four snapshots further back (a lone wave is pure latency,
+        // ~0.4 us per step, and most paths miss by a few columns), then from step 0
+        if ((rc = pass2((const Cand *)s.cand.p, true, 4 * CK_COLS, true))) return rc;
+        if ((rc = pass2((const Cand *)s.cand.p, true, 1 << 30, false))) return rc;
+        if (c.timed) {
             if ((rc = record(ctx, s, &e2))) return rc;
             s.fwd_spans.push_back({e0, e1});
             s.tb_spans.push_back({e1, e2});
         }
-        s.n_fwd_launches++;
-        for (int b = 0; b < NUM_BUCKETS; b++) s.n_cand += bucket_n[b];
     }
     return 0;
 }
 
-// Runs forward + traceback for one class list, chunked so the trace fits `trace`.
-int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *work, const Meta *meta, int n_items,
-              int max_lr, const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out, uint8_t *rs, int floor_len,
-              int gate, int64_t trace_budget, bool timed) {
-    if (ctx->two_pass)
-        return run_class_two_pass(ctx, s, st, cls, work, meta, n_items, max_lr, q_nib, r_nib, out, rs, floor_len, gate,
-                                  trace_budget, timed);
-    const int R = class_rows(cls);
+// Single-pass kernels (FADEHIP_KERNEL=pk|int32, and scoring schemes beyond the two-pass ranges): forward with full
+// trace + traceback for one class list whose item count the host knows, chunked so the trace fits the budget.
+int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c) {
+    const int cls = c.cls, R = class_rows(cls), n_items = c.n_bound, max_lr = c.max_lr;
     const bool packed = ctx->use_packed;
     const int per_wave = packed ? 8 : 4;  // alignments per wavefront
     const int n_blocks = (max_lr + 15 + 3) / 4;
@@ -427,7 +508,7 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
     if (lds > 64 * 1024)
         return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, lds);
     const int64_t quad_bytes = (int64_t)quad_stride * 4;
-    int64_t max_quads = std::max<int64_t>(1, trace_budget / quad_bytes);
+    int64_t max_quads = std::max<int64_t>(1, c.budget / quad_bytes);
     const int total_quads = (n_items + per_wave - 1) / per_wave;
     const int64_t chunk_quads = std::min<int64_t>(max_quads, total_quads);
     int rc = reserve(ctx, s.trace, (size_t)(chunk_quads * quad_bytes));
@@ -439,65 +520,59 @@ int run_class(fadehip_ctx *ctx, Slot &s, hipStream_t st, int cls, const Work *wo
         const int i0 = (int)(q0 * per_wave);
         const int n = std::min(n_items - i0, quads * per_wave);
         SwArgs a;
-        a.work = work + i0;
+        memset(&a, 0, sizeof a);
+        a.work = c.work + i0;
         a.n_items = n;
-        a.q_nib = q_nib;
-        a.r_nib = r_nib;
+        a.q_nib = c.q_nib;
+        a.r_nib = c.r_nib;
         a.trace = (uint32_t *)s.trace.p;
         a.quad_stride = quad_stride;
         a.ref_stride = ref_stride;
         a.fwd = (Fwd *)s.fwd.p + i0;
         a.sc = ctx->sc;
-        a.cand = nullptr;
-        a.ckpt = nullptr;
-        a.ck_stride = 0;
-        a.n_ck = 0;
         int e0 = -1, e1 = -1, e2 = -1;
-        if (timed && (rc = record(ctx, s, &e0))) return rc;
+        if (c.timed && (rc = record(ctx, s, &e0))) return rc;
         rc = launch_forward_c<0>(ctx, cls, a, quads, lds, st, packed);
         if (rc) return rc;
-        if (timed && (rc = record(ctx, s, &e1))) return rc;
+        if (c.timed && (rc = record(ctx, s, &e1))) return rc;
         TbArgs t;
-        t.work = work + i0;
-        t.meta = meta ? meta + i0 : nullptr;
+        memset(&t, 0, sizeof t);
+        t.work = c.work + i0;
+        t.meta = c.meta ? c.meta + i0 : nullptr;
         t.fwd = (Fwd *)s.fwd.p + i0;
         t.n_items = n;
         t.R = R;
-        t.q_nib = q_nib;
-        t.r_nib = r_nib;
+        t.q_nib = c.q_nib;
+        t.r_nib = c.r_nib;
         t.trace = (const uint32_t *)s.trace.p;
         t.quad_stride = quad_stride;
         t.sc = ctx->sc;
-        t.out = out + i0;
-        t.rs = rs;
-        t.stats = (rs && gate) ? s.d_stats() : nullptr;
-        t.floor_len = floor_len;
-        t.gate = gate;
+        t.out = c.out + i0;
+        t.rs = c.rs;
+        t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+        t.floor_len = c.floor_len;
+        t.gate = c.gate;
         t.early_out = 0;
         t.packed = packed ? 1 : 0;
-        t.cand = nullptr;
-        t.incomplete = nullptr;
-        t.incomplete_n = nullptr;
         hipLaunchKernelGGL(traceback_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t);
         HIPCHK(ctx, hipGetLastError());
-        if (timed) {
+        if (c.timed) {
             if ((rc = record(ctx, s, &e2))) return rc;
             s.fwd_spans.push_back({e0, e1});
             s.tb_spans.push_back({e1, e2});
         }
         s.prof_counts[2] += (int64_t)quads * quad_bytes;
-        s.n_fwd_launches++;
     }
     return 0;
 }
 
-// Queries longer than 512 bases: sw_long_kernel (thread per alignment, full trace) + the common traceback.
-int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const Work *work, const Meta *meta, int n_items, int max_lr, int max_lq,
-             const uint8_t *q_nib, const uint8_t *r_nib, fadehip_aln *out, uint8_t *rs, int32_t floor_len, int gate, int64_t budget,
-             bool timed) {
+// Queries longer than 512 bases (or windows beyond the wave kernels' LDS): sw_long_kernel (thread per alignment, full
+// trace) + the common traceback.  n_bound / max_lq / max_lr are upper bounds, the live count stays on the device.
+int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int max_lq) {
+    const int n_items = c.n_bound, max_lr = c.max_lr;
     const int lhalf = (max_lr + 1) / 2;
     const int64_t per_item = (int64_t)max_lq * lhalf + 8 * (int64_t)max_lr;
-    const int64_t chunk = std::min<int64_t>(n_items, budget / std::max<int64_t>(per_item, 1));
+    const int64_t chunk = std::min<int64_t>(n_items, c.budget / std::max<int64_t>(per_item, 1));
     if (chunk < 1)
         return set_err(ctx, FADEHIP_E_UNSUPPORTED, "a %d x %d alignment needs %lld B of trace, more than trace_bytes", max_lq, max_lr,
                        (long long)per_item);
@@ -509,10 +584,11 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const Work *work, const 
             (rc = reserve(ctx, s.lrows, 8 * (size_t)max_lr * (size_t)n)))
             return rc;
         LongArgs a;
-        a.work = work + i0;
+        memset(&a, 0, sizeof a);
+        a.work = c.work + i0;
         a.n_items = n;
-        a.q_nib = q_nib;
-        a.r_nib = r_nib;
+        a.q_nib = c.q_nib;
+        a.r_nib = c.r_nib;
         a.hrow = (int32_t *)s.lrows.p;
         a.frow = (int32_t *)s.lrows.p + (size_t)max_lr * (size_t)n;
         a.trace = (uint8_t *)s.trace.p;
@@ -521,44 +597,42 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const Work *work, const 
         a.max_lr = max_lr;
         a.fwd = (Fwd *)s.fwd.p + i0;
         a.sc = ctx->sc;
+        a.count_dev = c.count_dev;
+        a.item_base = (uint32_t)i0;
         int e0 = -1, e1 = -1, e2 = -1;
-        if (timed && (rc = record(ctx, s, &e0))) return rc;
+        if (c.timed && (rc = record(ctx, s, &e0))) return rc;
         hipLaunchKernelGGL(sw_long_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a);
         HIPCHK(ctx, hipGetLastError());
-        if (timed && (rc = record(ctx, s, &e1))) return rc;
+        if (c.timed && (rc = record(ctx, s, &e1))) return rc;
         TbArgs t;
         memset(&t, 0, sizeof t);
-        t.work = work + i0;
-        t.meta = meta ? meta + i0 : nullptr;
+        t.work = c.work + i0;
+        t.meta = c.meta ? c.meta + i0 : nullptr;
         t.fwd = (Fwd *)s.fwd.p + i0;
         t.n_items = n;
         t.R = 1;
-        t.q_nib = q_nib;
-        t.r_nib = r_nib;
-        t.trace = nullptr;
-        t.quad_stride = 0;
+        t.q_nib = c.q_nib;
+        t.r_nib = c.r_nib;
         t.sc = ctx->sc;
-        t.out = out + i0;
-        t.rs = rs;
-        t.stats = (rs && gate) ? s.d_stats() : nullptr;
-        t.floor_len = floor_len;
-        t.gate = gate;
+        t.out = c.out + i0;
+        t.rs = c.rs;
+        t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+        t.floor_len = c.floor_len;
+        t.gate = c.gate;
         t.early_out = 0;
         t.packed = 2;
         t.ltrace = (const uint8_t *)s.trace.p;
         t.lhalf = lhalf;
-        t.cand = nullptr;
-        t.incomplete = nullptr;
-        t.incomplete_n = nullptr;
+        t.count_dev = c.count_dev;
+        t.item_base = (uint32_t)i0;
         hipLaunchKernelGGL(traceback_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t);
         HIPCHK(ctx, hipGetLastError());
-        if (timed) {
+        if (c.timed) {
             if ((rc = record(ctx, s, &e2))) return rc;
             s.fwd_spans.push_back({e0, e1});
             s.tb_spans.push_back({e1, e2});
         }
         s.prof_counts[2] += (int64_t)max_lq * lhalf * n;
-        s.n_fwd_launches++;
     }
     return 0;
 }
@@ -566,6 +640,271 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const Work *work, const 
 int check_slot(fadehip_ctx *ctx, int slot) {
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
     if (slot < 0 || slot >= FADEHIP_NUM_SLOTS) return set_err(ctx, FADEHIP_E_INVALID, "slot %d out of range", slot);
+    return 0;
+}
+
+// typed views of the batch in flight, on the host and on the device
+template <class T>
+const T *h_arr(const Slot &s, int k) { return (const T *)(s.h_base + s.L.off[k]); }
+template <class T>
+const T *d_arr(const Slot &s, int k) { return (const T *)((const uint8_t *)s.in.p + s.L.off[k]); }
+
+// anno.d:61 + util.d:37-62 + dhtslib alignedLength over one record's CIGAR, as gate_kernel computes them
+struct CigarSummary {
+    int n_soft;
+    uint32_t clipL, clipR;
+    int64_t aligned;
+};
+inline CigarSummary summarize_cigar(const uint32_t *ops, uint32_t c0, uint32_t c1) {
+    CigarSummary r = {0, 0, 0, 0};
+    bool first = true;
+    for (uint32_t k = c0; k < c1; k++) {
+        const uint32_t op = ops[k] & 15u, len = ops[k] >> 4;
+        if (op == 4) r.n_soft++;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.aligned += len;
+        if (op == 5) continue;
+        const bool is_sc = (op == 4);
+        if (first && !is_sc) first = false;
+        else if (first && is_sc) r.clipL = len;
+        else if (is_sc) r.clipR = len;
+    }
+    return r;
+}
+
+// Host-side bounds of a run (the launches are sized from these; the device keeps the real counts and checks every bound
+// before it writes: a record beyond one is reported at results, never trusted).
+int plan_run(fadehip_ctx *ctx, Slot &s) {
+    const int n = s.n_reads;
+    const int64_t w = s.window;
+    for (int c = 0; c < NUM_LISTS; c++) s.bound[c] = s.hist[c];
+    const int64_t lr_bound = std::min<int64_t>(s.span_bound + 2 * w, ctx->prm.max_ref_len);
+    s.wave_lr_bound = (int)std::min<int64_t>(lr_bound, WAVE_MAX_WINDOW);
+    s.long_max_lq = s.max_lq;
+    s.long_max_lr = (int)std::max<int64_t>(lr_bound, 1);
+    if (lr_bound > WAVE_MAX_WINDOW) {
+        // some window may exceed what the wave kernels stage in LDS: count exactly which records go to the long list
+        // (analysis.d:45-59 per record), so that its buffers are sized for those and not for the whole batch
+        const int32_t *tid = h_arr<int32_t>(s, A_TID), *pos = h_arr<int32_t>(s, A_POS), *lseq = h_arr<int32_t>(s, A_LSEQ);
+        const uint16_t *flag = h_arr<uint16_t>(s, A_FLAG);
+        const uint32_t *coff = h_arr<uint32_t>(s, A_CIGOFF), *cops = h_arr<uint32_t>(s, A_CIG);
+        uint32_t n_long = 0;
+        int64_t max_lr = 1;
+        int max_lq = 1;
+        for (int i = 0; i < n; i++) {
+            const int lq = lseq[i];
+            const bool by_len = lq > 16 * class_rows(NUM_CLASSES - 1);
+            bool is_long = by_len;
+            int64_t lr = 0;
+            if ((flag[i] & 4u) == 0 && tid[i] >= 0 && tid[i] < ctx->n_contigs) {
+                const CigarSummary cs = summarize_cigar(cops, coff[i], coff[i + 1]);
+                const int64_t start = std::max<int64_t>((int64_t)pos[i] - w, 0);
+                const int64_t end = std::min<int64_t>((int64_t)pos[i] + cs.aligned + w, ctx->h_contig_len[(size_t)tid[i]]);
+                lr = end - start;
+                if (cs.n_soft > 0 && lr > WAVE_MAX_WINDOW) is_long = true;
+            }
+            if (is_long && lq > 0) {
+                n_long++;
+                max_lq = std::max(max_lq, lq);
+                max_lr = std::max(max_lr, std::min<int64_t>(lr > 0 ? lr : lr_bound, lr_bound));
+            }
+        }
+        s.bound[LONG_LIST] = n_long;
+        s.long_max_lq = max_lq;
+        s.long_max_lr = (int)max_lr;
+    }
+    uint32_t base = 0;
+    for (int c = 0; c < NUM_LISTS; c++) {
+        s.aln_base[c] = base;
+        base += s.bound[c];
+    }
+    return 0;
+}
+
+// Enqueue one whole run of the slot's uploaded batch on its stream (two-pass path: nothing is read back).
+int enqueue_run(fadehip_ctx *ctx, Slot &s) {
+    hipStream_t st = s.stream;
+    const int n = s.n_reads;
+    const int floor_len = s.floor_len;
+    s.ev_used = 0;
+    s.fwd_spans.clear();
+    s.tb_spans.clear();
+    s.tickets_used = 0;
+    memset(s.prof_counts, 0, sizeof s.prof_counts);
+    int rc;
+    uint32_t total_bound = 0;
+    for (int c = 0; c < NUM_LISTS; c++) total_bound += s.bound[c];
+    s.res_aln_off = ((size_t)n + 255) & ~(size_t)255;
+    if ((rc = reserve(ctx, s.rs, (size_t)n)) || (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)std::max<uint32_t>(total_bound, 1))) ||
+        (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)) ||
+        (rc = reserve_pinned(ctx, s.res, s.res_aln_off + sizeof(fadehip_aln) * (size_t)total_bound)))
+        return rc;
+    for (int c = 0; c < NUM_LISTS; c++) {
+        if (!s.bound[c]) continue;
+        if ((rc = reserve(ctx, s.work[c], sizeof(Work) * (size_t)s.bound[c])) || (rc = reserve(ctx, s.meta[c], sizeof(Meta) * (size_t)s.bound[c])))
+            return rc;
+    }
+    HIPCHK(ctx, hipMemsetAsync(s.zblock.p, 0, Slot::ZB_BYTES, st));  // every counter of the run in one fill
+    for (int c = 0; c < NUM_CLASSES; c++) s.sel_fresh[c] = true;
+    if ((rc = record(ctx, s, &s.ev_gate0))) return rc;
+    GateArgs g;
+    memset(&g, 0, sizeof g);
+    g.n_reads = n;
+    g.tid = d_arr<int32_t>(s, A_TID);
+    g.pos = d_arr<int32_t>(s, A_POS);
+    g.l_seq = d_arr<int32_t>(s, A_LSEQ);
+    g.flag = d_arr<uint16_t>(s, A_FLAG);
+    g.has_sa = d_arr<uint8_t>(s, A_SA);
+    g.cigar_off = d_arr<uint32_t>(s, A_CIGOFF);
+    g.cigar_ops = d_arr<uint32_t>(s, A_CIG);
+    g.seq_off = d_arr<uint32_t>(s, A_SEQOFF);
+    g.floor_len = floor_len;
+    g.window = s.window;
+    g.n_contigs = ctx->n_contigs;
+    g.contig_len = (const int64_t *)ctx->contig_len.p;
+    g.contig_base = (const uint64_t *)ctx->contig_base.p;
+    g.max_ref_len = ctx->prm.max_ref_len;
+    g.wave_lr_bound = s.wave_lr_bound;
+    g.long_lr_bound = s.long_max_lr;
+    g.long_lq_bound = std::max(s.long_max_lq, 1);
+    g.rs = (uint8_t *)s.rs.p;
+    for (int c = 0; c < NUM_LISTS; c++) {
+        g.work[c] = (Work *)s.work[c].p;
+        g.meta[c] = (Meta *)s.meta[c].p;
+        g.list_cap[c] = s.bound[c];
+    }
+    g.stats = s.d_stats();
+    g.counters = s.d_counters();
+    g.counters64 = s.d_counters64();
+    hipLaunchKernelGGL(gate_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, g);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
+    const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)16 << 30);
+    const uint8_t *q_nib = d_arr<uint8_t>(s, A_SEQ);
+    uint32_t exact[NUM_LISTS];
+    for (int c = 0; c < NUM_LISTS; c++) exact[c] = s.bound[c];
+    if (!ctx->two_pass) {
+        // single-pass kernels: their launches take the real counts
+        HIPCHK(ctx, hipMemcpyAsync(s.h_zb, s.zblock.p, 128, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int c = 0; c < NUM_LISTS; c++) exact[c] = std::min(s.h_counters()[c], s.bound[c]);
+    }
+    for (int c = 0; c < NUM_CLASSES; c++) {
+        if (!exact[c]) continue;
+        ClassRun cr;
+        cr.cls = c;
+        cr.work = (const Work *)s.work[c].p;
+        cr.meta = (const Meta *)s.meta[c].p;
+        cr.n_bound = (int)exact[c];
+        cr.count_dev = s.d_counters() + c;
+        cr.max_lr = std::max(s.wave_lr_bound, 1);
+        cr.q_nib = q_nib;
+        cr.r_nib = (const uint8_t *)ctx->genome.p;
+        cr.out = (fadehip_aln *)s.aln.p + s.aln_base[c];
+        cr.rs = (uint8_t *)s.rs.p;
+        cr.floor_len = floor_len;
+        cr.gate = 1;
+        cr.budget = budget;
+        cr.timed = true;
+        rc = ctx->two_pass ? run_class_two_pass(ctx, s, st, cr) : run_class_single(ctx, s, st, cr);
+        if (rc) return rc;
+    }
+    if (exact[LONG_LIST]) {
+        ClassRun cr;
+        cr.cls = LONG_LIST;
+        cr.work = (const Work *)s.work[LONG_LIST].p;
+        cr.meta = (const Meta *)s.meta[LONG_LIST].p;
+        cr.n_bound = (int)exact[LONG_LIST];
+        cr.count_dev = s.d_counters() + LONG_LIST;
+        cr.max_lr = s.long_max_lr;
+        cr.q_nib = q_nib;
+        cr.r_nib = (const uint8_t *)ctx->genome.p;
+        cr.out = (fadehip_aln *)s.aln.p + s.aln_base[LONG_LIST];
+        cr.rs = (uint8_t *)s.rs.p;
+        cr.floor_len = floor_len;
+        cr.gate = 1;
+        cr.budget = budget;
+        cr.timed = true;
+        if ((rc = run_long(ctx, s, st, cr, std::max(s.long_max_lq, 1)))) return rc;
+    }
+    if ((rc = record(ctx, s, &s.ev_end))) return rc;
+    // results to the slot's pinned block; the counter block tells the host how many entries of each list are live
+    HIPCHK(ctx, hipMemcpyAsync(s.h_zb, s.zblock.p, Slot::ZB_BYTES, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(s.res.p, s.rs.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    if (total_bound)
+        HIPCHK(ctx, hipMemcpyAsync(s.res.p + s.res_aln_off, s.aln.p, sizeof(fadehip_aln) * (size_t)total_bound, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// Wait for the slot's run and turn the counter block into results (state 2 -> 3).
+int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
+    if (s.state == 3) return 0;
+    if (s.state != 2) return set_err(ctx, FADEHIP_E_STATE, "slot %d has not been run", slot);
+    hipStream_t st = s.stream;
+    const int n = s.n_reads;
+    if (n == 0) {
+        s.n_aln = 0;
+        s.n_oversize = 0;
+        memset(s.stats, 0, sizeof s.stats);
+        s.stats[0] = s.n_skipped;
+        s.state = 3;
+        return 0;
+    }
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const uint32_t errbits = s.h_counters()[2 * NUM_LISTS];
+        if (errbits) {
+            s.state = 1;
+            if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
+            if (errbits & 16u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a record whose cigar.alignedLength exceeds ref_span_bound=%lld", (long long)s.span_bound);
+            if (errbits & 32u) return set_err(ctx, FADEHIP_E_STATE, "internal: a work list outgrew the bound its launches were sized from");
+            return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
+        }
+        const PlanOut *po = s.h_plan();
+        if (po->bound_violated) {
+            s.state = 1;
+            return set_err(ctx, FADEHIP_E_STATE, "internal: a pass-2 plan outgrew the bound its launches were sized from");
+        }
+        if (!po->overflow) break;
+        if (attempt >= 4) {
+            s.state = 1;
+            return set_err(ctx, FADEHIP_E_NOMEM, "pass-2 trace scratch still too small after %d re-runs", attempt);
+        }
+        // the traced re-computation needed more scratch than the slot held: grow it and run the batch again
+        const size_t need = (size_t)po->need_dwords * 4;
+        if (ctx->debug) fprintf(stderr, "[fadehip] slot %d: trace scratch %zu B too small, %zu B needed: batch re-run\n", slot, s.trace.cap, need);
+        int rc = reserve(ctx, s.trace, need + need / 4);
+        if (rc) return rc;
+        s.n_reruns_of_batch++;
+        if ((rc = enqueue_run(ctx, s))) return rc;
+    }
+    // live entries of each list; several lists leave holes between their segments of the result block: close them
+    fadehip_aln *aln = (fadehip_aln *)(s.res.p + s.res_aln_off);
+    uint32_t at = 0;
+    for (int c = 0; c < NUM_LISTS; c++) {
+        const uint32_t cnt = std::min(s.h_counters()[c], s.bound[c]);
+        if (cnt && s.aln_base[c] != at) memmove(aln + at, aln + s.aln_base[c], sizeof(fadehip_aln) * (size_t)cnt);
+        at += cnt;
+    }
+    s.n_aln = (int)at;
+    s.n_oversize = (int)s.h_counters()[2 * NUM_LISTS + 2];
+    for (int k = 0; k < 8; k++) {
+        s.stats[k] = 0;
+        for (int q = 0; q < STAT_PARTS; q++) s.stats[k] += (int64_t)s.h_stats()[8 * q + k];
+    }
+    s.stats[0] += s.n_skipped;  // records the caller left out (anno.d:61-65: rs = 0) are reads all the same
+    const PlanOut *po = s.h_plan();
+    s.n_cand = (int64_t)po->cand_total;
+    s.n_rerun = (int64_t)po->rerun_total;
+    s.prof_counts[0] = at;
+    s.prof_counts[1] = (int64_t)s.h_counters64()[0 * C64_STRIDE];
+    if (ctx->two_pass) s.prof_counts[2] = (int64_t)po->need_dwords * 4;
+    // algorithmic bytes of the dominant kernel: SURVEY §8(d)'s packed query + packed window + 16 B
+    // descriptor + 64 B result slot per alignment
+    s.prof_counts[3] = (int64_t)s.h_counters64()[1 * C64_STRIDE] + (int64_t)at * 80;
+    if (ctx->debug)
+        fprintf(stderr, "[fadehip] slot %d: %d reads, %u alignments, %lld candidates traced, %lld re-run, trace need %lld B\n", slot, n, at,
+                (long long)s.n_cand, (long long)s.n_rerun, (long long)s.prof_counts[2]);
+    s.state = 3;
     return 0;
 }
 
@@ -579,16 +918,24 @@ void fadehip_params_default(fadehip_params *p) {
     p->ext = 2;
     p->match = 2;
     p->mismatch = -3;
-    p->max_ref_len = 8192;
+    p->max_ref_len = 1 << 20;
     p->max_batch_reads = 1 << 20;
     p->trace_bytes = 0;
     p->trace_all = 0;
-    p->reserved = 0;
+    p->rules = FADEHIP_RULES_DEFAULT;
 }
 
 int fadehip_abi_version(void) { return FADEHIP_ABI_VERSION; }
 
-const char *fadehip_last_error(const fadehip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char *fadehip_last_error(const fadehip_ctx *ctx) {
+    if (!ctx || g_err_ctx == ctx) return g_err.c_str();
+    thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> l(const_cast<fadehip_ctx *>(ctx)->err_mu);
+        copy = ctx->err;
+    }
+    return copy.c_str();
+}
 
 int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) {
     if (!out) return set_err(nullptr, FADEHIP_E_INVALID, "out is NULL");
@@ -606,18 +953,27 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     fadehip_params_default(&ctx->prm);
     if (params) {
         ctx->prm = *params;
-        if (ctx->prm.max_ref_len <= 0) ctx->prm.max_ref_len = 8192;
+        if (ctx->prm.max_ref_len <= 0) ctx->prm.max_ref_len = 1 << 20;
         if (ctx->prm.max_batch_reads <= 0) ctx->prm.max_batch_reads = 1 << 20;
+        if (ctx->prm.rules == 0) ctx->prm.rules = FADEHIP_RULES_DEFAULT;
     }
     int rc = 0;
     auto fail = [&](int code) {
-        g_err = ctx->err;
+        {
+            std::lock_guard<std::mutex> l(ctx->err_mu);
+            g_err = ctx->err;
+        }
+        g_err_ctx = nullptr;
         fadehip_destroy(ctx);
         return code;
     };
     if (ctx->prm.max_ref_len > (1 << 20)) {
         set_err(ctx, FADEHIP_E_UNSUPPORTED, "max_ref_len %d exceeds 2^20", ctx->prm.max_ref_len);
         return fail(FADEHIP_E_UNSUPPORTED);
+    }
+    if (ctx->prm.rules & ~(uint32_t)FADEHIP_RULES_DEFAULT) {
+        set_err(ctx, FADEHIP_E_INVALID, "unknown rule bits 0x%x", ctx->prm.rules & ~(uint32_t)FADEHIP_RULES_DEFAULT);
+        return fail(FADEHIP_E_INVALID);
     }
     if ((rc = build_score_tab(ctx, ctx->prm, ctx->sc))) return fail(rc);
     hipDeviceProp_t prop;
@@ -640,27 +996,31 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     // whose ranges still hold: the single-pass packed kernel (32-bit keys) up to match 7, the int32 kernel beyond.
     if (ctx->prm.match > 2) ctx->two_pass = false;
     if (8 * (ctx->prm.match * FADEHIP_MAX_QUERY + ctx->prm.open + std::max(ctx->prm.match, 0)) >= 0x7c00) ctx->use_packed = false;
+    if (!ctx->two_pass && ctx->prm.rules != FADEHIP_RULES_DEFAULT) {
+        set_err(ctx, FADEHIP_E_UNSUPPORTED, "the rule switches exist on the two-pass path only (match <= 2, FADEHIP_KERNEL unset)");
+        return fail(FADEHIP_E_UNSUPPORTED);
+    }
     if (const char *kv = getenv("FADEHIP_SPAN_SLACK")) ctx->span_slack = atoi(kv);
+    if (const char *kv = getenv("FADEHIP_TRACE_INIT")) ctx->trace_init_bytes = atoll(kv);
+    ctx->debug = getenv("FADEHIP_DEBUG") != nullptr;
     uint8_t table[256];
     fill_ascii_table(table);
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_ascii_code), table, 256) != hipSuccess) {
         set_err(ctx, FADEHIP_E_HIP, "hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(FADEHIP_E_HIP);
     }
-    static_assert(sizeof(uint32_t) * (2 * NUM_LISTS + 2) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
+    static_assert(sizeof(uint32_t) * (2 * NUM_LISTS + 3) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
     static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
     static_assert(sizeof(uint32_t) * (NUM_BUCKETS + 1) <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
+    static_assert(sizeof(PlanOut) <= 128, "PlanOut overflows its slice");
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_gate, Slot::ZB_GATE_BYTES) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_sel, sizeof(uint32_t) * (NUM_BUCKETS + 1)) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_stats, sizeof(unsigned long long) * 8 * STAT_PARTS) != hipSuccess) {
+            hipHostMalloc((void **)&s.h_zb, Slot::ZB_BYTES) != hipSuccess) {
             set_err(ctx, FADEHIP_E_HIP, "stream / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(FADEHIP_E_HIP);
         }
-        s.h_counters64 = (unsigned long long *)(s.h_gate + Slot::ZB_C64);
-        s.h_counters = (uint32_t *)(s.h_gate + Slot::ZB_COUNTERS);
+        memset(s.h_zb, 0, Slot::ZB_BYTES);
     }
     *out = ctx;
     return 0;
@@ -672,24 +1032,22 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
-        for (DevBuf *b : {&s.tid, &s.pos, &s.lseq, &s.flag, &s.has_sa, &s.cigar_off, &s.cigar_ops, &s.seq_off, &s.seq,
-                          &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.incomplete})
-            release(*b);
-        release(s.lrows);
+        for (DevBuf *b : {&s.in, &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.incomplete, &s.p2tab, &s.lrows}) release(*b);
         for (int c = 0; c < NUM_LISTS; c++) {
             release(s.work[c]);
             release(s.meta[c]);
         }
+        release(s.stage);
+        release(s.res);
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
-        if (s.h_gate) (void)hipHostFree(s.h_gate);
-        if (s.h_sel) (void)hipHostFree(s.h_sel);
-        if (s.h_stats) (void)hipHostFree(s.h_stats);
+        if (s.h_zb) (void)hipHostFree(s.h_zb);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     release(ctx->genome);
     for (DevBuf *b : {&ctx->l1_q, &ctx->l1_r, &ctx->l1_qn, &ctx->l1_rn, &ctx->l1_bad, &ctx->l1_work, &ctx->l1_aln}) release(*b);
     release(ctx->contig_len);
     release(ctx->contig_base);
+    if (g_err_ctx == ctx) g_err_ctx = nullptr;
     delete ctx;
 }
 
@@ -706,6 +1064,31 @@ int fadehip_host_free(fadehip_ctx *ctx, void *p) {
     return 0;
 }
 
+size_t fadehip_batch_bytes(int32_t n_reads, int64_t n_cigar_ops, int64_t n_seq_bytes) {
+    if (n_reads < 0 || n_cigar_ops < 0 || n_seq_bytes < 0) return 0;
+    return batch_layout(n_reads, n_cigar_ops, n_seq_bytes).total;
+}
+
+int fadehip_batch_bind(void *base, int32_t n_reads, int64_t n_cigar_ops, int64_t n_seq_bytes, fadehip_read_batch *b) {
+    if (!base || !b || n_reads < 0 || n_cigar_ops < 0 || n_seq_bytes < 0) return set_err(nullptr, FADEHIP_E_INVALID, "bad batch_bind arguments");
+    if ((uintptr_t)base & 255u) return set_err(nullptr, FADEHIP_E_INVALID, "a batch block must be 256-byte aligned (fadehip_host_alloc memory is)");
+    const Layout L = batch_layout(n_reads, n_cigar_ops, n_seq_bytes);
+    uint8_t *p = (uint8_t *)base;
+    b->n_reads = n_reads;
+    b->tid = (const int32_t *)(p + L.off[A_TID]);
+    b->pos = (const int32_t *)(p + L.off[A_POS]);
+    b->l_seq = (const int32_t *)(p + L.off[A_LSEQ]);
+    b->cigar_off = (const uint32_t *)(p + L.off[A_CIGOFF]);
+    b->seq_off = (const uint32_t *)(p + L.off[A_SEQOFF]);
+    b->flag = (const uint16_t *)(p + L.off[A_FLAG]);
+    b->has_sa = (const uint8_t *)(p + L.off[A_SA]);
+    b->cigar_ops = (const uint32_t *)(p + L.off[A_CIG]);
+    b->seq_packed = (const uint8_t *)(p + L.off[A_SEQ]);
+    b->n_skipped = 0;
+    b->ref_span_bound = 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------- level 1
 int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_t *q_off, const uint8_t *r,
                      const int64_t *r_off, fadehip_sw_result *out) {
@@ -714,6 +1097,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
     if (n == 0) return 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Slot &s = ctx->slots[0];
+    if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));
     const int64_t q_total = q_off[n], r_total = r_off[n];
     // class-partitioned work lists, built on the host from the offsets (no sequence is touched here)
     std::vector<Work> lists[NUM_LISTS];
@@ -744,62 +1128,81 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
     DevBuf &d_q = ctx->l1_q, &d_r = ctx->l1_r, &d_qn = ctx->l1_qn, &d_rn = ctx->l1_rn, &d_bad = ctx->l1_bad,
            &d_work = ctx->l1_work, &d_aln = ctx->l1_aln;
     int rc = 0;
-    auto cleanup = [&]() {};  // the buffers stay with the ctx (hipMalloc / hipFree per call cost more than small batches)
-#define L1CHK(call)                                                                                        \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess) {                                                                            \
-            cleanup();                                                                                     \
-            return set_err(ctx, FADEHIP_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));            \
-        }                                                                                                  \
-    } while (0)
     hipStream_t st = s.stream;
+    size_t n_work = 0;
+    for (int c = 0; c < NUM_LISTS; c++) n_work += lists[c].size();
     if ((rc = reserve(ctx, d_q, (size_t)q_total + 2)) || (rc = reserve(ctx, d_r, (size_t)r_total + 2)) ||
         (rc = reserve(ctx, d_qn, (size_t)q_total / 2 + 8)) || (rc = reserve(ctx, d_rn, (size_t)r_total / 2 + 8)) ||
-        (rc = reserve(ctx, d_bad, 4)) || (rc = reserve(ctx, d_aln, (size_t)n * sizeof(fadehip_aln)))) {
-        cleanup();
+        (rc = reserve(ctx, d_bad, 4)) || (rc = reserve(ctx, d_aln, (size_t)n * sizeof(fadehip_aln))) ||
+        (rc = reserve(ctx, d_work, std::max<size_t>(1, n_work) * sizeof(Work))) || (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)))
         return rc;
-    }
-    L1CHK(hipMemcpyAsync(d_q.p, q, (size_t)q_total, hipMemcpyHostToDevice, st));
-    L1CHK(hipMemcpyAsync(d_r.p, r, (size_t)r_total, hipMemcpyHostToDevice, st));
-    L1CHK(hipMemsetAsync(d_bad.p, 0, 4, st));
+    HIPCHK(ctx, hipMemcpyAsync(d_q.p, q, (size_t)q_total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(d_r.p, r, (size_t)r_total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(d_bad.p, 0, 4, st));
     if (q_total > 0)
         hipLaunchKernelGGL(pack_ascii_kernel, dim3((unsigned)((q_total / 2 + 256) / 256)), dim3(256), 0, st,
                            (const uint8_t *)d_q.p, (uint64_t)q_total, (uint64_t)0, (uint8_t *)d_qn.p, 0, (int *)d_bad.p);
     if (r_total > 0)
         hipLaunchKernelGGL(pack_ascii_kernel, dim3((unsigned)((r_total / 2 + 256) / 256)), dim3(256), 0, st,
                            (const uint8_t *)d_r.p, (uint64_t)r_total, (uint64_t)0, (uint8_t *)d_rn.p, 0, (int *)d_bad.p);
-    L1CHK(hipGetLastError());
-    size_t n_work = 0;
-    for (int c = 0; c < NUM_LISTS; c++) n_work += lists[c].size();
-    if ((rc = reserve(ctx, d_work, std::max<size_t>(1, n_work) * sizeof(Work)))) {
-        cleanup();
-        return rc;
+    HIPCHK(ctx, hipGetLastError());
+    {
+        size_t base = 0;
+        for (int c = 0; c < NUM_LISTS; c++) {
+            if (lists[c].empty()) continue;
+            HIPCHK(ctx, hipMemcpyAsync((Work *)d_work.p + base, lists[c].data(), lists[c].size() * sizeof(Work), hipMemcpyHostToDevice, st));
+            base += lists[c].size();
+        }
     }
     const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)4 << 30);
-    size_t base = 0;
-    s.fwd_spans.clear();
-    s.tb_spans.clear();
-    for (int c = 0; c < NUM_LISTS; c++) {
-        if (lists[c].empty()) continue;
-        Work *dw = (Work *)d_work.p + base;
-        L1CHK(hipMemcpyAsync(dw, lists[c].data(), lists[c].size() * sizeof(Work), hipMemcpyHostToDevice, st));
-        if (c == LONG_LIST)
-            rc = run_long(ctx, s, st, dw, nullptr, (int)lists[c].size(), max_lr[c], max_long_lq, (const uint8_t *)d_qn.p,
-                          (const uint8_t *)d_rn.p, (fadehip_aln *)d_aln.p + base, nullptr, 0, 0, budget, false);
-        else
-            rc = run_class(ctx, s, st, c, dw, nullptr, (int)lists[c].size(), max_lr[c], (const uint8_t *)d_qn.p,
-                           (const uint8_t *)d_rn.p, (fadehip_aln *)d_aln.p + base, nullptr, 0, 0, budget, false);
-        if (rc) {
-            (void)hipStreamSynchronize(st);
-            cleanup();
-            return rc;
+    for (int attempt = 0;; attempt++) {
+        size_t base = 0;
+        s.fwd_spans.clear();
+        s.tb_spans.clear();
+        s.tickets_used = 0;
+        HIPCHK(ctx, hipMemsetAsync(s.zblock.p, 0, Slot::ZB_BYTES, st));
+        for (int c = 0; c < NUM_CLASSES; c++) s.sel_fresh[c] = true;
+        for (int c = 0; c < NUM_LISTS; c++) {
+            if (lists[c].empty()) continue;
+            // the lists come from the host here: their counts go where the gate leaves them at level 2
+            hipLaunchKernelGGL(set_counts_kernel, dim3(1), dim3(1), 0, st, s.d_counters() + c, (uint32_t)lists[c].size());
+            HIPCHK(ctx, hipGetLastError());
+            ClassRun cr;
+            cr.cls = c;
+            cr.work = (const Work *)d_work.p + base;
+            cr.meta = nullptr;
+            cr.n_bound = (int)lists[c].size();
+            cr.count_dev = s.d_counters() + c;
+            cr.max_lr = max_lr[c];
+            cr.q_nib = (const uint8_t *)d_qn.p;
+            cr.r_nib = (const uint8_t *)d_rn.p;
+            cr.out = (fadehip_aln *)d_aln.p + base;
+            cr.rs = nullptr;
+            cr.floor_len = 0;
+            cr.gate = 0;
+            cr.budget = budget;
+            cr.timed = false;
+            if (c == LONG_LIST) rc = run_long(ctx, s, st, cr, max_long_lq);
+            else rc = ctx->two_pass ? run_class_two_pass(ctx, s, st, cr) : run_class_single(ctx, s, st, cr);
+            if (rc) {
+                (void)hipStreamSynchronize(st);
+                return rc;
+            }
+            base += lists[c].size();
         }
-        base += lists[c].size();
+        HIPCHK(ctx, hipMemcpyAsync(s.h_zb, s.zblock.p, Slot::ZB_BYTES, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const PlanOut *po = s.h_plan();
+        if (po->bound_violated) return set_err(ctx, FADEHIP_E_STATE, "internal: a pass-2 plan outgrew the bound its launches were sized from");
+        if (!po->overflow) break;
+        if (attempt >= 4) return set_err(ctx, FADEHIP_E_NOMEM, "pass-2 trace scratch still too small after %d re-runs", attempt);
+        const size_t need = (size_t)po->need_dwords * 4;
+        if (ctx->debug) fprintf(stderr, "[fadehip] sw_batch: trace scratch %zu B too small, %zu B needed: batch re-run\n", s.trace.cap, need);
+        if ((rc = reserve(ctx, s.trace, need + need / 4))) return rc;
     }
+    s.state = 0;  // slot 0's level-2 buffers were borrowed
     std::vector<fadehip_aln> h_aln(n_work);
-    if (n_work) L1CHK(hipMemcpyAsync(h_aln.data(), d_aln.p, n_work * sizeof(fadehip_aln), hipMemcpyDeviceToHost, st));
-    L1CHK(hipStreamSynchronize(st));
+    if (n_work) HIPCHK(ctx, hipMemcpy(h_aln.data(), d_aln.p, n_work * sizeof(fadehip_aln), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < n_work; k++) out[h_aln[k].read_idx] = h_aln[k].sw;
     // empty query or reference: nothing to align (no DP): all of the query is soft-clipped
     for (int k : degenerate) {
@@ -807,14 +1210,12 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         memset(&o, 0, sizeof o);
         o.end_query = o.end_ref = -1;
         const int64_t lq = q_off[k + 1] - q_off[k];
-        if (lq > 0) {
+        if (lq > 0 && (ctx->sc.rules & FADEHIP_RULE_PAD_SOFTCLIP)) {
             o.n_ops = 1;
             o.ops[0] = ((uint32_t)lq << 4) | 4u;
         }
         out[k] = o;
     }
-    cleanup();
-#undef L1CHK
     return 0;
 }
 
@@ -871,57 +1272,67 @@ int fadehip_genome_upload(fadehip_ctx *ctx, int32_t n_contigs, const int64_t *le
 int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch *b) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
-    if (!b || b->n_reads < 0) return set_err(ctx, FADEHIP_E_INVALID, "bad batch");
+    if (!b || b->n_reads < 0 || b->n_skipped < 0 || b->ref_span_bound < 0) return set_err(ctx, FADEHIP_E_INVALID, "bad batch");
     if (b->n_reads > ctx->prm.max_batch_reads)
         return set_err(ctx, FADEHIP_E_INVALID, "batch of %d reads exceeds max_batch_reads %d", b->n_reads, ctx->prm.max_batch_reads);
     if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Slot &s = ctx->slots[slot];
+    if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));  // results never fetched: the slot's buffers are still in use
     const int n = b->n_reads;
     s.n_reads = n;
+    s.n_skipped = b->n_skipped;
     s.state = 0;
     if (n == 0) { s.state = 1; return 0; }
     if (!b->tid || !b->pos || !b->flag || !b->has_sa || !b->l_seq || !b->cigar_off || !b->seq_off ||
         (b->cigar_off[n] && !b->cigar_ops) || (b->seq_off[n] && !b->seq_packed))
         return set_err(ctx, FADEHIP_E_INVALID, "batch has NULL arrays");
     const size_t n_cig = b->cigar_off[n], n_seq = b->seq_off[n];
-    // the kernels index with these: offsets must be non-decreasing, lengths non-negative (one pass, ~1 ms per million)
-    for (int i = 0; i < n; i++) {
-        if (b->cigar_off[i] > b->cigar_off[i + 1] || b->seq_off[i] > b->seq_off[i + 1] || b->l_seq[i] < 0)
-            return set_err(ctx, FADEHIP_E_INVALID, "record %d: cigar_off / seq_off must be non-decreasing and l_seq >= 0", i);
-    }
     if ((uint64_t)n_seq * 2 >= ((uint64_t)1 << 32)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "packed sequence bytes per batch must stay below 2^31");
-    // classes present decide which work lists exist
-    bool present[NUM_LISTS] = {false};
+    // One pass over the records: the kernels index with these offsets (they must be non-decreasing and end where the
+    // arrays end, lengths non-negative), and the launches of the run are sized from the read-length histogram.  Without
+    // the caller's ref_span_bound the CIGARs are scanned too (then only records that pass anno.d:61 count).
+    const bool scan = b->ref_span_bound <= 0;
+    uint32_t hist[NUM_LISTS] = {0};
+    int max_lq = 0;
+    int64_t span = b->ref_span_bound;
+    uint8_t cls_of[33];  // class of a read of 16 k - 15 .. 16 k bases
+    for (int k = 0; k <= 32; k++) cls_of[k] = (uint8_t)list_of_len(std::max(16 * k, 1));
     for (int i = 0; i < n; i++) {
-        const int c = list_of_len(b->l_seq[i] > 0 ? b->l_seq[i] : 1);
-        if (c >= 0) present[c] = true;
+        const uint32_t c0 = b->cigar_off[i], c1 = b->cigar_off[i + 1];
+        const int lq = b->l_seq[i];
+        if (c0 > c1 || c1 > n_cig || b->seq_off[i] > b->seq_off[i + 1] || b->seq_off[i + 1] > n_seq || lq < 0)
+            return set_err(ctx, FADEHIP_E_INVALID, "record %d: cigar_off / seq_off must be non-decreasing and l_seq >= 0", i);
+        if (scan) {
+            if (b->flag[i] & 4u) continue;
+            const CigarSummary cs = summarize_cigar(b->cigar_ops, c0, c1);
+            if (cs.n_soft == 0) continue;
+            span = std::max(span, cs.aligned);
+        }
+        const int c = lq > 512 ? (lq <= MAX_LONG_QUERY ? LONG_LIST : -1) : (int)cls_of[(std::max(lq, 1) + 15) >> 4];
+        if (c >= 0) hist[c]++;
+        max_lq = std::max(max_lq, std::min(lq, MAX_LONG_QUERY));
     }
-    // windows beyond WAVE_MAX_WINDOW send any read to the long list; they only exist with a large --window-size
-    present[LONG_LIST] = present[LONG_LIST] || ctx->prm.max_ref_len > WAVE_MAX_WINDOW;
-    if ((rc = reserve(ctx, s.tid, 4 * (size_t)n)) || (rc = reserve(ctx, s.pos, 4 * (size_t)n)) ||
-        (rc = reserve(ctx, s.lseq, 4 * (size_t)n)) || (rc = reserve(ctx, s.flag, 2 * (size_t)n)) ||
-        (rc = reserve(ctx, s.has_sa, (size_t)n)) || (rc = reserve(ctx, s.cigar_off, 4 * ((size_t)n + 1))) ||
-        (rc = reserve(ctx, s.seq_off, 4 * ((size_t)n + 1))) || (rc = reserve(ctx, s.cigar_ops, 4 * n_cig + 4)) ||
-        (rc = reserve(ctx, s.seq, n_seq + 8)) || (rc = reserve(ctx, s.rs, (size_t)n)) ||
-        (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)n)) ||
-        (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)))
-        return rc;
-    for (int c = 0; c < NUM_LISTS; c++) {
-        if (!present[c]) continue;
-        if ((rc = reserve(ctx, s.work[c], sizeof(Work) * (size_t)n)) || (rc = reserve(ctx, s.meta[c], sizeof(Meta) * (size_t)n)))
-            return rc;
+    memcpy(s.hist, hist, sizeof hist);
+    s.max_lq = max_lq;
+    s.span_bound = span;
+    const Layout L = batch_layout(n, (int64_t)n_cig, (int64_t)n_seq);
+    const void *src[N_ARR] = {b->tid, b->pos, b->l_seq, b->cigar_off, b->seq_off, b->flag, b->has_sa, b->cigar_ops, b->seq_packed};
+    const uint8_t *base = (const uint8_t *)b->tid;
+    bool direct = ((uintptr_t)base & 255u) == 0;
+    for (int k = 0; k < N_ARR && direct; k++)
+        if (L.bytes[k] && (const uint8_t *)src[k] != base + L.off[k]) direct = false;
+    if ((rc = reserve(ctx, s.in, L.total))) return rc;
+    if (!direct) {
+        // arrays from anywhere: gather them into the slot's pinned staging block (one host copy) for the one DMA
+        if ((rc = reserve_pinned(ctx, s.stage, L.total))) return rc;
+        for (int k = 0; k < N_ARR; k++)
+            if (L.bytes[k]) memcpy(s.stage.p + L.off[k], src[k], L.bytes[k]);
+        base = s.stage.p;
     }
-    hipStream_t st = s.stream;
-    HIPCHK(ctx, hipMemcpyAsync(s.tid.p, b->tid, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.pos.p, b->pos, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.lseq.p, b->l_seq, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.flag.p, b->flag, 2 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.has_sa.p, b->has_sa, (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.cigar_off.p, b->cigar_off, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.seq_off.p, b->seq_off, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, st));
-    if (n_cig) HIPCHK(ctx, hipMemcpyAsync(s.cigar_ops.p, b->cigar_ops, 4 * n_cig, hipMemcpyHostToDevice, st));
-    if (n_seq) HIPCHK(ctx, hipMemcpyAsync(s.seq.p, b->seq_packed, n_seq, hipMemcpyHostToDevice, st));
+    s.L = L;
+    s.h_base = base;
+    HIPCHK(ctx, hipMemcpyAsync(s.in.p, base, L.off[N_ARR - 1] + L.bytes[N_ARR - 1], hipMemcpyHostToDevice, s.stream));
     s.state = 1;
     return 0;
 }
@@ -933,89 +1344,22 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     if (s.state < 1) return set_err(ctx, FADEHIP_E_STATE, "slot %d has no uploaded batch", slot);
     if (window < 0) return set_err(ctx, FADEHIP_E_INVALID, "window must be >= 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = s.stream;
-    const int n = s.n_reads;
-    s.ev_used = 0;
-    s.fwd_spans.clear();
-    s.tb_spans.clear();
-    s.n_aln = 0;
-    s.n_fwd_launches = 0;
-    s.n_cand = 0;
-    s.n_rerun = 0;
-    memset(s.prof_counts, 0, sizeof s.prof_counts);
-    if (n == 0) {
-        memset(s.h_stats, 0, sizeof(unsigned long long) * 8 * STAT_PARTS);
+    if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    s.floor_len = floor_len;
+    s.window = window;
+    s.n_reruns_of_batch = 0;
+    if (s.n_reads == 0) {
         s.ev_gate0 = s.ev_gate1 = s.ev_end = -1;
+        memset(s.prof_counts, 0, sizeof s.prof_counts);
         s.state = 2;
         return 0;
     }
-    HIPCHK(ctx, hipMemsetAsync(s.zblock.p, 0, Slot::ZB_BYTES, st));  // every counter of the run in one fill
-    for (int c = 0; c < NUM_CLASSES; c++) s.sel_fresh[c] = true;
-    if ((rc = record(ctx, s, &s.ev_gate0))) return rc;
-    GateArgs g;
-    g.n_reads = n;
-    g.tid = (const int32_t *)s.tid.p;
-    g.pos = (const int32_t *)s.pos.p;
-    g.l_seq = (const int32_t *)s.lseq.p;
-    g.flag = (const uint16_t *)s.flag.p;
-    g.has_sa = (const uint8_t *)s.has_sa.p;
-    g.cigar_off = (const uint32_t *)s.cigar_off.p;
-    g.cigar_ops = (const uint32_t *)s.cigar_ops.p;
-    g.seq_off = (const uint32_t *)s.seq_off.p;
-    g.floor_len = floor_len;
-    g.window = window;
-    g.n_contigs = ctx->n_contigs;
-    g.contig_len = (const int64_t *)ctx->contig_len.p;
-    g.contig_base = (const uint64_t *)ctx->contig_base.p;
-    g.max_ref_len = ctx->prm.max_ref_len;
-    g.rs = (uint8_t *)s.rs.p;
-    for (int c = 0; c < NUM_LISTS; c++) {
-        g.work[c] = (Work *)s.work[c].p;
-        g.meta[c] = (Meta *)s.meta[c].p;
-    }
-    g.stats = s.d_stats();
-    g.counters = s.d_counters();
-    g.counters64 = s.d_counters64();
-    hipLaunchKernelGGL(gate_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, g);
-    HIPCHK(ctx, hipGetLastError());
-    if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(s.h_gate, s.zblock.p, Slot::ZB_GATE_BYTES, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    const uint32_t errbits = s.h_counters[2 * NUM_LISTS];
-    if (errbits) {
+    if ((rc = plan_run(ctx, s))) return rc;
+    if ((rc = enqueue_run(ctx, s))) {
+        (void)hipStreamSynchronize(s.stream);
         s.state = 1;
-        if (errbits & 2u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a soft-clipped read longer than %d bases", FADEHIP_MAX_LONG_QUERY);
-        if (errbits & 4u) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "batch has a re-alignment window longer than max_ref_len=%d", ctx->prm.max_ref_len);
-        if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
-        return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
+        return rc;
     }
-    const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)16 << 30);
-    int base = 0;
-    for (int c = 0; c < NUM_CLASSES; c++) {
-        const int cnt = (int)s.h_counters[c];
-        if (!cnt) continue;
-        rc = run_class(ctx, s, st, c, (const Work *)s.work[c].p, (const Meta *)s.meta[c].p, cnt,
-                       (int)s.h_counters[NUM_LISTS + c], (const uint8_t *)s.seq.p, (const uint8_t *)ctx->genome.p,
-                       (fadehip_aln *)s.aln.p + base, (uint8_t *)s.rs.p, floor_len, 1, budget, true);
-        if (rc) return rc;
-        base += cnt;
-    }
-    if (const int cnt = (int)s.h_counters[LONG_LIST]) {
-        rc = run_long(ctx, s, st, (const Work *)s.work[LONG_LIST].p, (const Meta *)s.meta[LONG_LIST].p, cnt,
-                      (int)s.h_counters[NUM_LISTS + LONG_LIST], (int)s.h_counters[2 * NUM_LISTS + 1], (const uint8_t *)s.seq.p,
-                      (const uint8_t *)ctx->genome.p, (fadehip_aln *)s.aln.p + base, (uint8_t *)s.rs.p, floor_len, 1, budget, true);
-        if (rc) return rc;
-        base += cnt;
-    }
-    s.n_aln = base;
-    if ((rc = record(ctx, s, &s.ev_end))) return rc;
-    s.prof_counts[0] = base;
-    s.prof_counts[1] = (int64_t)s.h_counters64[0 * C64_STRIDE];
-    // algorithmic bytes of the forward kernel: packed query + packed window +
-    // 16 B descriptor + 64 B result slot + 4-bit trace cell
-    // two-pass: the dominant kernel (pass 1) writes H/E checkpoints instead of the trace
-    s.prof_counts[3] = (int64_t)s.h_counters64[1 * C64_STRIDE] + (int64_t)base * 80 +
-                       (ctx->two_pass ? (int64_t)s.h_counters64[2 * C64_STRIDE] : (int64_t)(s.h_counters64[0 * C64_STRIDE] / 2));
     s.state = 2;
     return 0;
 }
@@ -1026,28 +1370,43 @@ int fadehip_annotate_submit(fadehip_ctx *ctx, int slot, const fadehip_read_batch
     return fadehip_annotate_run(ctx, slot, floor_len, window);
 }
 
+int fadehip_annotate_results(fadehip_ctx *ctx, int slot, fadehip_anno_view *out) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!out) return set_err(ctx, FADEHIP_E_INVALID, "out is NULL");
+    Slot &s = ctx->slots[slot];
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = finish_run(ctx, s, slot))) return rc;
+    out->rs = s.n_reads ? s.res.p : nullptr;
+    out->aln = s.n_aln ? (const fadehip_aln *)(s.res.p + s.res_aln_off) : nullptr;
+    out->n_reads = s.n_reads;
+    out->n_aln = s.n_aln;
+    memcpy(out->stats, s.stats, sizeof out->stats);
+    out->n_oversize = s.n_oversize;
+    out->reserved = 0;
+    return 0;
+}
+
 int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
-    Slot &s = ctx->slots[slot];
-    if (s.state != 2) return set_err(ctx, FADEHIP_E_STATE, "slot %d has not been run", slot);
     if (!out) return set_err(ctx, FADEHIP_E_INVALID, "out is NULL");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = s.stream;
-    const int n = s.n_reads;
+    Slot &s = ctx->slots[slot];
+    if (s.state < 2) return set_err(ctx, FADEHIP_E_STATE, "slot %d has not been run", slot);
     out->n_aln = 0;
+    out->n_oversize = 0;
+    out->reserved = 0;
     memset(out->stats, 0, sizeof out->stats);
-    if (n == 0) return 0;
-    if (!out->rs) return set_err(ctx, FADEHIP_E_INVALID, "out->rs is NULL");
+    if (s.n_reads > 0 && !out->rs) return set_err(ctx, FADEHIP_E_INVALID, "out->rs is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = finish_run(ctx, s, slot))) return rc;
     if (s.n_aln > 0 && (!out->aln || out->aln_cap < s.n_aln))
         return set_err(ctx, FADEHIP_E_INVALID, "out->aln holds %d entries, %d needed", out->aln ? out->aln_cap : 0, s.n_aln);
-    HIPCHK(ctx, hipMemcpyAsync(out->rs, s.rs.p, (size_t)n, hipMemcpyDeviceToHost, st));
-    if (s.n_aln) HIPCHK(ctx, hipMemcpyAsync(out->aln, s.aln.p, sizeof(fadehip_aln) * (size_t)s.n_aln, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(s.h_stats, s.d_stats(), sizeof(unsigned long long) * 8 * STAT_PARTS, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (s.n_reads) memcpy(out->rs, s.res.p, (size_t)s.n_reads);
+    if (s.n_aln) memcpy(out->aln, s.res.p + s.res_aln_off, sizeof(fadehip_aln) * (size_t)s.n_aln);
     out->n_aln = s.n_aln;
-    for (int k = 0; k < 8; k++)
-        for (int q = 0; q < STAT_PARTS; q++) out->stats[k] += (int64_t)s.h_stats[8 * q + k];
+    out->n_oversize = s.n_oversize;
+    memcpy(out->stats, s.stats, sizeof out->stats);
     return 0;
 }
 
@@ -1062,7 +1421,7 @@ int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t co
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
-    if (s.state != 2) return set_err(ctx, FADEHIP_E_STATE, "slot %d has not been run", slot);
+    if (s.state != 3) return set_err(ctx, FADEHIP_E_STATE, "slot %d has no collected run", slot);
     if (!ms || !counts) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
     ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
     for (int k = 0; k < 4; k++) counts[k] = s.prof_counts[k];

@@ -107,7 +107,9 @@ __host__ __device__ inline int list_of_len(int lq, int64_t lr = 0) {
 struct ScoreTab {
     uint32_t prof[8];  // prof[q class] : 8 x 4-bit entries (W + open) indexed by ref class*4
     int32_t open, ext, match, mismatch;
+    uint32_t rules;    // FADEHIP_RULE_* (include/fadehip.h): the assumptions about libparasail that could not be checked
 };
+__host__ __device__ inline bool rule(uint32_t rules, uint32_t bit) { return (rules & bit) != 0; }
 
 // ---------------------------------------------------------------- ASCII -> packed 4-bit
 __constant__ uint8_t c_ascii_code[256];
@@ -152,10 +154,13 @@ struct GateArgs {
     const int64_t *contig_len;
     const uint64_t *contig_base;  // first base of each contig in the packed genome
     int32_t max_ref_len;
+    int32_t wave_lr_bound;       // longest window the wave kernels' launches were sized for (LDS, snapshots): the host's bound
+    int32_t long_lr_bound, long_lq_bound;  // the same for the long list's row and trace buffers
+    uint32_t list_cap[NUM_LISTS];  // entries reserved per work list (from the host's count of the batch's read lengths)
     uint8_t *rs;
     Work *work[NUM_LISTS];
     Meta *meta[NUM_LISTS];
-    uint32_t *counters;  // NL = NUM_LISTS: [0..NL) item counts, [NL..2NL) max lr, [2NL] error bits, [2NL+1] max lq of the long list
+    uint32_t *counters;  // NL = NUM_LISTS: [0..NL) item counts, [NL..2NL) max lr, [2NL] error bits, [2NL+1] max lq of the long list, [2NL+2] oversize reads
     unsigned long long *counters64;  // [k * C64_STRIDE]: k = 0 DP cells, 1 packed sequence bytes read (query + window), 2 checkpoint bytes
     unsigned long long *stats;       // stats.d:45-54: [0] read_count, [1] clipped, [2] sup (the artifact counters come from traceback_kernel)
 };
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // per-thread contribution to the batch counters; reduced per wave before touching memory
     unsigned long long cells = 0, seq_bytes = 0, ck_bytes = 0;
-    uint32_t lr_for_max = 0, errbits = 0, st_bits = 0;
+    uint32_t lr_for_max = 0, errbits = 0, st_bits = 0, oversize = 0;
     int cls = -1;
     Work w;
     Meta m;
@@ -217,8 +222,13 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
             const int64_t lr = end - start;
             if (lr > 0) {
                 cls = list_of_len(lq, lr);
-                if (cls < 0) errbits |= 2u;  // read longer than MAX_LONG_QUERY
-                else if (lr > a.max_ref_len) { errbits |= 4u; cls = -1; }  // window longer than max_ref_len
+                // a read or window beyond the kernels' limits is left un-re-aligned (its rs keeps the sc / sup bits) and counted
+                if (cls < 0) oversize = 1u;  // read longer than MAX_LONG_QUERY
+                else if (lr > a.max_ref_len) { oversize = 1u; cls = -1; }  // window longer than max_ref_len
+                else if (cls != LONG_LIST ? lr > a.wave_lr_bound : (lr > a.long_lr_bound || lq > a.long_lq_bound)) {
+                    errbits |= 16u;  // the caller's ref_span_bound was too small
+                    cls = -1;
+                }
                 else {
                     cells = (unsigned long long)lq * (unsigned long long)lr;
                     seq_bytes = (unsigned long long)((lq + 1) / 2 + (lr + 1) / 2);
@@ -270,6 +280,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         }
     }
     if (errbits) atomicOr(&s_err, errbits);
+    if (oversize) atomicAdd(&a.counters[2 * NUM_LISTS + 2], 1u);  // rare by construction
     {
         // stats.d:45-54, the part known here: reads, clipped, supplementary — one LDS add per wave and counter
         const unsigned long long m_read = __ballot(st_bits & 4u), m_sc = __ballot(st_bits & 1u), m_sup = __ballot(st_bits & 2u);
@@ -312,8 +323,10 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     __syncthreads();
     if (cls >= 0) {
         const uint32_t slot = s_base[cls] + s_rank[compact];
-        a.work[cls][slot] = w;
-        a.meta[cls][slot] = m;
+        if (slot < a.list_cap[cls]) {
+            a.work[cls][slot] = w;
+            a.meta[cls][slot] = m;
+        } else atomicOr(&a.counters[2 * NUM_LISTS], 32u);  // more items than the host's bound: never written, reported at collect
     }
 }
 
@@ -347,7 +360,12 @@ struct SwArgs {
     uint32_t *ckpt;         // [pass-1 octet][checkpoint][H rows | E rows][64 lanes]
     uint64_t ck_stride;     // dwords per pass-1 octet
     int32_t n_ck;           // checkpoints per octet
-    P2Table tab;            // MODE 2
+    // Launches are sized on the host from upper bounds; what the gate and the selection actually produced stays on
+    // the device (fadehip_annotate_run never reads a counter back):
+    const uint32_t *count_dev;  // MODE 0 / 1: items in the class list (this launch covers [item_base, item_base + n_items) of them); nullptr = n_items is exact
+    uint32_t item_base;
+    const P2Table *tab_dev;     // MODE 2: built by plan_kernel from the selection's bucket counts
+    uint32_t *ticket;           // MODE 2: the waves of the launch draw octets from this counter until the table is exhausted
 };
 
 #define DPP_ROW_SHR1 0x111
@@ -569,6 +587,8 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 // MODE 1: pass 1 — score and end cell only, plus a snapshot of the wave state every CK_COLS steps
 // MODE 2: pass 2 — traced re-computation of sweep steps [T0, end_ref + lane(end_query)] of a candidate,
 //         resumed from the snapshot taken after step T0-1; no end-cell tracking
+// MODE 3: MODE 2 with the A.4 rule switches read at run time (FADEHIP_RULE_HDIR_DIAG_F_E, _GAP_TIE_EXTENDS off):
+//         a few more instructions per cell, used only when a rule differs from the default
 // waves per SIMD asked of the register allocator for the score pass (the other modes are left alone)
 __host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return (MODE == 1 && R <= 10) ? 4 : 1; }
 
@@ -577,7 +597,46 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x;
     const int g = lane >> 4, lig = lane & 15;
-    const int oct = blockIdx.x;
+    // ---- score table in LDS, indexed by the PAIR of column classes (cA, cB) of a lane's two alignments: entry
+    // (7 cA + cB) = 16 bytes {rowA.lo, rowB.lo, rowA.hi, rowB.hi}, row c = 8 bytes, byte q = 8 * W'(query class q,
+    // column class c).  The class word that travels along the lanes IS the entry's byte offset, so a step costs one
+    // LDS read and no address arithmetic; every row then picks its bytes with v_perm_b32 (selector = query class).
+    __shared__ uint4 wtab[49];
+    if (lane < 49) {
+        const int cA = lane / 7, cB = lane - 7 * cA;
+        uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            alo |= (((a.sc.prof[q] >> (4 * cA)) & 15u) * PK_SCALE) << (8 * q);
+            blo |= (((a.sc.prof[q] >> (4 * cB)) & 15u) * PK_SCALE) << (8 * q);
+        }
+#pragma unroll
+        for (int q = 4; q < 7; q++) {
+            ahi |= (((a.sc.prof[q] >> (4 * cA)) & 15u) * PK_SCALE) << (8 * (q - 4));
+            bhi |= (((a.sc.prof[q] >> (4 * cB)) & 15u) * PK_SCALE) << (8 * (q - 4));
+        }
+        wtab[lane] = make_uint4(alo, blo, ahi, bhi);
+    }
+    // items of this launch: the host's bound, clamped by what the gate put on the list
+    int n_items = a.n_items;
+    constexpr bool P2 = (MODE >= 2);
+    if constexpr (!P2) {
+        if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
+    }
+    // MODE 2 is a persistent launch: its size comes from an upper bound, the number of octets from the device-side
+    // table, so every wave draws octets from a ticket counter until the table is exhausted (an exit every wave reaches).
+    // MODE 0 / 1: one octet per wave, blockIdx.x.
+    for (bool first_round = true;; first_round = false) {
+    int oct = blockIdx.x;
+    if constexpr (P2) {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(a.ticket, 1u);
+        oct = (int)__builtin_amdgcn_readfirstlane(tk);
+        if (oct >= (int)a.tab_dev->oct_first[NUM_BUCKETS]) break;
+        if (!first_round) __syncthreads();  // the previous octet's window is no longer read
+    } else {
+        if (!first_round || oct * 8 >= n_items) break;
+    }
     const int itemA = oct * 8 + g * 2, itemB = itemA + 1;
     Work wa, wb;
     wa.r_base = wb.r_base = 0; wa.q_base = wb.q_base = 0; wa.lq = wb.lq = 0; wa.lr = wb.lr = 0;
@@ -585,13 +644,14 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     uint32_t srcA = 0, srcB = 0, c0A = 0, c0B = 0;
     int stepsA = 0, stepsB = 0;  // MODE 2: sweep steps to run for each half
     uint64_t trace_off = (uint64_t)oct * a.quad_stride;
-    if constexpr (MODE == 2) {
+    if constexpr (P2) {
+        const P2Table &tab = *a.tab_dev;
         int b = 0;
-        while (oct >= (int)a.tab.oct_first[b + 1]) b++;
-        const int local = oct - (int)a.tab.oct_first[b];
-        trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
-        const Cand *cl = a.cand + (uint64_t)a.tab.bucket[b] * a.tab.cap;
-        const int n_b = (int)a.tab.count[b];
+        while (oct >= (int)tab.oct_first[b + 1]) b++;
+        const int local = oct - (int)tab.oct_first[b];
+        trace_off = tab.trace_base[b] + (uint64_t)local * tab.stride[b];
+        const Cand *cl = a.cand + (uint64_t)tab.bucket[b] * tab.cap;
+        const int n_b = (int)tab.count[b];
         const int kA = local * 8 + g * 2, kB = kA + 1;
         // lane 0 feeds column T0 + tau at relative step tau: the staged "window" is columns [T0, end_ref]
         if (kA < n_b) {
@@ -613,37 +673,17 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             wb.r_base += c0B;
         }
     } else {
-        if (itemA < a.n_items) wa = a.work[itemA];
-        if (itemB < a.n_items) wb = a.work[itemB];
+        if (itemA < n_items) wa = a.work[itemA];
+        if (itemB < n_items) wb = a.work[itemB];
     }
     const int lqA = (int)wa.lq, lrA = (int)wa.lr, lqB = (int)wb.lq, lrB = (int)wb.lr;
-    int mx = (MODE == 2) ? max(stepsA, stepsB) : max(lrA, lrB) + 15;
+    int mx = P2 ? max(stepsA, stepsB) : max(lrA, lrB) + 15;
     int maxst = __builtin_amdgcn_readlane(mx, 0);
     maxst = max(maxst, __builtin_amdgcn_readlane(mx, 16));
     maxst = max(maxst, __builtin_amdgcn_readlane(mx, 32));
     maxst = max(maxst, __builtin_amdgcn_readlane(mx, 48));
     const int n_blocks = (maxst + 3) >> 2;
 
-    // ---- score table in LDS, indexed by the PAIR of column classes (cA, cB) of a lane's two alignments: entry
-    // (7 cA + cB) = 16 bytes {rowA.lo, rowB.lo, rowA.hi, rowB.hi}, row c = 8 bytes, byte q = 8 * W'(query class q,
-    // column class c).  The class word that travels along the lanes IS the entry's byte offset, so a step costs one
-    // LDS read and no address arithmetic; every row then picks its bytes with v_perm_b32 (selector = query class).
-    __shared__ uint4 wtab[49];
-    if (lane < 49) {
-        const int cA = lane / 7, cB = lane - 7 * cA;
-        uint32_t alo = 0, ahi = 0, blo = 0, bhi = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            alo |= (((a.sc.prof[q] >> (4 * cA)) & 15u) * PK_SCALE) << (8 * q);
-            blo |= (((a.sc.prof[q] >> (4 * cB)) & 15u) * PK_SCALE) << (8 * q);
-        }
-#pragma unroll
-        for (int q = 4; q < 7; q++) {
-            ahi |= (((a.sc.prof[q] >> (4 * cA)) & 15u) * PK_SCALE) << (8 * (q - 4));
-            bhi |= (((a.sc.prof[q] >> (4 * cB)) & 15u) * PK_SCALE) << (8 * (q - 4));
-        }
-        wtab[lane] = make_uint4(alo, blo, ahi, bhi);
-    }
     // ---- stage both windows: 16 bits per column = (7 classA + classB) * 16, the byte offset into wtab
     uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
     const int n_cols = n_blocks * 4;
@@ -689,7 +729,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; bestA[r] = 0; bestB[r] = 0; GT[r] = 0; }
     uint32_t hu_out = 0, fu_out = 0, hu_prev = 0;
     uint32_t rc = (7 * PAD_CLASS + PAD_CLASS) * 16;
-    if constexpr (MODE == 2) {
+    if constexpr (P2) {
         // resume: the wave state pass 1 snapshotted after step T0-1, per half from that half's own octet
         constexpr int CKD = ck_dwords(R);
         const uint32_t laneA = ((srcA >> 1) & 3u) * 16u + (uint32_t)lig, laneB = ((srcB >> 1) & 3u) * 16u + (uint32_t)lig;
@@ -730,6 +770,13 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     uint32_t *tq = a.trace + trace_off + lane;
     uint32_t *ckw = a.ckpt + (uint64_t)oct * a.ck_stride + lane;
     const uint32_t himask = __builtin_amdgcn_readfirstlane(0xffff0000u);
+    // rule switches (wave-uniform; the default path never reads them inside the sweep)
+    const bool hdir_f_first = rule(a.sc.rules, FADEHIP_RULE_HDIR_DIAG_F_E), tie_extends = rule(a.sc.rules, FADEHIP_RULE_GAP_TIE_EXTENDS);
+    const uint32_t tie_flip2 = tie_extends ? 0u : 0x00020002u, tie_flip1 = tie_extends ? 0u : 0x00010001u;
+    // A.3 with the rule off: ties go to the smallest query index, then the smallest ref index.  The per-row keys already
+    // hold each row's first column; the paired key ranks (H, even row, position) instead of (H, position, even row)
+    const bool end_min_ref = rule(a.sc.rules, FADEHIP_RULE_END_MIN_REF_THEN_QUERY);
+    (void)hdir_f_first; (void)tie_flip2; (void)tie_flip1; (void)end_min_ref;
 
     // The sweep exists twice.  FAST (no N / wildcard in either query of the octet, i.e. nearly always): the four
     // A,C,G,T bytes of the two column rows sit in one register pair, so ONE v_perm_b32 yields both halves of the
@@ -782,7 +829,8 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             }
             const uint32_t ct = (uint32_t)(0xffff - t);
             const uint32_t tk = (uint32_t)(31 - (t & 31)) * 0x10001u;  // MODE 1: position inside the 32-step window
-            const uint32_t tk_even = tk * 2u + 0x10001u, tk_odd = tk * 2u;  // PAIRKEY: ... and which row of the pair
+            // PAIRKEY: ... and which row of the pair: 2 * position + (row even), or 32 * (row even) + position
+            const uint32_t tk_even = end_min_ref ? tk * 2u + 0x10001u : tk + 0x00200020u, tk_odd = end_min_ref ? tk * 2u : tk;
             uint32_t kprev = 0;
             uint32_t hd = hu_prev;
             hu_prev = hu;
@@ -806,9 +854,18 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                 if constexpr (MODE != 1) {
                     // trace nibble: 8*(H!=D) + 4*(H!=F) + 2*(E opened) + 1*(F opened)
                     const uint32_t m1 = pk_min_k<8>(pk_sub(T, Dp));
-                    const uint32_t m2 = pk_min_k<4>(pk_sub(T, Fn));
-                    const uint32_t m3 = pk_min_k<2>(pk_sub(En, Ee));
-                    const uint32_t m4 = pk_min_k<1>(pk_sub(Fn, Fe));
+                    uint32_t m2, m3, m4;
+                    if constexpr (MODE == 3) {
+                        // A.4 switches: bit 4 says H != E when E has priority over F; with "ties open" a gap opens iff
+                        // H - open >= G - ext, i.e. unless the extension is strictly larger
+                        m2 = pk_min_k<4>(pk_sub(T, hdir_f_first ? Fn : En));
+                        m3 = pk_min_k<2>(pk_sub(En, tie_extends ? Ee : hl)) ^ tie_flip2;
+                        m4 = pk_min_k<1>(pk_sub(Fn, tie_extends ? Fe : hu)) ^ tie_flip1;
+                    } else {
+                        m2 = pk_min_k<4>(pk_sub(T, Fn));
+                        m3 = pk_min_k<2>(pk_sub(En, Ee));
+                        m4 = pk_min_k<1>(pk_sub(Fn, Fe));
+                    }
                     uint32_t &ac = acc[(r - s + R) % R];  // dword k of the block = the 4 cells (s, row (k + s) % R): a diagonal
                     ac = pk_shl4_add(ac, m1) + m2 + m3 + m4;
                 }
@@ -843,9 +900,11 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     if constexpr (MODE == 1) {
         // fold the window's keys into (GH, GT); a later window wins only with a strictly larger H (Appendix A.3)
         // PAIRKEY: GT holds 2 * t + (row odd) = (2 * (32 * window + 31) + 1) - (2 * (31 - t % 32) + (row even))
-        const uint32_t wbase = PAIRKEY ? (uint32_t)(((blk0 >> 3) * 32 + 31) * 2 + 1) * 0x10001u
+        // (a pair key under the other A.3 rule: the row bit ranks with H, GT = 64 * window + 32 * (row odd) + t % 32)
+        const uint32_t wbase = PAIRKEY ? (end_min_ref ? (uint32_t)(((blk0 >> 3) * 32 + 31) * 2 + 1) * 0x10001u
+                                                      : (uint32_t)((blk0 >> 3) * 64 + 63) * 0x10001u)
                                        : (uint32_t)((blk0 >> 3) * 32 + 31) * 0x10001u;
-        constexpr uint32_t HMASK = PAIRKEY ? 0xffc0ffc0u : 0xffe0ffe0u, PMASK = PAIRKEY ? 0x003f003fu : 0x001f001fu;
+        const uint32_t HMASK = PAIRKEY ? (end_min_ref ? 0xffc0ffc0u : 0xffe0ffe0u) : 0xffe0ffe0u, PMASK = PAIRKEY ? 0x003f003fu : 0x001f001fu;
 #pragma unroll
         for (int r = 0; r < (PAIRKEY ? R / 2 : R); r++) {
             const uint32_t wk = bestA[r];
@@ -897,34 +956,52 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
 #pragma unroll
         for (int p2 = 0; p2 < NK; p2++) {
             const uint32_t gh = bestB[p2], gt = GT[p2];
-            const uint32_t ha = (gh & 0xffffu) >> 3, hb = gh >> 19;  // 64*H = 8*H8
-            const uint32_t ta = (gt & 0xffffu) >> 1, tb = gt >> 17;
-            rowA[p2] = 2u * (uint32_t)p2 + (gt & 1u);
-            rowB[p2] = 2u * (uint32_t)p2 + ((gt >> 16) & 1u);
+            const uint32_t ha = (gh & 0xffc0u) >> 3, hb = (gh >> 19) & 0x1ff8u;  // 64*H = 8*H8
+            const uint32_t gta = gt & 0xffffu, gtb = gt >> 16;
+            // GT = 2 t + (row odd), or 64 * (t / 32) + 32 * (row odd) + t % 32 under the other A.3 rule
+            const uint32_t ta = end_min_ref ? gta >> 1 : ((gta >> 6) << 5) | (gta & 31u);
+            const uint32_t tb = end_min_ref ? gtb >> 1 : ((gtb >> 6) << 5) | (gtb & 31u);
+            rowA[p2] = 2u * (uint32_t)p2 + (end_min_ref ? (gta & 1u) : ((gta >> 5) & 1u));
+            rowB[p2] = 2u * (uint32_t)p2 + (end_min_ref ? (gtb & 1u) : ((gtb >> 5) & 1u));
             bestA[p2] = ha ? ((ha << 16) | (0xffffu - ta)) : 0u;
             bestB[p2] = hb ? ((hb << 16) | (0xffffu - tb)) : 0u;
         }
     }
-    if constexpr (MODE != 2) {
+    if constexpr (!P2) {
         // ---- end cells (Appendix A.3) for A and B: equal keys keep the earlier (smaller) row
         uint32_t bka = 0, bkb = 0;
         int browa = 0, browb = 0;
 #pragma unroll
         for (int r = 0; r < NK; r++) {
             const int ra = lig * R + (int)rowA[r], rb = lig * R + (int)rowB[r];
-            if (ra < lqA && bestA[r] > bka) { bka = bestA[r]; browa = ra; }
-            if (rb < lqB && bestB[r] > bkb) { bkb = bestB[r]; browb = rb; }
+            // a lane's rows share the column of a step, so equal keys mean equal columns; under the other A.3 rule the
+            // earlier row also wins against a later row's smaller column
+            const uint32_t ka = end_min_ref ? bestA[r] : (bestA[r] & 0xffff0000u), kb = end_min_ref ? bestB[r] : (bestB[r] & 0xffff0000u);
+            if (ra < lqA && ka > (end_min_ref ? bka : (bka & 0xffff0000u))) { bka = bestA[r]; browa = ra; }
+            if (rb < lqB && kb > (end_min_ref ? bkb : (bkb & 0xffff0000u))) { bkb = bestB[r]; browb = rb; }
         }
-        uint64_t ca = (bka >> 16) ? ((((uint64_t)(bka + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browa)) : 0ull;
-        uint64_t cb = (bkb >> 16) ? ((((uint64_t)(bkb + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - browb)) : 0ull;
+        // (H, -column, -row), or (H, -row, -column)
+        uint64_t ca = 0, cb = 0;
+        if (bka >> 16) {
+            const uint64_t h = bka >> 16, nj = (bka + (uint32_t)lig) & 0xffffu, ni = (uint64_t)(0xffff - browa);
+            ca = end_min_ref ? (h << 32) | (nj << 16) | ni : (h << 32) | (ni << 16) | nj;
+        }
+        if (bkb >> 16) {
+            const uint64_t h = bkb >> 16, nj = (bkb + (uint32_t)lig) & 0xffffu, ni = (uint64_t)(0xffff - browb);
+            cb = end_min_ref ? (h << 32) | (nj << 16) | ni : (h << 32) | (ni << 16) | nj;
+        }
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
             const uint64_t oa = __shfl_xor(ca, m, 64), ob = __shfl_xor(cb, m, 64);
             ca = oa > ca ? oa : ca;
             cb = ob > cb ? ob : cb;
         }
+        if (!end_min_ref) {  // back to (H, -column, -row) for the unpacking below
+            ca = (ca & 0xffffffff00000000ull) | ((ca & 0xffffull) << 16) | ((ca >> 16) & 0xffffull);
+            cb = (cb & 0xffffffff00000000ull) | ((cb & 0xffffull) << 16) | ((cb >> 16) & 0xffffull);
+        }
         if (lig == 0) {
-            if (itemA < a.n_items) {
+            if (itemA < n_items) {
                 Fwd f;
                 f.score = (int32_t)(ca >> 32) / PK_SCALE;
                 f.end_r = ca ? (int32_t)(0xffff - ((ca >> 16) & 0xffff)) : 0;
@@ -932,7 +1009,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                 f.pad = 0;
                 a.fwd[itemA] = f;
             }
-            if (itemB < a.n_items) {
+            if (itemB < n_items) {
                 Fwd f;
                 f.score = (int32_t)(cb >> 32) / PK_SCALE;
                 f.end_r = cb ? (int32_t)(0xffff - ((cb >> 16) & 0xffff)) : 0;
@@ -942,6 +1019,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             }
         }
     }
+    }  // octets of this wave
 }
 
 // ---------------------------------------------------------------- forward SW for queries longer than 512 bases
@@ -959,17 +1037,23 @@ struct LongArgs {
     int32_t max_lq, max_lr;
     Fwd *fwd;
     ScoreTab sc;
+    const uint32_t *count_dev;  // items on the long list (nullptr = n_items is exact); n_items stays the interleave stride
+    uint32_t item_base;
 };
 
 __global__ __launch_bounds__(64) void sw_long_kernel(LongArgs a) {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = item < a.n_items;
+    int n_live = a.n_items;
+    if (a.count_dev) n_live = min(n_live, max(0, (int)*a.count_dev - (int)a.item_base));
+    const bool have = item < n_live;
     Work w;
     w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.pad = 0;
     if (have) w = a.work[item];
     const int lq = (int)w.lq, lr = (int)w.lr;
     const uint32_t n = (uint32_t)a.n_items;
     const int32_t open = a.sc.open, ext = a.sc.ext;
+    const bool hdir_f_first = rule(a.sc.rules, FADEHIP_RULE_HDIR_DIAG_F_E), tie_extends = rule(a.sc.rules, FADEHIP_RULE_GAP_TIE_EXTENDS);
+    const bool end_min_ref = rule(a.sc.rules, FADEHIP_RULE_END_MIN_REF_THEN_QUERY);
     for (int j = 0; j < lr; j++) {
         a.hrow[(uint64_t)j * n + item] = 0;
         a.frow[(uint64_t)j * n + item] = 0;
@@ -1017,14 +1101,16 @@ __global__ __launch_bounds__(64) void sw_long_kernel(LongArgs a) {
                     const int32_t T = max(max(Dp, En), Fn);
                     const int32_t H = max(T - open, 0);
                     // trace nibble as in the wave kernels: 8 (D < T), 4 (F < T), 2 (E opened), 1 (F opened)
-                    const uint32_t nb = (Dp < T ? 8u : 0u) | (Fn < T ? 4u : 0u) | (Ee < hl ? 2u : 0u) | (Fe < hu ? 1u : 0u);
+                    // (A.4 switches: bit 4 is "H != E" when E has priority; with "ties open" a gap opens unless its extension is strictly larger)
+                    const uint32_t nb = (Dp < T ? 8u : 0u) | ((hdir_f_first ? Fn : En) < T ? 4u : 0u) |
+                                        ((tie_extends ? Ee < hl : Ee <= hl) ? 2u : 0u) | ((tie_extends ? Fe < hu : Fe <= hu) ? 1u : 0u);
                     if (k & 1) trow[(uint64_t)(j >> 1) * n] = (uint8_t)(pair | (nb << 4));
                     else {
                         pair = nb;
                         if (j == lr - 1) trow[(uint64_t)(j >> 1) * n] = (uint8_t)pair;  // odd window length: last cell alone
                     }
                     // end cell: max H, then smallest ref index, then smallest query index (rows are visited in order)
-                    if (H > best || (H == best && H > 0 && j < bj)) { best = H; bi = i; bj = j; }
+                    if (H > best || (end_min_ref && H == best && H > 0 && j < bj)) { best = H; bi = i; bj = j; }
                     const uint64_t at = (uint64_t)j * n + item;
                     a.hrow[at] = H;
                     a.frow[at] = Fn;
@@ -1069,7 +1155,9 @@ struct TbArgs {
     const Cand *cand;
     Cand *incomplete;       // candidates whose path leaves the traced steps ...
     uint32_t *incomplete_n; // ... are listed here (with the T0 they had) and re-run from further back
-    P2Table tab;            // with cand: thread k serves slot k & 7 of wave k >> 3
+    const P2Table *tab_dev; // with cand: thread k serves slot k & 7 of wave k >> 3 of the table plan_kernel built
+    const uint32_t *count_dev;  // without cand: items on the list (nullptr = n_items is exact), as in SwArgs
+    uint32_t item_base;
 };
 
 __device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int g, int i, int j) {
@@ -1118,19 +1206,22 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
     int src = item, c0 = 0;
     uint64_t trace_off;
     if (a.cand) {
+        const P2Table &tab = *a.tab_dev;
         const int oct = item >> 3;
         int b = 0;
-        if (oct >= (int)a.tab.oct_first[NUM_BUCKETS]) return 0u;
-        while (oct >= (int)a.tab.oct_first[b + 1]) b++;
-        const int local = oct - (int)a.tab.oct_first[b];
+        if (oct >= (int)tab.oct_first[NUM_BUCKETS]) return 0u;
+        while (oct >= (int)tab.oct_first[b + 1]) b++;
+        const int local = oct - (int)tab.oct_first[b];
         const int k = local * 8 + (item & 7);
-        if (k >= (int)a.tab.count[b]) return 0u;
-        const Cand c = a.cand[(uint64_t)a.tab.bucket[b] * a.tab.cap + k];
+        if (k >= (int)tab.count[b]) return 0u;
+        const Cand c = a.cand[(uint64_t)tab.bucket[b] * tab.cap + k];
         src = (int)c.src;
         c0 = (int)c.c0;
-        trace_off = a.tab.trace_base[b] + (uint64_t)local * a.tab.stride[b];
+        trace_off = tab.trace_base[b] + (uint64_t)local * tab.stride[b];
     } else {
-        if (item >= a.n_items) return 0u;
+        int n_items = a.n_items;
+        if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
+        if (item >= n_items) return 0u;
         trace_off = (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
     }
     const Work w = a.work[src];
@@ -1142,6 +1233,9 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
     const int lq = (int)w.lq;
     const bool rcq = w.flags & 1u;
     const int32_t open = a.sc.open, ext = a.sc.ext;
+    const bool hdir_f_first = rule(a.sc.rules, FADEHIP_RULE_HDIR_DIAG_F_E), eq_by_char = rule(a.sc.rules, FADEHIP_RULE_EQ_BY_CHAR);
+    const bool pad = rule(a.sc.rules, FADEHIP_RULE_PAD_SOFTCLIP);
+    const int op_ref_only = rule(a.sc.rules, FADEHIP_RULE_SAM_GAP_LETTERS) ? 2 : 1, op_query_only = 3 - op_ref_only;  // A.5: 'D' / 'I'
 
     // Appendix A.4 traceback.  The value of the current cell is carried along (h), so the
     // ZERO stop needs no stored flag.
@@ -1206,15 +1300,15 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
                 if (stop) continue;
                 if (!vk[k]) { stop = true; continue; }          // the outer loop re-checks bounds and range
                 if (h == 0) { done = true; stop = true; continue; }
-                if (nbk[k] & 8u) {                               // H != D: H == F (query-only) has priority over E
-                    state = (nbk[k] & 4u) ? 1 : 2;
+                if (nbk[k] & 8u) {                               // H != D: H == F (query-only) has priority over E (A.4; bit 4 = "H != E" the other way)
+                    state = ((nbk[k] & 4u) != 0) == hdir_f_first ? 1 : 2;
                     stop = true;
                     continue;
                 }
                 const uint32_t cq = lut4(CLASS_LUT, qck[k]), cr = lut4(CLASS_LUT, rck[k]);
                 const int32_t wsc = (cq == 5 || cr == 5) ? 0 : (cq == cr ? a.sc.match : a.sc.mismatch);
                 h -= wsc;
-                emit((qck[k] == rck[k] && qck[k] != 0) ? 7 : 8);  // '=' : 'X' by residue equality
+                emit((eq_by_char ? (qck[k] == rck[k] && qck[k] != 0) : wsc > 0) ? 7 : 8);  // '=' : 'X' by residue equality (A.4)
                 i--; j--;
             }
             if (done) break;
@@ -1224,11 +1318,11 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
         if (state == 1) {  // E: consumes reference only -> 'D'
             if (nb & 2u) { h += open; state = 0; } else h += ext;
             j--;
-            emit(2);
+            emit(op_ref_only);
         } else {           // F: consumes query only -> 'I'
             if (nb & 1u) { h += open; state = 0; } else h += ext;
             i--;
-            emit(1);
+            emit(op_query_only);
         }
     }
     if (cur_op >= 0) {
@@ -1238,7 +1332,7 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
         n_runs++;
     }
 
-    if (left_range && !(state == 0 && h == 0) && a.early_out && n_runs + (lq - 1 - f.end_q > 0 ? 1 : 0) > 10) {
+    if (left_range && !(state == 0 && h == 0) && a.early_out && n_runs + ((pad && lq - 1 - f.end_q > 0) ? 1 : 0) > 10) {
         // The path continues before step T0, but it already has more than 10 ops and can only gain more:
         // analysis.d:69-70 rejects it whatever the rest looks like.  Report it like an untraced alignment.
         fadehip_aln o;
@@ -1283,7 +1377,7 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
     uint32_t first_op = 0, last_op = 0;
 #pragma unroll
     for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
-    if (o.sw.beg_query > 0) {
+    if (pad && o.sw.beg_query > 0) {
         first_op = ((uint32_t)o.sw.beg_query << 4) | 4u;
         o.sw.ops[0] = first_op;
         n = 1;
@@ -1298,7 +1392,7 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
     }
     if (n_runs > 0) last_op = first_gen;
     const int tail = lq - 1 - f.end_q;
-    if (tail > 0) {
+    if (pad && tail > 0) {
         last_op = ((uint32_t)tail << 4) | 4u;
         if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = last_op;
         n++;
@@ -1380,6 +1474,9 @@ struct SelArgs {
     unsigned long long *stats;
     int32_t gate;
     int32_t match;          // score of a matching pair; 0 switches the shortcut off
+    uint32_t rules;         // FADEHIP_RULE_*
+    const uint32_t *count_dev;  // items on the class list (nullptr = n_items is exact); this launch covers [item_base, item_base + n_items)
+    uint32_t item_base;
 };
 
 // 128-thread blocks: a class list has ~10^5 items, and the shortcut's diagonal check is a chain of dependent loads
@@ -1396,7 +1493,9 @@ __global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
     Cand c;
     c.src = 0;
     c.c0 = 0;
-    if (item < a.n_items) {
+    int n_items = a.n_items;
+    if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
+    if (item < n_items) {
         const Work w = a.work[item];
         const Fwd f = a.fwd[item];
         bool cand = true;
@@ -1406,7 +1505,8 @@ __global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
                               f.end_q == (int32_t)w.lq - 1;
             const bool right = m.clip_right > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_right &&
                                f.end_q < (int32_t)w.lq - 1;
-            cand = left || right;
+            // (without A.6's soft-clip padding no result CIGAR has an S op and analysis.d:78-80 / 102-104 never hold)
+            cand = (left || right) && rule(a.rules, FADEHIP_RULE_PAD_SOFTCLIP);
             if (!cand) {
                 fadehip_aln o;
                 o.read_idx = (int32_t)w.idx;
@@ -1437,6 +1537,8 @@ __global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
             if (L * a.match == f.score && L <= f.end_q + 1 && L <= f.end_r + 1) {
                 const bool rcq = w.flags & 1u;
                 const int lq = (int)w.lq;
+                const uint32_t n_match_classes = rule(a.rules, FADEHIP_RULE_N_MATCHES_N) ? 5u : 4u;
+                const bool pad = rule(a.rules, FADEHIP_RULE_PAD_SOFTCLIP);
                 bool ok = true;
                 for (int k0 = 0; k0 < L && ok; k0 += 8) {
                     const int nv = min(8, L - k0);
@@ -1450,7 +1552,7 @@ __global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
                             const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
                             const uint32_t cq = lut4(CLASS_LUT, rcq ? lut4(COMP_LUT, qraw) : qraw);
                             const uint32_t cr = lut4(CLASS_LUT, nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k)));
-                            ok = ok && cq == cr && cq < 5u;  // same letter of A,C,G,T,N: the pair scores `match`
+                            ok = ok && cq == cr && cq < n_match_classes;  // same letter of A,C,G,T,N: the pair scores `match`
                         }
                     }
                 }
@@ -1467,9 +1569,9 @@ __global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
                     for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
                     const int lead = o.sw.beg_query, tail = lq - 1 - f.end_q;
                     int n = 0;
-                    if (lead > 0) o.sw.ops[n++] = ((uint32_t)lead << 4) | 4u;
+                    if (pad && lead > 0) o.sw.ops[n++] = ((uint32_t)lead << 4) | 4u;
                     o.sw.ops[n++] = ((uint32_t)L << 4) | 7u;
-                    if (tail > 0) o.sw.ops[n++] = ((uint32_t)tail << 4) | 4u;
+                    if (pad && tail > 0) o.sw.ops[n++] = ((uint32_t)tail << 4) | 4u;
                     o.sw.n_ops = n;
                     if (a.meta) {
                         const Meta m = a.meta[item];
@@ -1535,5 +1637,92 @@ __global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------- pass-2 planning (device side)
+// The selection's bucket counts never leave the device: one wave turns them into the table the pass-2 launch and
+// its traceback read (which octet belongs to which bucket, where its trace scratch starts).  The launches themselves
+// are sized from upper bounds; if the trace scratch the table needs exceeds what the slot holds, the table stays
+// empty and the need is left in `plan` for the host (fadehip_annotate_collect grows the scratch and runs the batch
+// again: DESIGN.md §4).
+struct PlanOut {            // in the slot's counter block, read by the host after the run
+    uint32_t overflow;      // some plan did not fit the trace scratch
+    uint32_t bound_violated;  // a device-side count exceeded the bound its launch was sized from
+    unsigned long long need_dwords;  // largest trace scratch any plan asked for
+    unsigned long long cand_total;   // candidates traced (all classes and rounds)
+    unsigned long long rerun_total;  // candidates listed for a re-run
+};
+struct PlanArgs {
+    const uint32_t *bucket_n;   // [NUM_BUCKETS] from select_kernel; nullptr for a re-run round
+    uint32_t *incomplete_n;     // re-run round: number of listed candidates (reset to 0 here)
+    const Cand *incomplete;     // re-run round: the list ...
+    Cand *again;                // ... copied here with T0 moved `back` steps towards 0
+    int32_t back;
+    int32_t steps_max[NUM_BUCKETS];
+    int32_t n_buckets;          // NUM_BUCKETS, or 1 for a re-run round
+    int32_t R;
+    uint32_t cap;               // entries per bucket of the candidate array
+    uint32_t oct_bound;         // octets the pass-2 launch and its traceback were sized for
+    unsigned long long trace_cap_dwords;
+    P2Table *tab;
+    PlanOut *plan;
+};
+
+__global__ __launch_bounds__(256) void plan_kernel(PlanArgs a) {
+    __shared__ uint32_t s_n;
+    if (a.bucket_n == nullptr) {
+        if (threadIdx.x == 0) s_n = *a.incomplete_n;
+        __syncthreads();
+        const uint32_t m = s_n;
+        for (uint32_t k = threadIdx.x; k < m; k += blockDim.x) {
+            Cand c = a.incomplete[k];
+            c.c0 = (int)c.c0 > a.back ? c.c0 - (uint32_t)a.back : 0u;
+            a.again[k] = c;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    P2Table t;
+    t.cap = a.cap;
+    t.pad = 0;
+    uint64_t off = 0;
+    uint32_t oct = 0, total = 0;
+    for (int k = 0; k < NUM_BUCKETS; k++) {
+        const int b = a.n_buckets - 1 - k;  // longest bucket first
+        t.oct_first[k] = oct;
+        t.count[k] = 0;
+        t.bucket[k] = 0;
+        t.trace_base[k] = 0;
+        t.stride[k] = 0;
+        if (b < 0) continue;
+        const uint32_t cnt = a.bucket_n ? a.bucket_n[b] : s_n;
+        if (!cnt) continue;
+        const uint64_t stride = (uint64_t)((a.steps_max[b] + 3) / 4) * (uint64_t)a.R * 64u;
+        t.count[k] = cnt;
+        t.bucket[k] = (uint32_t)b;
+        t.trace_base[k] = off;
+        t.stride[k] = stride;
+        const uint32_t octs_b = (cnt + 7) / 8;
+        off += (uint64_t)octs_b * stride;
+        oct += octs_b;
+        total += cnt;
+    }
+    t.oct_first[NUM_BUCKETS] = oct;
+    if (a.bucket_n == nullptr) {
+        *a.incomplete_n = 0;
+        if (total) atomicAdd(&a.plan->rerun_total, (unsigned long long)total);
+    } else if (total) atomicAdd(&a.plan->cand_total, (unsigned long long)total);
+    if (off > a.plan->need_dwords) a.plan->need_dwords = off;
+    bool ok = true;
+    if (off > a.trace_cap_dwords) { a.plan->overflow = 1; ok = false; }
+    if (oct > a.oct_bound) { a.plan->bound_violated = 1; ok = false; }
+    if (!ok) {
+        for (int k = 0; k <= NUM_BUCKETS; k++) t.oct_first[k] = 0;
+        for (int k = 0; k < NUM_BUCKETS; k++) t.count[k] = 0;
+    }
+    *a.tab = t;
+}
+
+// level 1 builds its class lists on the host: their counts go where the gate would have left them
+__global__ void set_counts_kernel(uint32_t *dst, uint32_t v) { *dst = v; }
 
 }  // namespace fadehip

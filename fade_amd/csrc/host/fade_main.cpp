@@ -419,6 +419,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             pack_chunk(*c, pool);
             ck_pack.stop();
             fadehip_read_batch b;
+            memset(&b, 0, sizeof b);
             b.n_reads = (int)c->recs.size();
             b.tid = c->tid.data(); b.pos = c->pos.data(); b.flag = c->flag.data(); b.has_sa = c->has_sa.data();
             b.l_seq = c->l_seq.data(); b.cigar_off = c->cigar_off.data(); b.cigar_ops = c->cigar_ops.data();

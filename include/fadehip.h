@@ -22,8 +22,8 @@
  *
  * Plain C: pointers and sizes only.  Every function returns 0 on success or a negative
  * FADEHIP_E_* code and never throws or aborts across the boundary; fadehip_last_error(ctx) returns
- * a sticky message.  A ctx is bound to one device; each of its slots may be driven by its own host thread (create,
- * destroy, genome_upload and sw_batch by one thread while no slot is busy).
+ * the message of the calling thread's last failure on that ctx.  A ctx is bound to one device; its slots may be driven
+ * by one host thread or by one thread each (create, destroy, genome_upload and sw_batch by one thread while no slot is busy).
  * There is no CPU fallback: without a usable HIP device fadehip_create fails.
  */
 #ifndef FADEHIP_H
@@ -34,11 +34,11 @@
 extern "C" {
 #endif
 
-#define FADEHIP_ABI_VERSION 1
+#define FADEHIP_ABI_VERSION 2
 #define FADEHIP_MAX_OPS 16   /* ops reported per alignment (FADE rejects > 10, analysis.d:69) */
 #define FADEHIP_MAX_QUERY 512 /* longest query of the wave kernels (8 alignments per wavefront) */
 #define FADEHIP_MAX_LONG_QUERY 32768 /* longer queries, up to this, take a thread-per-alignment kernel (slow path) */
-#define FADEHIP_NUM_SLOTS 2   /* double-buffered batches per ctx */
+#define FADEHIP_NUM_SLOTS 4   /* batches in flight per ctx (each slot has its own stream, device buffers and pinned result block) */
 
 enum {
     FADEHIP_OK = 0,
@@ -65,14 +65,31 @@ typedef struct {
     int32_t ext;       /* 2 : cost of each further gap base */
     int32_t match;     /* 2 */
     int32_t mismatch;  /* -3 */
-    int32_t max_ref_len;   /* longest reference window accepted; 0 -> 8192, at most 2^20.  Windows of up to 8000 bases
-                              take the wave kernels, longer ones the thread-per-alignment kernel (slow path) */
+    int32_t max_ref_len;   /* longest reference window re-aligned; 0 -> 2^20, which is also the most.  Windows of up to 8000
+                              bases take the wave kernels, longer ones the thread-per-alignment kernel (slow path); a read
+                              whose window is longer still is left un-re-aligned and counted in n_oversize */
     int32_t max_batch_reads; /* capacity of one annotate batch; 0 -> 1<<20 */
     int64_t trace_bytes;   /* device bytes reserved for trace tables / checkpoints; 0 -> sized on demand */
     int32_t trace_all;     /* 1: level 2 returns a CIGAR for every re-aligned read (default: only for reads whose
                               score and end cell can still pass FADE's gates; the others have sw.n_ops == 0) */
-    int32_t reserved;
+    uint32_t rules;        /* FADEHIP_RULE_* bits; 0 -> FADEHIP_RULES_DEFAULT */
 } fadehip_params;
+
+/* Behaviour of the un-vendored arithmetic behind analysis.d:67 (libparasail 2.4.3 through dparasail 0.3.3) that could
+ * not be checked against its source in this environment (DESIGN.md "parity unpinned").  Each
+ * assumption is a switch with the same meaning and bit as oracle/fade_oracle.h's FO_RULE_*: should a maintainer find
+ * that parasail does the opposite, it is a parameter, not a kernel edit.  Non-default settings run a slower variant of
+ * the traced re-computation; the default costs nothing. */
+enum {
+    FADEHIP_RULE_END_MIN_REF_THEN_QUERY = 1u << 0, /* A.3 end cell: max H, ties -> smallest ref index, then smallest query index (off: first in row-major order) */
+    FADEHIP_RULE_HDIR_DIAG_F_E = 1u << 1,          /* A.4 traceback priority DIAG > F (query-only) > E (ref-only)  (off: DIAG > E > F) */
+    FADEHIP_RULE_GAP_TIE_EXTENDS = 1u << 2,        /* A.4 a gap "opens" only on strict >, ties extend  (off: ties open) */
+    FADEHIP_RULE_EQ_BY_CHAR = 1u << 3,             /* A.4 '=' vs 'X' by residue equality  (off: by the sign of the matrix entry) */
+    FADEHIP_RULE_SAM_GAP_LETTERS = 1u << 4,        /* A.5 ref-only step 'D', query-only step 'I'  (off: swapped) */
+    FADEHIP_RULE_PAD_SOFTCLIP = 1u << 5,           /* A.6 CIGAR padded with S for unaligned query ends  (off: no padding) */
+    FADEHIP_RULE_N_MATCHES_N = 1u << 6,            /* A.1 N vs N scores `match`  (off: `mismatch`) */
+    FADEHIP_RULES_DEFAULT = 0x7f
+};
 
 void fadehip_params_default(fadehip_params *p);
 int fadehip_abi_version(void);
@@ -121,7 +138,23 @@ typedef struct {
     const uint32_t *seq_off;   /* [n+1] byte offset of the record's packed sequence */
     const uint8_t *seq_packed; /* BAM 4-bit sequence bytes, each record byte-aligned.  Only mapped records with an S op
                                   are ever read (anno.d:61): the others may have an empty slice, seq_off[i+1] == seq_off[i] */
+    /* ABI 2.  anno.d:61-65 gives an unmapped record, or one without an S op, rs = 0 before looking at anything else:
+     * a caller may leave such records out of the batch (they need not cross PCIe) and pass their number here; it is
+     * added to the read_count of the batch's stats.  rs / read_idx then index the records that were sent. */
+    int32_t n_skipped;
+    /* Upper bound of cigar.alignedLength (analysis.d:53) over the batch, or 0 if the caller does not know it: the
+     * launches of a run are sized from it (window <= bound + 2 * window-size).  With 0 the library scans the CIGARs
+     * itself (about 1 ms per 10^5 records on one host thread).  A bound that turns out too small fails the batch at
+     * collect (FADEHIP_E_INVALID), it is never trusted for memory safety. */
+    int32_t ref_span_bound;
 } fadehip_read_batch;
+
+/* One pinned block for the nine arrays of a batch, so that upload is ONE hipMemcpyAsync at PCIe speed: allocate
+ * fadehip_batch_bytes(...) with fadehip_host_alloc, let fadehip_batch_bind point the arrays into it (canonical order,
+ * 256-byte aligned), fill them through the pointers (cigar_off[n] = n_cigar_ops, seq_off[n] = n_seq_bytes).  Arrays
+ * laid out any other way are first gathered into the slot's own pinned staging block (one host copy more). */
+size_t fadehip_batch_bytes(int32_t n_reads, int64_t n_cigar_ops, int64_t n_seq_bytes);
+int fadehip_batch_bind(void *base, int32_t n_reads, int64_t n_cigar_ops, int64_t n_seq_bytes, fadehip_read_batch *b);
 
 /* One entry per read that was re-aligned (clip longer than min-length), in no particular order.
  * sw.score / end_query / end_ref are always set.  Unless params.trace_all, the traceback (beg_*, ops)
@@ -145,27 +178,46 @@ typedef struct {
     int32_t n_aln;        /* out */
     int64_t stats[8];     /* out: stats.d:45-54 over this batch: read_count, clipped, sup, art_sup,
                              art, art_mate, aln_l, aln_r */
+    int32_t n_oversize;   /* out: soft-clipped reads left un-re-aligned because the read (> FADEHIP_MAX_LONG_QUERY) or its
+                             window (> max_ref_len) exceeds the kernels' limits; their rs keeps the sc / sup bits */
+    int32_t reserved;
 } fadehip_anno_out;
 
-/* Asynchronous pipeline, slot in [0, FADEHIP_NUM_SLOTS):
- *   upload  : H2D copies of the batch arrays (hipMemcpyAsync on the slot's stream)
- *   run     : gate -> score pass (SW score, end cell, wave snapshots) -> selection of the alignments that can
- *             still be artifact calls -> traced re-computation of their last steps -> traceback + artifact
- *             gates, all on device (three small counter read-backs size the launches)
- *   collect : D2H of rs / aln / stats; blocks until the slot is done
- * submit = upload + run.  Results stay valid until the slot is uploaded again.  The batch arrays handed to upload /
- * submit must stay valid and unchanged until the slot's run has returned (the copies from pinned memory are
- * asynchronous; run synchronises the stream when it reads the gate's counters back).
- * floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
+/* Zero-copy form of the results: pointers into the slot's pinned result block, valid until the slot is uploaded again. */
+typedef struct {
+    const uint8_t *rs;        /* [n_reads] */
+    const fadehip_aln *aln;   /* [n_aln] */
+    int32_t n_reads, n_aln;
+    int64_t stats[8];
+    int32_t n_oversize;       /* as in fadehip_anno_out */
+    int32_t reserved;
+} fadehip_anno_view;
+
+/* Asynchronous pipeline, slot in [0, FADEHIP_NUM_SLOTS); one host thread can keep every slot busy:
+ *   upload  : ONE hipMemcpyAsync of the batch block on the slot's stream (see fadehip_batch_bind); returns at once
+ *   run     : enqueues gate -> score pass (SW score, end cell, wave snapshots) -> selection of the alignments that can
+ *             still be artifact calls -> device-side plan of the traced re-computation -> traced re-computation of
+ *             their last steps -> traceback + artifact gates -> D2H of rs / aln / counters into the slot's pinned
+ *             result block.  Nothing is read back in between: launches are sized from host-side bounds (read lengths,
+ *             ref_span_bound), counts stay on the device, persistent waves draw work from device-side tables.
+ *             Returns as soon as everything is enqueued (FADEHIP_KERNEL=pk|int32, the single-pass kernels kept for
+ *             A/B runs, still block on the gate's counters).
+ *   results : waits for the slot, then hands out views (collect: copies them into the caller's arrays).  Errors the
+ *             device found in the batch (bad tid, window beyond max_ref_len, ...) are reported HERE, not by run.  If
+ *             the traced re-computation needed more scratch than the slot held, the scratch grows and the batch runs
+ *             again inside this call (a warm-up effect; FADEHIP_DEBUG=1 reports it).
+ * submit = upload + run.  The batch arrays handed to upload / submit must stay valid and unchanged until the slot's
+ * results / collect has returned.  floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
 int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch);
 int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t window);
 int fadehip_annotate_submit(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch,
                             int32_t floor_len, int32_t window);
+int fadehip_annotate_results(fadehip_ctx *ctx, int slot, fadehip_anno_view *out);
 int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out);
 int fadehip_sync(fadehip_ctx *ctx);
 
-/* Measurement: device time of the last run on `slot`, from hipEvents recorded on the slot's
- * stream around the kernels.  ms[0] gate, ms[1] the dominant kernel (the score pass; the single forward kernel
+/* Measurement (after results / collect of that run): device time of the last run on `slot`, from hipEvents recorded
+ * on the slot's stream around the kernels.  ms[0] gate, ms[1] the dominant kernel (the score pass; the single forward kernel
  * under FADEHIP_KERNEL=pk|int32), ms[2] everything after it up to the artifact gates (selection, traced pass 2,
  * traceback, re-runs), ms[3] whole run.  counts[0] alignments, counts[1] DP cells, counts[2] trace scratch
  * bytes, counts[3] algorithmic bytes of the dominant kernel. */

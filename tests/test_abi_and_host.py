@@ -26,16 +26,42 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libfadehip.so lacks %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert L.fadehip_abi_version() == 1
+    assert L.fadehip_abi_version() == _lib.ABI_VERSION == 2
+    hdr = open(os.path.join(ROOT, "include", "fadehip.h")).read()
+    assert "#define FADEHIP_ABI_VERSION %d" % _lib.ABI_VERSION in hdr and "#define FADEHIP_NUM_SLOTS %d" % _lib.NUM_SLOTS in hdr
     p = _lib.Params()
     L.fadehip_params_default(ctypes.byref(p))
     assert (p.open, p.ext, p.match, p.mismatch) == (10, 2, 2, -3)  # anno.d:36
+    assert p.rules == _lib.RULES_DEFAULT and p.max_ref_len == 1 << 20
+
+
+def test_batch_block_layout():
+    """fadehip_batch_bytes / fadehip_batch_bind (no GPU needed): nine arrays, 256-byte aligned, inside the block."""
+    from fade_amd import _lib
+    L = _lib.load()
+    n, n_cig, n_seq = 1000, 2345, 75_000
+    total = L.fadehip_batch_bytes(n, n_cig, n_seq)
+    assert total >= 4 * n * 3 + 8 * (n + 1) + 3 * n + 4 * n_cig + n_seq
+    buf = ctypes.create_string_buffer(total + 256)
+    base = (ctypes.addressof(buf) + 255) & ~255
+    b = _lib.ReadBatch()
+    assert L.fadehip_batch_bind(base, n, n_cig, n_seq, ctypes.byref(b)) == 0
+    sizes = dict(tid=4 * n, pos=4 * n, l_seq=4 * n, cigar_off=4 * (n + 1), seq_off=4 * (n + 1), flag=2 * n, has_sa=n,
+                 cigar_ops=4 * n_cig, seq_packed=n_seq)
+    spans = sorted((getattr(b, k), getattr(b, k) + v) for k, v in sizes.items())
+    assert spans[0][0] == base and spans[-1][1] <= base + total
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0 and b0 % 256 == 0
+    assert b.n_reads == n and b.n_skipped == 0 and b.ref_span_bound == 0
+    assert L.fadehip_batch_bind(base + 8, n, n_cig, n_seq, ctypes.byref(b)) != 0  # misaligned block
 
 
 def test_struct_layouts_match_header():
     from fade_amd import _lib
     assert ctypes.sizeof(_lib.SwResult) == 24 + 4 * 16
     assert ctypes.sizeof(_lib.Aln) == 32 + ctypes.sizeof(_lib.SwResult)
+    assert ctypes.sizeof(_lib.ReadBatch) == 8 + 9 * 8 + 8 and ctypes.sizeof(_lib.Params) == 40
+    assert ctypes.sizeof(_lib.AnnoView) == 16 + 8 + 64 + 8 and ctypes.sizeof(_lib.AnnoOut) == 16 + 8 + 64 + 8
     assert _lib.ALN_DTYPE.fields["sw"][1] == 32
 
 

@@ -1,0 +1,179 @@
+"""The asynchronous level-2 pipeline of ABI 2 (include/fadehip.h): one-DMA pinned batch blocks, records the caller
+leaves out (anno.d:61-65), host-side bounds with device-side checks, device-planned pass 2 with its scratch-overflow
+re-run, several slots driven by one thread, several contexts on one device.  Everything is compared with the
+plain full-batch path, which test_gpu_annotate / test_gpu_edges / test_gpu_fuzz compare with the oracle."""
+import numpy as np
+import pytest
+
+import fade_amd
+from fade_amd import shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _key(aln, idx=None):
+    """read index (mapped through idx when the batch was a subset) -> the bytes FADE reads from the alignment."""
+    out = {}
+    for x in aln:
+        i = int(x["read_idx"])
+        y = x.copy()
+        y["read_idx"] = 0
+        out[int(idx[i]) if idx is not None else i] = y.tobytes()
+    return out
+
+
+@pytest.mark.parametrize("name", ["C2", "C5"])
+def test_clipped_only_pinned_batch_equals_full_batch(ctx, name):
+    cfg, g, b = synth.make_config(name, 40_000, contig_len=500_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    rs0, aln0, st0 = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+    sub, idx = ctx.clipped_only(b)
+    assert sub["n_skipped"] + len(idx) == len(rs0) and 0 < len(idx) < 0.4 * len(rs0)
+    # anno.d:61-65: everything that was left out has rs = 0
+    left_out = np.ones(len(rs0), bool)
+    left_out[idx] = False
+    assert not rs0[left_out].any()
+    for form in ("dict", "pinned"):
+        batch = ctx.pinned_batch(sub) if form == "pinned" else sub
+        ctx.annotate_upload(1, batch)
+        ctx.annotate_run(1, cfg["floor_len"], cfg["window"])
+        rs1, aln1, st1 = ctx.annotate_collect(1)
+        assert np.array_equal(rs1, rs0[idx]), form
+        assert list(st1) == list(st0), form  # read_count includes the records that were not sent
+        assert _key(aln1, idx) == _key(aln0), form
+    # without the caller's bound the library scans the CIGARs itself: same answer
+    sub2 = dict(sub)
+    sub2.pop("ref_span_bound")
+    rs2, aln2, st2 = ctx.annotate(sub2, cfg["floor_len"], cfg["window"], slot=2)
+    assert np.array_equal(rs2, rs0[idx]) and list(st2) == list(st0) and _key(aln2, idx) == _key(aln0)
+
+
+def test_ref_span_bound_too_small_is_an_error_not_a_fault(ctx):
+    cfg, g, b = synth.make_config("C2", 5000, contig_len=200_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    sub, idx = ctx.clipped_only(b)
+    bad = dict(sub)
+    bad["ref_span_bound"] = 20  # the reads align over 100-144 reference bases
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(bad, cfg["floor_len"], cfg["window"])
+    assert e.value.code == -1 and "ref_span_bound" in str(e.value)
+    rs, aln, st = ctx.annotate(sub, cfg["floor_len"], cfg["window"])  # the context stays usable
+    assert int(st[0]) == 5000
+
+
+def test_trace_scratch_overflow_reruns_the_batch(monkeypatch, capfd):
+    """The launches of pass 2 are sized before its candidates are known.  When the device-side plan needs more trace
+    scratch than the slot holds, results() grows it and runs the batch again: same bytes as a run that had room."""
+    cfg, g, b = synth.make_config("C5", 30_000, contig_len=400_000)
+    big = fade_amd.Context(device=0)
+    big.genome_upload(g.names, g.ascii_contigs())
+    monkeypatch.setenv("FADEHIP_NO_SHORTCUT", "1")  # every candidate goes through pass 2
+    rs0, aln0, st0 = big.annotate(b, cfg["floor_len"], cfg["window"])
+    monkeypatch.setenv("FADEHIP_TRACE_INIT", "65536")
+    monkeypatch.setenv("FADEHIP_DEBUG", "1")
+    small = fade_amd.Context(device=0)
+    try:
+        small.genome_upload(g.names, g.ascii_contigs())
+        capfd.readouterr()
+        rs1, aln1, st1 = small.annotate(b, cfg["floor_len"], cfg["window"])
+        assert "batch re-run" in capfd.readouterr().err
+        assert np.array_equal(rs0, rs1) and list(st0) == list(st1) and _key(aln0) == _key(aln1)
+        # the scratch stays grown: the next batch runs once
+        rs2, aln2, st2 = small.annotate(b, cfg["floor_len"], cfg["window"])
+        assert "batch re-run" not in capfd.readouterr().err
+        assert np.array_equal(rs0, rs2) and _key(aln0) == _key(aln2)
+        # level 1 (everything is traced) through the same plan / overflow path
+        from helpers import concat, make_pairs
+        qs, rs_ = make_pairs(np.random.default_rng(11), 400, kinds=("related", "planted", "random"))
+        qc, qo = concat(qs)
+        rc, ro = concat(rs_)
+        tiny = fade_amd.Context(device=0)
+        try:
+            got = tiny.sw_batch_packed(qc, qo, rc, ro)
+            assert "batch re-run" in capfd.readouterr().err
+        finally:
+            tiny.close()
+        assert got.tobytes() == big.sw_batch_packed(qc, qo, rc, ro).tobytes()
+    finally:
+        small.close()
+        big.close()
+
+
+def test_all_slots_in_flight_from_one_thread(ctx):
+    """run() returns once the work is enqueued: one host thread keeps every slot of the ctx busy."""
+    cfg, g, b = synth.make_config("C2", 8 * 6000, contig_len=500_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    n_slots = fade_amd._lib.NUM_SLOTS
+    parts = [synth.take(b, np.arange(k * 6000, (k + 1) * 6000)) for k in range(8)]
+    ref = []
+    for p in parts:
+        ref.append(ctx.annotate(p, cfg["floor_len"], cfg["window"]))
+    pinned = [ctx.pinned_batch(p) for p in parts]
+    got = [None] * 8
+    for k in range(8 + n_slots):
+        slot = k % n_slots
+        if k >= n_slots:
+            got[k - n_slots] = ctx.annotate_collect(slot)
+        if k < 8:
+            ctx.annotate_upload(slot, pinned[k])
+            ctx.annotate_run(slot, cfg["floor_len"], cfg["window"])
+    for k in range(8):
+        assert np.array_equal(got[k][0], ref[k][0]) and list(got[k][2]) == list(ref[k][2]), k
+        assert _key(got[k][1]) == _key(ref[k][1]), k
+
+
+def test_results_are_views_until_the_next_upload(ctx):
+    cfg, g, b = synth.make_config("C2", 4000, contig_len=200_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    ctx.annotate_upload(3, b)
+    ctx.annotate_run(3, cfg["floor_len"], cfg["window"])
+    rs, aln, st = ctx.annotate_results(3)
+    rs2, aln2, st2 = ctx.annotate_results(3)  # asking again is free and gives the same block
+    assert rs.ctypes.data == rs2.ctypes.data and aln.ctypes.data == aln2.ctypes.data and list(st) == list(st2)
+    assert len(rs) == 4000 and int(st[0]) == 4000 and len(aln) == int((np.asarray(aln["read_idx"]) >= 0).sum())
+    p = ctx.last_profile(3)
+    assert p["alignments"] == len(aln) and p["forward_ms"] > 0
+    ctx.annotate_upload(3, b)  # a new batch in the slot: the old results and their profile are gone
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.last_profile(3)
+    assert e.value.code == -6
+    with pytest.raises(fade_amd.FadeHipError):
+        ctx.annotate_results(3)  # uploaded, not run
+    ctx.annotate_run(3, cfg["floor_len"], cfg["window"])
+    assert np.array_equal(ctx.annotate_results(3)[0], rs)
+
+
+def test_two_contexts_on_one_device_interleaved(oracle):
+    """What `fade annotate --gpus 2` does when both contexts sit on one device (the test map of the CLI): batches dealt
+    round-robin to two fadehip_ctx, each with its own genome copy, streams and slots; results as from one context."""
+    cfg, g, b = synth.make_config("C2", 24_000, contig_len=300_000)
+    one = fade_amd.Context(device=0)
+    cs = [fade_amd.Context(device=0), fade_amd.Context(device=0)]
+    try:
+        for c in [one] + cs:
+            c.genome_upload(g.names, g.ascii_contigs())
+        rs0, aln0, st0 = one.annotate(b, cfg["floor_len"], cfg["window"])
+        parts = [np.arange(k * 4000, (k + 1) * 4000) for k in range(6)]
+        rs = np.zeros_like(rs0)
+        keys, stats = {}, np.zeros(8, np.int64)
+        for k, idx in enumerate(parts):  # deal: ctx k % 2, slot (k // 2) % 2
+            cs[k % 2].annotate_upload((k // 2) % 2, synth.take(b, idx))
+            cs[k % 2].annotate_run((k // 2) % 2, cfg["floor_len"], cfg["window"])
+            if k >= 2:
+                j = k - 2
+                r, a, s = cs[j % 2].annotate_collect((j // 2) % 2)
+                rs[parts[j]] = r
+                keys.update(_key(a, parts[j]))
+                stats += s
+        for j in (4, 5):
+            r, a, s = cs[j % 2].annotate_collect((j // 2) % 2)
+            rs[parts[j]] = r
+            keys.update(_key(a, parts[j]))
+            stats += s
+        assert np.array_equal(rs, rs0) and list(stats) == list(st0) and keys == _key(aln0)
+        # the one collective of the path, over the two contexts (RCCL communicator with both ranks on device 0 is not
+        # possible: the sum is what stats_allreduce must give on a multi-device node, checked here on the host)
+        assert list(stats) == list(shard.stats_from_rs(rs0))
+    finally:
+        for c in [one] + cs:
+            c.close()

@@ -161,9 +161,19 @@ def test_limits_fail_loudly(ctx):
     g = synth.Genome(1, 50_000, 2)
     ctx.genome_upload(g.names, g.ascii_contigs())
     ok = synth.make_reads(g, 50, 1, read_len=150, window=100, p_sc=1.0, clip_min=10, clip_max=20)
-    with pytest.raises(fade_amd.FadeHipError) as e:
-        ctx.annotate(ok, 5, 9000)  # window beyond max_ref_len
-    assert e.value.code == -5
+    # a window beyond max_ref_len does not fail the batch: the read stays un-re-aligned (rs keeps sc / sup) and is counted
+    small = fade_amd.Context(device=0, max_ref_len=8192)
+    try:
+        small.genome_upload(g.names, g.ascii_contigs())
+        rs, aln, stats = small.annotate(ok, 5, 9000)
+        n_clipped = int(((ok["flag"] & 4) == 0).sum())
+        assert small.last_oversize == n_clipped and len(aln) == 0
+        assert set(int(x) for x in rs) <= {0, 1, 33} and int(stats[0]) == 50 and int(stats[4]) == 0
+    finally:
+        small.close()
+    # the default (2^20) sends such windows to the thread-per-alignment kernel instead
+    rs, aln, stats = ctx.annotate(synth.take(ok, np.arange(6)), 5, 9000)
+    assert ctx.last_oversize == 0 and len(aln) == int(((ok["flag"][:6] & 4) == 0).sum())
     bad = dict(ok)
     bad["tid"] = np.where((ok["flag"] & 4) == 0, 7, ok["tid"]).astype(np.int32)
     with pytest.raises(fade_amd.FadeHipError) as e:
