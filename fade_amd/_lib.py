@@ -15,6 +15,12 @@ MAX_OPS = 16
 NUM_SLOTS = 4
 ABI_VERSION = 2
 RULES_DEFAULT = 0x7f
+ROW_CLASSES = (4, 6, 8, 10, 12, 14, 16, 20, 24, 32)  # query rows per lane of the wave kernels (fadehip_kernels.hpp class_rows)
+
+
+def row_class(l_seq):
+    """R of the sw_pk_kernel<R, .> instantiation that serves reads of l_seq bases (16 R >= l_seq)."""
+    return next(r for r in ROW_CLASSES if 16 * r >= l_seq)
 
 # every symbol include/fadehip.h declares
 EXPORTS = [
@@ -107,7 +113,7 @@ def load():
     L.fadehip_annotate_submit.argtypes = [vp, C.c_int, C.POINTER(ReadBatch), i32, i32]
     L.fadehip_annotate_collect.argtypes = [vp, C.c_int, C.POINTER(AnnoOut)]
     L.fadehip_sync.argtypes = [vp]
-    L.fadehip_last_run_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_float * 4), C.POINTER(i64 * 4)]
+    L.fadehip_last_run_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_float * 4), C.POINTER(i64 * 6)]
     L.fadehip_stats_allreduce.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here means the .so is stale against include/fadehip.h

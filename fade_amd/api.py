@@ -225,10 +225,10 @@ class Context:
 
     def last_profile(self, slot=0):
         ms = (C.c_float * 4)()
-        cnt = (C.c_int64 * 4)()
+        cnt = (C.c_int64 * 6)()
         self._chk(self._L.fadehip_last_run_profile(self._h, slot, C.byref(ms), C.byref(cnt)))
         return dict(gate_ms=ms[0], forward_ms=ms[1], traceback_ms=ms[2], total_ms=ms[3], alignments=cnt[0],
-                    cells=cnt[1], trace_bytes=cnt[2], algorithmic_bytes=cnt[3])
+                    cells=cnt[1], trace_bytes=cnt[2], algorithmic_bytes=cnt[3], snapshot_bytes=cnt[4], candidates=cnt[5])
 
 
 class PinnedBatch:

@@ -56,12 +56,16 @@ Layout batch_layout(int64_t n, int64_t n_cig, int64_t n_seq) {
 
 struct Slot {
     hipStream_t stream = nullptr;
+    // The score pass fills every wave slot it may use for ~0.8 ms; the small, latency-bound kernels of the other
+    // slots (gate, selection, plan, pass 2, traceback) would wait behind it for a slot each.  So the score pass runs
+    // on a stream whose CU mask leaves a few CUs (one per XCD by default) to everything else.
+    hipStream_t score_stream = nullptr;
     DevBuf in;                       // device mirror of the batch block
     Layout L;                        // layout of the batch in flight
     PinBuf stage;                    // staging for batches that do not come as one canonical block
     const uint8_t *h_base = nullptr; // host block of the batch in flight (the caller's or `stage`)
     DevBuf rs, fwd, aln, trace;
-    DevBuf ckpt, cand, incomplete, p2tab;  // two-pass path
+    DevBuf ckpt, cand;  // two-pass path
     // All small counters of a run live in one block so that one memset clears them and one copy brings them to the host.
     // Counters that different kernels (or different atomics of one kernel) hammer sit in different 128-byte lines:
     // same-line atomics serialise in one L2 channel (the gate kernel took 60 instead of 49 us with them packed).
@@ -106,9 +110,9 @@ struct Slot {
     // (start,end) event index pairs of the last run
     std::vector<std::pair<int, int>> fwd_spans, tb_spans;
     int ev_gate0 = -1, ev_gate1 = -1, ev_end = -1;
-    int64_t prof_counts[4] = {0, 0, 0, 0};
+    int64_t prof_counts[6] = {0, 0, 0, 0, 0, 0};
     int64_t n_cand = 0, n_rerun = 0;  // two-pass: candidates traced / candidates re-run from further back
-    int n_reruns_of_batch = 0;        // runs repeated because the trace scratch was too small
+    int p2_last_octs[NUM_CLASSES];    // octets pass 2 served for this class in the slot's previous run (-1: none yet)
 };
 
 }  // namespace
@@ -130,8 +134,9 @@ struct fadehip_ctx {
     // FADEHIP_KERNEL = twopass (default) | pk (single-pass packed int16) | int32 (single-pass int32): A/B runs
     bool use_packed = true;
     bool two_pass = true;
+    int tail_cus_per_xcd = 1;  // FADEHIP_TAIL_CUS: CUs per XCD the score pass leaves alone (0: no CU mask, one stream per slot)
+    int p2_waves_fixed = 0;    // FADEHIP_P2_WAVES: waves of the persistent pass-2 launch (0: adaptive, see run_class_two_pass)
     int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
-    int64_t trace_init_bytes = 0;  // FADEHIP_TRACE_INIT overrides the first size of the pass-2 trace scratch (tests: tiny -> the batch is re-run)
     bool debug = false;
     std::map<uint64_t, int> resident;  // (class, mode, LDS bytes) -> waves of that kernel the device holds at once
     std::mutex resident_mu;
@@ -249,10 +254,10 @@ int new_event(fadehip_ctx *ctx, Slot &s, int *idx) {
     return 0;
 }
 
-int record(fadehip_ctx *ctx, Slot &s, int *idx) {
+int record(fadehip_ctx *ctx, Slot &s, int *idx, hipStream_t on = nullptr) {
     int rc = new_event(ctx, s, idx);
     if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(s.ev[*idx], s.stream));
+    HIPCHK(ctx, hipEventRecord(s.ev[*idx], on ? on : s.stream));
     return 0;
 }
 
@@ -329,10 +334,10 @@ struct ClassRun {
 };
 
 // Two-pass path for one class list, enqueued without a read-back: pass 1 scores every alignment and
-// leaves wave snapshots every CK_COLS steps; the selection keeps the alignments that can still become an artifact call
-// and buckets them by the steps to re-compute; plan_kernel turns the bucket counts into the pass-2 table; pass 2
-// (persistent waves) re-computes those steps with trace; the traceback walks them.  A candidate whose path leaves its
-// traced steps is listed and re-run from further back (two fixed rounds, no-ops when the list is empty).
+// leaves wave snapshots every CK_COLS steps; the selection finishes what needs no DP (non-candidates, forced diagonals),
+// buckets the remaining candidates by the steps to re-compute, and its last block turns the bucket counts into the
+// pass-2 table; pass 2 — ONE persistent launch — re-computes those steps with trace, walks the tracebacks and traces
+// again, from further back, the few paths that left their steps.
 int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c) {
     const int cls = c.cls, R = class_rows(cls), max_lr = c.max_lr, n_items = c.n_bound;
     const int n_ck = (max_lr + 15 + CK_COLS - 1) / CK_COLS;
@@ -350,27 +355,28 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
     const int total_oct = (n_items + 7) / 8;
     const int64_t chunk_oct = std::max<int64_t>(1, std::min<int64_t>(total_oct, (c.budget / 2) / std::max<int64_t>(ck_bytes, 1)));
     int rc;
-    if ((rc = reserve(ctx, s.ckpt, (size_t)(chunk_oct * ck_bytes))) || (rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd))) ||
-        (rc = reserve(ctx, s.p2tab, sizeof(P2Table))))
-        return rc;
-    // trace scratch of pass 2: what a chunk whose candidates all re-compute ~128 steps would need, unless it is already
-    // larger; a plan that needs more reports it and the batch is run again (finish_run)
-    {
-        const int64_t stride128 = (int64_t)((std::min(128, max_lr + 15) + 3) / 4) * R * 64 * 4;
-        int64_t want = ctx->trace_init_bytes > 0 ? ctx->trace_init_bytes
-                                                 : std::min<int64_t>(std::max<int64_t>(c.budget / 2, 1 << 20), (chunk_oct / 2 + NUM_BUCKETS) * stride128);
-        if ((int64_t)s.trace.cap < want && (rc = reserve(ctx, s.trace, (size_t)want))) return rc;
-    }
-    const unsigned long long trace_cap_dwords = s.trace.cap / 4;
+    if ((rc = reserve(ctx, s.ckpt, (size_t)(chunk_oct * ck_bytes))) || (rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd)))) return rc;
+    // Pass 2 is a persistent launch; a wave traces into its own scratch region, sized for a whole window (a path that
+    // left its steps is traced again from step 0).  How many waves: what the previous batch of this class needed (its
+    // octets are known by the time its results are fetched), twice over, within what the device holds at once; before
+    // any batch has run, a moderate guess.  Few waves cost time only when candidates abound; many cost time always,
+    // because each must find a wave slot next to the other slots' score passes before it can see that nothing is left.
+    const uint64_t wave_stride = (uint64_t)n_blocks1 * R * 64;  // dwords
+    const int resident = resident_waves(ctx, cls, mode2, lds1);
+    const int bound_waves = (int)std::min<int64_t>(chunk_oct + NUM_BUCKETS, resident);
+    int p2_waves = s.p2_last_octs[cls] >= 0 ? std::min(2 * s.p2_last_octs[cls] + 64, bound_waves) : std::min(1024, bound_waves);
+    if (ctx->p2_waves_fixed > 0) p2_waves = std::min(ctx->p2_waves_fixed, bound_waves);
+    // ... and within the scratch the budget allows
+    p2_waves = (int)std::max<int64_t>(1, std::min<int64_t>(p2_waves, (c.budget / 2) / std::max<int64_t>((int64_t)wave_stride * 4, 1)));
+    if ((rc = reserve(ctx, s.trace, (size_t)p2_waves * (size_t)wave_stride * 4))) return rc;
+    s.prof_counts[2] = std::max<int64_t>(s.prof_counts[2], (int64_t)p2_waves * (int64_t)wave_stride * 4);
     uint32_t *const sel_counters = s.d_sel(cls);
     for (int64_t o0 = 0; o0 < total_oct; o0 += chunk_oct) {
         const int octs = (int)std::min<int64_t>(chunk_oct, total_oct - o0);
         const int i0 = (int)(o0 * 8);
         const int n = std::min(n_items - i0, octs * 8);
-        if ((rc = reserve(ctx, s.cand, sizeof(Cand) * (size_t)NUM_BUCKETS * (size_t)n)) ||
-            (rc = reserve(ctx, s.incomplete, sizeof(Cand) * (size_t)n)))
-            return rc;
-        if (!s.sel_fresh[cls]) HIPCHK(ctx, hipMemsetAsync(sel_counters, 0, sizeof(uint32_t) * (NUM_BUCKETS + 1), st));
+        if ((rc = reserve(ctx, s.cand, sizeof(Cand) * (size_t)NUM_BUCKETS * (size_t)n))) return rc;
+        if (!s.sel_fresh[cls]) HIPCHK(ctx, hipMemsetAsync(sel_counters, 0, sizeof(uint32_t) * NUM_BUCKETS, st));
         s.sel_fresh[cls] = false;
         SwArgs a;
         memset(&a, 0, sizeof a);
@@ -389,102 +395,56 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
         a.n_ck = n_ck;
         a.count_dev = c.count_dev;
         a.item_base = (uint32_t)i0;
-        a.tab_dev = nullptr;
-        a.ticket = nullptr;
+        // the selection rides in the score pass's waves
+        a.sel.enabled = 1;
+        a.sel.meta = c.meta ? c.meta + i0 : nullptr;
+        a.sel.floor_len = c.floor_len;
+        a.sel.trace_all = ctx->prm.trace_all;
+        a.sel.span_slack = ctx->span_slack;
+        a.sel.cand = (Cand *)s.cand.p;
+        a.sel.cap = (uint32_t)n;
+        a.sel.bucket_n = sel_counters;
+        a.sel.out = c.out + i0;
+        a.sel.rs = c.rs;
+        a.sel.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+        a.sel.gate = c.gate;
+        a.sel.match = getenv("FADEHIP_NO_SHORTCUT") ? 0 : ctx->sc.match;  // read per run: a test flips it on a live ctx
+        a.sel.mismatch = ctx->sc.mismatch;
         int e0 = -1, e1 = -1, e2 = -1;
-        if (c.timed && (rc = record(ctx, s, &e0))) return rc;
-        if ((rc = launch_pk_mode(ctx, cls, 1, a, octs, lds1, st))) return rc;
-        if (c.timed && (rc = record(ctx, s, &e1))) return rc;
-        SelArgs sel;
-        memset(&sel, 0, sizeof sel);
-        sel.work = c.work + i0;
-        sel.meta = c.meta ? c.meta + i0 : nullptr;
-        sel.fwd = (const Fwd *)s.fwd.p + i0;
-        sel.n_items = n;
-        sel.floor_len = c.floor_len;
-        sel.trace_all = ctx->prm.trace_all;
-        sel.R = R;
-        sel.span_slack = ctx->span_slack;
-        sel.cand = (Cand *)s.cand.p;
-        sel.cap = (uint32_t)n;
-        sel.bucket_n = sel_counters;
-        sel.out = c.out + i0;
-        sel.q_nib = c.q_nib;
-        sel.r_nib = c.r_nib;
-        sel.rs = c.rs;
-        sel.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
-        sel.gate = c.gate;
-        sel.match = getenv("FADEHIP_NO_SHORTCUT") ? 0 : ctx->sc.match;  // read per run: a test flips it on a live ctx
-        sel.rules = ctx->sc.rules;
-        sel.count_dev = c.count_dev;
-        sel.item_base = (uint32_t)i0;
-        hipLaunchKernelGGL(select_kernel, dim3((n + SELECT_BLOCK - 1) / SELECT_BLOCK), dim3(SELECT_BLOCK), 0, st, sel);
-        HIPCHK(ctx, hipGetLastError());
-        // pass 2: every bucket in ONE persistent forward launch and ONE traceback launch
-        auto pass2 = [&](const Cand *cand, bool rerun, int back, bool may_be_incomplete) -> int {
-            PlanArgs pa;
-            memset(&pa, 0, sizeof pa);
-            pa.bucket_n = rerun ? nullptr : sel_counters;
-            pa.incomplete_n = sel_counters + NUM_BUCKETS;
-            pa.incomplete = (const Cand *)s.incomplete.p;
-            pa.again = (Cand *)s.cand.p;  // the bucket lists are consumed by then, reuse their storage
-            pa.back = back;
-            for (int b = 0; b < NUM_BUCKETS; b++) pa.steps_max[b] = rerun ? max_lr + 15 : std::min(bucket_cols(b), max_lr + 15);
-            pa.n_buckets = rerun ? 1 : NUM_BUCKETS;
-            pa.R = R;
-            pa.cap = (uint32_t)n;
-            const uint32_t oct_bound = (uint32_t)((n + 7) / 8) + (rerun ? 0u : (uint32_t)NUM_BUCKETS);
-            pa.oct_bound = oct_bound;
-            pa.trace_cap_dwords = trace_cap_dwords;
-            pa.tab = (P2Table *)s.p2tab.p;
-            pa.plan = s.d_plan();
-            hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, st, pa);
-            HIPCHK(ctx, hipGetLastError());
-            if (s.tickets_used >= (int)Slot::N_TICKETS)
-                return set_err(ctx, FADEHIP_E_UNSUPPORTED, "more than %d pass-2 launches in one run (raise trace_bytes)", (int)Slot::N_TICKETS);
-            SwArgs b2 = a;
-            b2.n_items = 0;
-            b2.cand = cand;
-            b2.trace = (uint32_t *)s.trace.p;
-            b2.count_dev = nullptr;
-            b2.tab_dev = (const P2Table *)s.p2tab.p;
-            b2.ticket = s.d_ticket(s.tickets_used++);
-            // a re-run round serves the handful of paths the span estimate missed: a few waves are plenty
-            const int waves = (int)std::min<uint32_t>(oct_bound, (uint32_t)(rerun ? 2 * ctx->cu_count : resident_waves(ctx, cls, mode2, lds1)));
-            int r2 = launch_pk_mode(ctx, cls, mode2, b2, std::max(waves, 1), lds1, st);
-            if (r2) return r2;
-            TbArgs t;
-            memset(&t, 0, sizeof t);
-            t.work = c.work + i0;
-            t.meta = c.meta ? c.meta + i0 : nullptr;
-            t.fwd = (const Fwd *)s.fwd.p + i0;
-            t.n_items = (int)oct_bound * 8;
-            t.R = R;
-            t.q_nib = c.q_nib;
-            t.r_nib = c.r_nib;
-            t.trace = (const uint32_t *)s.trace.p;
-            t.quad_stride = 0;
-            t.sc = ctx->sc;
-            t.out = c.out + i0;
-            t.rs = c.rs;
-            t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
-            t.floor_len = c.floor_len;
-            t.gate = c.gate;
-            t.early_out = (c.gate && c.meta && !ctx->prm.trace_all) ? 1 : 0;
-            t.packed = 1;
-            t.cand = cand;
-            t.incomplete = may_be_incomplete ? (Cand *)s.incomplete.p : nullptr;
-            t.incomplete_n = sel_counters + NUM_BUCKETS;
-            t.tab_dev = (const P2Table *)s.p2tab.p;
-            hipLaunchKernelGGL(traceback_kernel, dim3((oct_bound * 8 + 63) / 64), dim3(64), 0, st, t);
-            HIPCHK(ctx, hipGetLastError());
-            return 0;
-        };
-        if ((rc = pass2((const Cand *)s.cand.p, false, 0, true))) return rc;
-        // candidates whose path left the traced steps: from four snapshots further back (a lone wave is pure latency,
-        // ~0.4 us per step, and most paths miss by a few columns), then from step 0
-        if ((rc = pass2((const Cand *)s.cand.p, true, 4 * CK_COLS, true))) return rc;
-        if ((rc = pass2((const Cand *)s.cand.p, true, 1 << 30, false))) return rc;
+        // the score pass goes to the slot's CU-masked stream (fork / join by events); its timing events are recorded there
+        hipStream_t sst = s.score_stream ? s.score_stream : st;
+        if (sst != st) {
+            int ef = -1;
+            if ((rc = record(ctx, s, &ef, st))) return rc;
+            HIPCHK(ctx, hipStreamWaitEvent(sst, s.ev[ef], 0));
+        }
+        if (c.timed && (rc = record(ctx, s, &e0, sst))) return rc;
+        if ((rc = launch_pk_mode(ctx, cls, 1, a, octs, lds1, sst))) return rc;
+        if ((c.timed || sst != st) && (rc = record(ctx, s, &e1, sst))) return rc;
+        if (sst != st) HIPCHK(ctx, hipStreamWaitEvent(st, s.ev[e1], 0));
+        // pass 2 + tracebacks + re-traced paths: one persistent launch
+        if (s.tickets_used >= (int)Slot::N_TICKETS)
+            return set_err(ctx, FADEHIP_E_UNSUPPORTED, "more than %d pass-2 launches in one run (raise trace_bytes)", (int)Slot::N_TICKETS);
+        SwArgs b2 = a;
+        b2.sel.enabled = 0;
+        b2.n_items = 0;
+        b2.cand = (const Cand *)s.cand.p;
+        b2.cand_cap = (uint32_t)n;
+        b2.bucket_n = sel_counters;
+        b2.cand_total = &s.d_plan()->cand_total;
+        b2.trace = (uint32_t *)s.trace.p;
+        b2.quad_stride = wave_stride;
+        b2.count_dev = nullptr;
+        b2.ticket = s.d_ticket(s.tickets_used++);
+        b2.meta = c.meta ? c.meta + i0 : nullptr;
+        b2.out = c.out + i0;
+        b2.rs = c.rs;
+        b2.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+        b2.floor_len = c.floor_len;
+        b2.gate = c.gate;
+        b2.early_out = (c.gate && c.meta && !ctx->prm.trace_all) ? 1 : 0;
+        b2.rerun_total = &s.d_plan()->rerun_total;
+        if ((rc = launch_pk_mode(ctx, cls, mode2, b2, std::min(p2_waves, octs + NUM_BUCKETS), lds1, st))) return rc;
         if (c.timed) {
             if ((rc = record(ctx, s, &e2))) return rc;
             s.fwd_spans.push_back({e0, e1});
@@ -849,34 +809,22 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
         s.state = 3;
         return 0;
     }
-    for (int attempt = 0;; attempt++) {
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        const uint32_t errbits = s.h_counters()[2 * NUM_LISTS];
-        if (errbits) {
-            s.state = 1;
-            if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
-            if (errbits & 16u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a record whose cigar.alignedLength exceeds ref_span_bound=%lld", (long long)s.span_bound);
-            if (errbits & 32u) return set_err(ctx, FADEHIP_E_STATE, "internal: a work list outgrew the bound its launches were sized from");
-            return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
-        }
-        const PlanOut *po = s.h_plan();
-        if (po->bound_violated) {
-            s.state = 1;
-            return set_err(ctx, FADEHIP_E_STATE, "internal: a pass-2 plan outgrew the bound its launches were sized from");
-        }
-        if (!po->overflow) break;
-        if (attempt >= 4) {
-            s.state = 1;
-            return set_err(ctx, FADEHIP_E_NOMEM, "pass-2 trace scratch still too small after %d re-runs", attempt);
-        }
-        // the traced re-computation needed more scratch than the slot held: grow it and run the batch again
-        const size_t need = (size_t)po->need_dwords * 4;
-        if (ctx->debug) fprintf(stderr, "[fadehip] slot %d: trace scratch %zu B too small, %zu B needed: batch re-run\n", slot, s.trace.cap, need);
-        int rc = reserve(ctx, s.trace, need + need / 4);
-        if (rc) return rc;
-        s.n_reruns_of_batch++;
-        if ((rc = enqueue_run(ctx, s))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    const uint32_t errbits = s.h_counters()[2 * NUM_LISTS];
+    if (errbits) {
+        s.state = 1;
+        if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
+        if (errbits & 16u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a record whose cigar.alignedLength exceeds ref_span_bound=%lld", (long long)s.span_bound);
+        if (errbits & 32u) return set_err(ctx, FADEHIP_E_STATE, "internal: a work list outgrew the bound its launches were sized from");
+        return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
     }
+    for (int c = 0; c < NUM_CLASSES; c++)  // what pass 2 served: sizes the next run's persistent launch
+        if (s.bound[c]) {
+            const uint32_t *bn = (const uint32_t *)(s.h_zb + Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * (size_t)c);
+            int octs = 0;
+            for (int b = 0; b < NUM_BUCKETS; b++) octs += (int)((bn[b] + 7) / 8);
+            s.p2_last_octs[c] = octs;
+        }
     // live entries of each list; several lists leave holes between their segments of the result block: close them
     fadehip_aln *aln = (fadehip_aln *)(s.res.p + s.res_aln_off);
     uint32_t at = 0;
@@ -897,10 +845,11 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
     s.n_rerun = (int64_t)po->rerun_total;
     s.prof_counts[0] = at;
     s.prof_counts[1] = (int64_t)s.h_counters64()[0 * C64_STRIDE];
-    if (ctx->two_pass) s.prof_counts[2] = (int64_t)po->need_dwords * 4;
     // algorithmic bytes of the dominant kernel: SURVEY §8(d)'s packed query + packed window + 16 B
     // descriptor + 64 B result slot per alignment
     s.prof_counts[3] = (int64_t)s.h_counters64()[1 * C64_STRIDE] + (int64_t)at * 80;
+    s.prof_counts[4] = ctx->two_pass ? (int64_t)s.h_counters64()[2 * C64_STRIDE] : (int64_t)(s.h_counters64()[0 * C64_STRIDE] / 2);
+    s.prof_counts[5] = s.n_cand;
     if (ctx->debug)
         fprintf(stderr, "[fadehip] slot %d: %d reads, %u alignments, %lld candidates traced, %lld re-run, trace need %lld B\n", slot, n, at,
                 (long long)s.n_cand, (long long)s.n_rerun, (long long)s.prof_counts[2]);
@@ -1001,7 +950,8 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         return fail(FADEHIP_E_UNSUPPORTED);
     }
     if (const char *kv = getenv("FADEHIP_SPAN_SLACK")) ctx->span_slack = atoi(kv);
-    if (const char *kv = getenv("FADEHIP_TRACE_INIT")) ctx->trace_init_bytes = atoll(kv);
+    if (const char *kv = getenv("FADEHIP_TAIL_CUS")) ctx->tail_cus_per_xcd = std::max(0, std::min(atoi(kv), 8));
+    if (const char *kv = getenv("FADEHIP_P2_WAVES")) ctx->p2_waves_fixed = std::max(0, atoi(kv));
     ctx->debug = getenv("FADEHIP_DEBUG") != nullptr;
     uint8_t table[256];
     fill_ascii_table(table);
@@ -1011,7 +961,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     }
     static_assert(sizeof(uint32_t) * (2 * NUM_LISTS + 3) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
     static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
-    static_assert(sizeof(uint32_t) * (NUM_BUCKETS + 1) <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
+    static_assert(sizeof(uint32_t) * NUM_BUCKETS <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     static_assert(sizeof(PlanOut) <= 128, "PlanOut overflows its slice");
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
@@ -1021,6 +971,30 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
             return fail(FADEHIP_E_HIP);
         }
         memset(s.h_zb, 0, Slot::ZB_BYTES);
+        for (int c = 0; c < NUM_CLASSES; c++) s.p2_last_octs[c] = -1;
+        if (ctx->tail_cus_per_xcd > 0 && ctx->cu_count >= 64 && ctx->cu_count % 32 == 0) {
+            // Bits 33 k + 8 j, k = 0..7, j < tail CUs per XCD: one CU in each of the 8 XCDs whether the mask counts CUs
+            // XCD-interleaved (bit i -> XCD i % 8) or XCD by XCD (bit i -> XCD i / 32); everything else is enabled.
+            std::vector<uint32_t> mask((size_t)ctx->cu_count / 32, 0xffffffffu);
+            for (int x = 0; x < 8 && 33 * x < ctx->cu_count; x++)
+                for (int j = 0; j < ctx->tail_cus_per_xcd && j < 3; j++) {
+                    const int bit = 33 * x + 8 * j;
+                    if (bit < ctx->cu_count) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+                }
+            if (const char *kv = getenv("FADEHIP_CU_MASK")) {  // experiments: comma-separated hex words, lowest CUs first
+                size_t w = 0;
+                for (const char *q = kv; *q && w < mask.size(); w++) {
+                    mask[w] = (uint32_t)strtoul(q, nullptr, 16);
+                    q = strchr(q, ',');
+                    if (!q) { w++; break; }
+                    q++;
+                }
+            }
+            if (hipExtStreamCreateWithCUMask(&s.score_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                s.score_stream = nullptr;  // no CU masks on this stack: the score pass stays on the slot's stream
+            }
+        }
     }
     *out = ctx;
     return 0;
@@ -1032,7 +1006,7 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
-        for (DevBuf *b : {&s.in, &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.incomplete, &s.p2tab, &s.lrows}) release(*b);
+        for (DevBuf *b : {&s.in, &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.lrows}) release(*b);
         for (int c = 0; c < NUM_LISTS; c++) {
             release(s.work[c]);
             release(s.meta[c]);
@@ -1041,6 +1015,7 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         release(s.res);
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
         if (s.h_zb) (void)hipHostFree(s.h_zb);
+        if (s.score_stream) (void)hipStreamDestroy(s.score_stream);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     release(ctx->genome);
@@ -1155,7 +1130,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         }
     }
     const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)4 << 30);
-    for (int attempt = 0;; attempt++) {
+    {
         size_t base = 0;
         s.fwd_spans.clear();
         s.tb_spans.clear();
@@ -1190,15 +1165,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
             }
             base += lists[c].size();
         }
-        HIPCHK(ctx, hipMemcpyAsync(s.h_zb, s.zblock.p, Slot::ZB_BYTES, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        const PlanOut *po = s.h_plan();
-        if (po->bound_violated) return set_err(ctx, FADEHIP_E_STATE, "internal: a pass-2 plan outgrew the bound its launches were sized from");
-        if (!po->overflow) break;
-        if (attempt >= 4) return set_err(ctx, FADEHIP_E_NOMEM, "pass-2 trace scratch still too small after %d re-runs", attempt);
-        const size_t need = (size_t)po->need_dwords * 4;
-        if (ctx->debug) fprintf(stderr, "[fadehip] sw_batch: trace scratch %zu B too small, %zu B needed: batch re-run\n", s.trace.cap, need);
-        if ((rc = reserve(ctx, s.trace, need + need / 4))) return rc;
     }
     s.state = 0;  // slot 0's level-2 buffers were borrowed
     std::vector<fadehip_aln> h_aln(n_work);
@@ -1347,7 +1314,6 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));
     s.floor_len = floor_len;
     s.window = window;
-    s.n_reruns_of_batch = 0;
     if (s.n_reads == 0) {
         s.ev_gate0 = s.ev_gate1 = s.ev_end = -1;
         memset(s.prof_counts, 0, sizeof s.prof_counts);
@@ -1417,14 +1383,14 @@ int fadehip_sync(fadehip_ctx *ctx) {
     return 0;
 }
 
-int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[4]) {
+int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[6]) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
     if (s.state != 3) return set_err(ctx, FADEHIP_E_STATE, "slot %d has no collected run", slot);
     if (!ms || !counts) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
     ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
-    for (int k = 0; k < 4; k++) counts[k] = s.prof_counts[k];
+    for (int k = 0; k < 6; k++) counts[k] = s.prof_counts[k];
     if (s.ev_end < 0) return 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipEventSynchronize(s.ev[s.ev_end]));

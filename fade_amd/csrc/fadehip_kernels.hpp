@@ -14,7 +14,7 @@
 // coalesced 256-byte stores.
 //
 // Default pipeline (two-pass):
-//   gate_kernel -> sw_pk_kernel<R,1> (score + end cell + wave snapshots) -> select_kernel (who needs a CIGAR,
+//   gate_kernel -> sw_pk_kernel<R,1> (score + end cell + wave snapshots; each wave then selects: who needs a CIGAR,
 //   from which step) -> sw_pk_kernel<R,2> (traced re-computation of those steps) -> traceback_kernel (CIGAR,
 //   FADE's gates, rs bits).  The stats.d:45-54 counters are summed on the way: gate_kernel counts reads, clipped
 //   and supplementary ones, traceback_kernel the artifact calls.  sw_pk_kernel<R,0> and sw_forward_kernel<R> are the single-pass
@@ -165,7 +165,7 @@ struct GateArgs {
     unsigned long long *stats;       // stats.d:45-54: [0] read_count, [1] clipped, [2] sup (the artifact counters come from traceback_kernel)
 };
 
-constexpr int GATE_BLOCK = 1024;
+constexpr int GATE_BLOCK = 256;  // small blocks find room next to another slot's score pass; a block orders its items by window length
 __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // per-thread contribution to the batch counters; reduced per wave before touching memory
@@ -331,18 +331,27 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
 }
 
 // ---------------------------------------------------------------- forward SW with trace
-// Pass 2 runs all buckets in one launch, longest first (the dispatcher hands waves out in order, so the short
-// ones fill the tail): wave `oct` belongs to table slot k with oct_first[k] <= oct < oct_first[k+1]; its
-// candidates are cand[bucket[k] * cap + 8 * (oct - oct_first[k]) ...] and its trace scratch starts at
-// trace_base[k] + (oct - oct_first[k]) * stride[k] dwords.
-struct P2Table {
-    uint32_t oct_first[NUM_BUCKETS + 1];
-    uint32_t count[NUM_BUCKETS];
-    uint32_t bucket[NUM_BUCKETS];
-    uint64_t trace_base[NUM_BUCKETS];
-    uint64_t stride[NUM_BUCKETS];
+// Pass 2 runs all buckets in one persistent launch, longest first.  Each wave turns the selection's bucket counts into
+// the table itself: octet `oct` (a ticket) belongs to slot k with oct_first[k] <= oct < oct_first[k+1], bucket
+// NUM_BUCKETS - 1 - k; its candidates are cand[bucket * cap + 8 * (oct - oct_first[k]) ...].  The trace of an octet goes
+// to the scratch region of the WAVE that drew it (blockIdx.x * quad_stride dwords): the scratch is sized by the launch,
+// not by the number of candidates.
+// what the score pass's waves need to finish their alignments on the spot (select_one, below)
+struct SelArgs {
+    const Meta *meta;       // nullptr: level 1, every alignment is traced
+    int32_t floor_len;
+    int32_t trace_all;
+    int32_t span_slack;     // columns added to the expected path span (24; tests shrink it to force re-traced paths)
+    Cand *cand;             // [NUM_BUCKETS][cap]
     uint32_t cap;
-    uint32_t pad;
+    uint32_t *bucket_n;     // [NUM_BUCKETS] candidates per bucket (atomically appended)
+    fadehip_aln *out;
+    uint8_t *rs;
+    unsigned long long *stats;
+    int32_t gate;
+    int32_t match;          // score of a matching pair; 0 switches the forced-diagonal shortcut off
+    int32_t mismatch;
+    int32_t enabled;        // 0: the launch only scores (single-pass A/B kernels never get here)
 };
 
 struct SwArgs {
@@ -364,8 +373,18 @@ struct SwArgs {
     // the device (fadehip_annotate_run never reads a counter back):
     const uint32_t *count_dev;  // MODE 0 / 1: items in the class list (this launch covers [item_base, item_base + n_items) of them); nullptr = n_items is exact
     uint32_t item_base;
-    const P2Table *tab_dev;     // MODE 2: built by plan_kernel from the selection's bucket counts
+    SelArgs sel;                // MODE 1: the selection, done by the wave that scored the alignment
+    const uint32_t *bucket_n;   // MODE 2: [NUM_BUCKETS] candidates per bucket, as the selection left them
+    uint32_t cand_cap;          // MODE 2: entries per bucket of `cand`
     uint32_t *ticket;           // MODE 2: the waves of the launch draw octets from this counter until the table is exhausted
+    unsigned long long *cand_total;  // MODE 2: + candidates of this launch (by the wave that draws ticket 0)
+    // MODE 2 walks the traceback of an octet's candidates right after tracing them (same wave, trace still in L2)
+    const Meta *meta;           // nullptr for level 1
+    fadehip_aln *out;
+    uint8_t *rs;
+    unsigned long long *stats;
+    int32_t floor_len, gate, early_out;
+    unsigned long long *rerun_total;  // candidates whose path left the traced steps and were traced again from further back
 };
 
 #define DPP_ROW_SHR1 0x111
@@ -507,6 +526,463 @@ __global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- traceback + artifact gates
+struct TbArgs {
+    const Work *work;
+    const Meta *meta;       // nullptr for level 1
+    const Fwd *fwd;
+    int32_t n_items;
+    int32_t R;
+    const uint8_t *q_nib, *r_nib;
+    const uint32_t *trace;
+    uint64_t quad_stride;
+    ScoreTab sc;
+    fadehip_aln *out;       // [n_items] at this launch's base
+    uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
+    unsigned long long *stats;  // level 2: stats.d:45-54 [3] art_sup, [4] art, [6] aln_l, [7] aln_r are added here
+    int32_t floor_len;
+    int32_t gate;           // 1: apply analysis.d:69-83,98-107
+    int32_t early_out;      // 1: a path that leaves the traced steps with > 10 ops already is not re-run (see below)
+    int32_t packed;         // trace layout: 0 sw_forward_kernel (quads), 1 packed kernels (octets), 2 sw_long_kernel (per thread)
+    const uint8_t *ltrace;  // packed == 2: cell (i, j) of item k is nibble j & 1 of ltrace[(i * lhalf + j / 2) * n_items + k]
+    int32_t lhalf;          // packed == 2: bytes per trace row
+    const uint32_t *count_dev;  // items on the list (nullptr = n_items is exact), as in SwArgs
+    uint32_t item_base;
+};
+
+__device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int g, int i, int j) {
+    const int lig = i / R, r = i - lig * R;
+    const int t = j + lig;
+    const int k0 = ((t & 3) * R + r) * 4;
+    const uint32_t wv = tq[((uint64_t)(t >> 2) * (R >> 1) + (k0 >> 5)) * 64 + (g * 16 + lig)];
+    return (wv >> (28 - (k0 & 31))) & 15u;
+}
+
+// Packed trace: [block of 4 steps][R dwords][64 lanes]; dword k of a block holds, for s = 0..3, the cell of step
+// 4*blk + s in row (k + s) % R — four cells of one DP diagonal — at nibble 3 - s of the low / high half (A / B).
+// A traceback that walks a diagonal therefore stays in one dword for up to four steps.
+__device__ __forceinline__ uint32_t trace_nibble_pk(const uint32_t *to, int R, int g, int half, int i, int j) {
+    const int lig = i / R, r = i - lig * R;
+    const int t = j + lig;
+    const int s = t & 3;
+    int k = r - s;
+    if (k < 0) k += R;
+    const uint32_t wv = to[((uint64_t)(t >> 2) * R + k) * 64 + (g * 16 + lig)];
+    return (wv >> (16 * half + 4 * (3 - s))) & 15u;
+}
+
+// 8 consecutive nibbles starting at nibble index n0 of a packed sequence: the two aligned dwords that hold them
+struct Nib8 {
+    uint64_t word;
+    uint64_t byte0;  // byte index of the word's first byte
+};
+__device__ __forceinline__ Nib8 load_nib8(const uint8_t *p, uint64_t n0) {
+    Nib8 r;
+    r.byte0 = (n0 >> 1) & ~3ull;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r.byte0);
+    const uint32_t lo = q[0];
+    // 8 nibbles starting in byte (n0 >> 1) end at most 4 bytes later: the second dword is needed unless they fit
+    const uint32_t hi = (((n0 + 7) >> 1) - r.byte0 >= 4) ? q[1] : 0u;
+    r.word = (uint64_t)lo | ((uint64_t)hi << 32);
+    return r;
+}
+__device__ __forceinline__ uint32_t nib8_at(const Nib8 &w, uint64_t n) {
+    const uint32_t byte = (uint32_t)((w.word >> (8 * ((n >> 1) - w.byte0))) & 0xffu);
+    return (n & 1) ? (byte & 15u) : (byte >> 4);
+}
+
+// One alignment: list entry `src`, traced from sweep step c0 on (0 = from the start) into `tq`, where it occupies group g
+// (16-lane row), half `half`; `item` is its index in the launch (thread-per-alignment trace layout only).
+// Returns the artifact bits it set (bit0 left, bit1 right) | 4 if the read is supplementary | 8 if the path left the
+// traced steps and the alignment must be traced again from further back (nothing is written then).
+__device__ __forceinline__ uint32_t traceback_path(const TbArgs &a, const int src, const int c0, const uint32_t *tq, const int g,
+                                                   const int half, const int item) {
+    const Work w = a.work[src];
+    const Fwd f = a.fwd[src];
+    const int R = a.R;
+    const int lq = (int)w.lq;
+    const bool rcq = w.flags & 1u;
+    const int32_t open = a.sc.open, ext = a.sc.ext;
+    const bool hdir_f_first = rule(a.sc.rules, FADEHIP_RULE_HDIR_DIAG_F_E), eq_by_char = rule(a.sc.rules, FADEHIP_RULE_EQ_BY_CHAR);
+    const bool pad = rule(a.sc.rules, FADEHIP_RULE_PAD_SOFTCLIP), n_eq_n = rule(a.sc.rules, FADEHIP_RULE_N_MATCHES_N);
+    const int op_ref_only = rule(a.sc.rules, FADEHIP_RULE_SAM_GAP_LETTERS) ? 2 : 1, op_query_only = 3 - op_ref_only;  // A.5: 'D' / 'I'
+
+    // Appendix A.4 traceback.  The value of the current cell is carried along (h), so the
+    // ZERO stop needs no stored flag.
+    uint32_t ring[FADEHIP_MAX_OPS];
+    uint32_t first_gen = 0;  // first generated run == last run of the CIGAR
+    int n_runs = 0;
+    int cur_op = -1;
+    uint32_t cur_len = 0;
+    int i = f.end_q, j = f.end_r, state = 0;
+    int32_t h = f.score;
+    bool done = false, left_range = false;  // path ended (H reached 0) / path left the traced steps
+    auto emit = [&](int op) {
+        if (op == cur_op) cur_len++;
+        else {
+            if (cur_op >= 0) {
+                const uint32_t v = (cur_len << 4) | (uint32_t)cur_op;
+                if (n_runs == 0) first_gen = v;
+                ring[n_runs & (FADEHIP_MAX_OPS - 1)] = v;
+                n_runs++;
+            }
+            cur_op = op; cur_len = 1;
+        }
+    };
+    auto in_range = [&](int ii, int jj) { return ii >= 0 && jj >= 0 && !(c0 > 0 && jj + ii / R < c0); };
+    auto nibble = [&](int ii, int jj) -> uint32_t {
+        if (a.packed == 2) {
+            const uint32_t v = a.ltrace[((uint64_t)ii * (uint32_t)a.lhalf + (uint32_t)(jj >> 1)) * (uint32_t)a.n_items + (uint32_t)item];
+            return (jj & 1) ? (v >> 4) : (v & 15u);
+        }
+        return a.packed ? trace_nibble_pk(tq, R, g, half, ii, jj - c0) : trace_nibble(tq, R, g, ii, jj);
+    };
+    constexpr int DIAG_BATCH = 8;
+    while (i >= 0 && j >= 0) {
+        if (c0 > 0 && j + i / R < c0) { left_range = true; break; }  // cell (i, j) was computed at step j + i/R
+        if (state == 0) {
+            // A path is mostly diagonal runs, and every step of this walk is a chain of dependent global loads
+            // (trace nibble, query base, window base).  Fetch the next DIAG_BATCH cells of the diagonal at once and
+            // consume them while the flags say "diagonal": one memory round trip per 8 steps instead of per step.
+            uint32_t nbk[DIAG_BATCH], qck[DIAG_BATCH], rck[DIAG_BATCH];
+            bool vk[DIAG_BATCH];
+            // the batch's 8 query and 8 window bases are 8 consecutive nibbles each: two aligned dwords per
+            // sequence instead of 8 byte loads (this kernel is bound by its scattered memory transactions)
+            const int nv = min(DIAG_BATCH, min(i, j) + 1);  // cells of the batch inside the matrix
+            const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - i) : (uint64_t)w.q_base + (uint32_t)(i - (nv - 1));
+            const uint64_t rn_lo = w.r_base + (uint64_t)(j - (nv - 1));
+            const Nib8 qw = load_nib8(a.q_nib, qn_lo), rw = load_nib8(a.r_nib, rn_lo);
+#pragma unroll
+            for (int k = 0; k < DIAG_BATCH; k++) {
+                const int ii = i - k, jj = j - k;
+                vk[k] = in_range(ii, jj);
+                nbk[k] = 0; qck[k] = 0; rck[k] = 0;
+                if (vk[k]) {
+                    nbk[k] = nibble(ii, jj);
+                    const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
+                    qck[k] = rcq ? lut4(COMP_LUT, qraw) : qraw;
+                    rck[k] = nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k));
+                }
+            }
+            bool stop = false;
+#pragma unroll
+            for (int k = 0; k < DIAG_BATCH; k++) {
+                if (stop) continue;
+                if (!vk[k]) { stop = true; continue; }          // the outer loop re-checks bounds and range
+                if (h == 0) { done = true; stop = true; continue; }
+                if (nbk[k] & 8u) {                               // H != D: H == F (query-only) has priority over E (A.4; bit 4 = "H != E" the other way)
+                    state = ((nbk[k] & 4u) != 0) == hdir_f_first ? 1 : 2;
+                    stop = true;
+                    continue;
+                }
+                const uint32_t cq = lut4(CLASS_LUT, qck[k]), cr = lut4(CLASS_LUT, rck[k]);
+                const int32_t wsc = (cq == 5 || cr == 5) ? 0 : ((cq == cr && (cq != 4 || n_eq_n)) ? a.sc.match : a.sc.mismatch);
+                h -= wsc;
+                emit((eq_by_char ? (qck[k] == rck[k] && qck[k] != 0) : wsc > 0) ? 7 : 8);  // '=' : 'X' by residue equality (A.4)
+                i--; j--;
+            }
+            if (done) break;
+            continue;
+        }
+        const uint32_t nb = nibble(i, j);
+        if (state == 1) {  // E: consumes reference only -> 'D'
+            if (nb & 2u) { h += open; state = 0; } else h += ext;
+            j--;
+            emit(op_ref_only);
+        } else {           // F: consumes query only -> 'I'
+            if (nb & 1u) { h += open; state = 0; } else h += ext;
+            i--;
+            emit(op_query_only);
+        }
+    }
+    if (cur_op >= 0) {
+        const uint32_t v = (cur_len << 4) | (uint32_t)cur_op;
+        if (n_runs == 0) first_gen = v;
+        ring[n_runs & (FADEHIP_MAX_OPS - 1)] = v;
+        n_runs++;
+    }
+
+    if (left_range && !(state == 0 && h == 0) && a.early_out && n_runs + ((pad && lq - 1 - f.end_q > 0) ? 1 : 0) > 10) {
+        // The path continues before step T0, but it already has more than 10 ops and can only gain more:
+        // analysis.d:69-70 rejects it whatever the rest looks like.  Report it like an untraced alignment.
+        fadehip_aln o;
+        o.read_idx = (int32_t)w.idx;
+        o.art = 0;
+        o.sw.score = f.score;
+        o.sw.end_query = f.end_q;
+        o.sw.end_ref = f.end_r;
+        o.sw.beg_query = o.sw.beg_ref = -1;
+        o.sw.n_ops = 0;
+#pragma unroll
+        for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+        const Meta m = a.meta[src];
+        o.win_start = m.win_start;
+        o.win_len = (int32_t)w.lr;
+        o.clip_left = m.clip_left;
+        o.clip_right = m.clip_right;
+        o.aligned_len = m.aligned_len;
+        a.out[src] = o;
+        return 0u;
+    }
+    if (left_range && !(state == 0 && h == 0)) return 8u;  // the path continues before step T0: trace again from further back
+    uint32_t art_ret = 0;
+    fadehip_aln o;
+    o.read_idx = (int32_t)w.idx;
+    o.art = 0;
+    o.sw.score = f.score;
+    o.sw.end_query = f.end_q;
+    o.sw.end_ref = f.end_r;
+    o.sw.beg_query = i + 1;
+    o.sw.beg_ref = j + 1;
+    // Appendix A.6: [beg_query S] + runs (front = last generated) + [(lq-1-end_query) S]
+    int n = 0;
+    uint32_t first_op = 0, last_op = 0;
+#pragma unroll
+    for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+    if (pad && o.sw.beg_query > 0) {
+        first_op = ((uint32_t)o.sw.beg_query << 4) | 4u;
+        o.sw.ops[0] = first_op;
+        n = 1;
+    }
+    for (int k = 0; k < n_runs; k++) {  // k-th run of the CIGAR = generated run n_runs-1-k
+        if (k < FADEHIP_MAX_OPS) {
+            const uint32_t v = ring[(n_runs - 1 - k) & (FADEHIP_MAX_OPS - 1)];
+            if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = v;
+            if (n == 0) first_op = v;
+        }
+        n++;
+    }
+    if (n_runs > 0) last_op = first_gen;
+    const int tail = lq - 1 - f.end_q;
+    if (pad && tail > 0) {
+        last_op = ((uint32_t)tail << 4) | 4u;
+        if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = last_op;
+        n++;
+    }
+    o.sw.n_ops = n;
+
+    if (a.meta) {
+        const Meta m = a.meta[src];
+        o.win_start = m.win_start;
+        o.win_len = (int32_t)w.lr;
+        o.clip_left = m.clip_left;
+        o.clip_right = m.clip_right;
+        o.aligned_len = m.aligned_len;
+        if (a.gate && n >= 1 && n <= 10) {  // analysis.d:69-70
+            const uint32_t lead_s = (first_op & 15u) == 4u ? (first_op >> 4) : 0u;
+            const uint32_t trail_s = (n > 1 && (last_op & 15u) == 4u) ? (last_op >> 4) : 0u;
+            // analysis.d:34,74-80: left clip longer than the floor, last op '=', score > 1.8*clip
+            // (float cutoff == integer 5*score > 9*clip, SURVEY.md §8d), result has leading S only
+            if (m.clip_left != 0 && m.clip_left > a.floor_len && (last_op & 15u) == 7u &&
+                5 * (int64_t)f.score > 9 * (int64_t)m.clip_left && trail_s == 0 && lead_s != 0)
+                o.art |= 1;
+            // analysis.d:34,98-104
+            if (m.clip_right != 0 && m.clip_right > a.floor_len && (first_op & 15u) == 7u &&
+                5 * (int64_t)f.score > 9 * (int64_t)m.clip_right && lead_s == 0 && trail_s != 0)
+                o.art |= 2;
+            if (o.art) {  // readstatus.d: bit1 art_left, bit2 art_right
+                const uint8_t before = a.rs[w.idx];
+                a.rs[w.idx] = before | (uint8_t)(o.art << 1);
+                art_ret = (uint32_t)o.art | ((before & 32u) ? 4u : 0u);
+            }
+        }
+    } else {
+        o.win_start = 0;
+        o.win_len = (int32_t)w.lr;
+        o.clip_left = o.clip_right = o.aligned_len = 0;
+    }
+    a.out[src] = o;
+    return art_ret;
+}
+
+// stats.d:45-54, the artifact part, from the per-alignment codes of a wave: per-wave popcounts, one atomic per wave and
+// non-zero counter
+__device__ __forceinline__ void add_artifact_stats(unsigned long long *stats, uint32_t r, uint32_t part) {
+    const unsigned long long m_art = __ballot(r & 3u), m_sup = __ballot((r & 3u) && (r & 4u)), m_l = __ballot(r & 1u), m_r = __ballot(r & 2u);
+    if ((threadIdx.x & 63) == 0 && m_art) {
+        unsigned long long *st = stats + 8 * (part % STAT_PARTS);
+        atomicAdd(&st[4], (unsigned long long)__popcll(m_art));
+        if (m_sup) atomicAdd(&st[3], (unsigned long long)__popcll(m_sup));
+        if (m_l) atomicAdd(&st[6], (unsigned long long)__popcll(m_l));
+        if (m_r) atomicAdd(&st[7], (unsigned long long)__popcll(m_r));
+    }
+}
+
+// ---------------------------------------------------------------- pass-2 selection
+// After pass 1 every alignment has score and end cell.  Level 2: only alignments that can still become an
+// artifact call need a CIGAR — left: clip > floor, 5*score > 9*clip and the end cell in the last query row
+// (analysis.d:74-80 needs the last op to be '=' with no trailing S); right: clip > floor, 5*score > 9*clip and
+// end cell above the last row (analysis.d:102-104 needs a trailing S).  Everything else gets its record
+// here with n_ops = 0 ("not traced").  Level 1 (meta == nullptr) traces everything.
+
+// One alignment of the score pass, right after its wave has its score and end cell (a lane per alignment: the dependent
+// loads of the diagonal walk hide behind the sweeps of the SIMD's other waves; as a kernel of its own the selection
+// waited for wave slots next to the other slots' score passes).  Returns the artifact bits it set (bit0 left, bit1
+// right) | 4 if the read is supplementary.
+__device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item, const Work &w, const Fwd &f, const int R,
+                                               const uint8_t *q_nib, const uint8_t *r_nib, const uint32_t rules) {
+    int b = -1;
+    uint32_t art_ret = 0;
+    Cand c;
+    c.src = 0;
+    c.c0 = 0;
+    {
+        bool cand = true;
+        if (a.meta && !a.trace_all) {
+            const Meta m = a.meta[item];
+            const bool left = m.clip_left > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_left &&
+                              f.end_q == (int32_t)w.lq - 1;
+            const bool right = m.clip_right > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_right &&
+                               f.end_q < (int32_t)w.lq - 1;
+            // (without A.6's soft-clip padding no result CIGAR has an S op and analysis.d:78-80 / 102-104 never hold)
+            cand = (left || right) && rule(rules, FADEHIP_RULE_PAD_SOFTCLIP);
+            if (!cand) {
+                fadehip_aln o;
+                o.read_idx = (int32_t)w.idx;
+                o.art = 0;
+                o.win_start = m.win_start;
+                o.win_len = (int32_t)w.lr;
+                o.clip_left = m.clip_left;
+                o.clip_right = m.clip_right;
+                o.aligned_len = m.aligned_len;
+                o.sw.score = f.score;
+                o.sw.end_query = f.end_q;
+                o.sw.end_ref = f.end_r;
+                o.sw.beg_query = -1;
+                o.sw.beg_ref = -1;
+                o.sw.n_ops = 0;
+                for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+                a.out[item] = o;
+            }
+        }
+        // Forced-diagonal shortcut.  Walk back along the end cell's diagonal d_0 = (end_q, end_r), d_1, ... with
+        // P_0 = score, P_{k+1} = P_k - W(d_k).  If the partial sums stay positive and hit exactly 0 at some d_L (a cell,
+        // or the matrix border, where H is 0 by definition), the traceback is forced: H(d_k) >= P_k because the diagonal
+        // chains up from H(d_L) >= 0 (H >= D everywhere), and H(d_k) <= P_k because any excess would chain up to more than
+        // the given H(d_0) = score; so every cell equals its diagonal predecessor + W — the direction the traceback tries
+        // first under either A.4 priority — and it stops at d_L.  CIGAR = [beg_query S] runs of = / X [tail S] with no
+        // DP re-computation.  This is the planted artifact (an exact or near-exact reverse-complement copy), by far the
+        // most common candidate; gapped paths, and the rare ones with more runs than an op array holds, go to pass 2.
+        if (cand && a.match > 0 && f.score > 0) {
+            const bool rcq = w.flags & 1u;
+            const int lq = (int)w.lq;
+            const bool n_eq_n = rule(rules, FADEHIP_RULE_N_MATCHES_N), eq_by_char = rule(rules, FADEHIP_RULE_EQ_BY_CHAR);
+            const bool pad = rule(rules, FADEHIP_RULE_PAD_SOFTCLIP);
+            constexpr int MAX_RUNS = FADEHIP_MAX_OPS - 2;
+            uint32_t runs[MAX_RUNS];  // generated from the end cell backwards
+            int n_runs = 0, cur_op = -1;
+            uint32_t cur_len = 0;
+            int P = f.score, L = 0;
+            bool ok = false, give_up = false;
+            const int kmax = min(f.end_q, f.end_r) + 1;  // cells of the diagonal inside the matrix
+            for (int k0 = 0; k0 < kmax && !ok && !give_up; k0 += 8) {
+                const int nv = min(8, kmax - k0);
+                const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - f.end_q + k0)
+                                           : (uint64_t)w.q_base + (uint32_t)(f.end_q - k0 - (nv - 1));
+                const uint64_t rn_lo = w.r_base + (uint64_t)(f.end_r - k0 - (nv - 1));
+                const Nib8 qw = load_nib8(q_nib, qn_lo), rw = load_nib8(r_nib, rn_lo);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k < nv && !ok && !give_up) {
+                        const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
+                        const uint32_t qc = rcq ? lut4(COMP_LUT, qraw) : qraw, rc = nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k));
+                        const uint32_t cq = lut4(CLASS_LUT, qc), cr = lut4(CLASS_LUT, rc);
+                        const int wsc = (cq == 5 || cr == 5) ? 0 : ((cq == cr && (cq != 4 || n_eq_n)) ? a.match : a.mismatch);
+                        const int op = (eq_by_char ? (qc == rc && qc != 0) : wsc > 0) ? 7 : 8;
+                        if (op == cur_op) cur_len++;
+                        else {
+                            if (cur_op >= 0) {
+                                if (n_runs < MAX_RUNS) runs[n_runs] = (cur_len << 4) | (uint32_t)cur_op;
+                                n_runs++;
+                            }
+                            cur_op = op;
+                            cur_len = 1;
+                        }
+                        P -= wsc;
+                        L = k0 + k + 1;
+                        if (P == 0) ok = true;
+                        else if (P < 0) give_up = true;
+                    }
+                }
+            }
+            if (ok) {
+                if (n_runs < MAX_RUNS) runs[n_runs] = (cur_len << 4) | (uint32_t)cur_op;
+                n_runs++;
+                if (n_runs > MAX_RUNS) ok = false;
+            }
+            if (ok) {
+                cand = false;
+                fadehip_aln o;
+                o.read_idx = (int32_t)w.idx;
+                o.art = 0;
+                o.sw.score = f.score;
+                o.sw.end_query = f.end_q;
+                o.sw.end_ref = f.end_r;
+                o.sw.beg_query = f.end_q - L + 1;
+                o.sw.beg_ref = f.end_r - L + 1;
+                for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+                const int lead = o.sw.beg_query, tail = lq - 1 - f.end_q;
+                int n = 0;
+                uint32_t first_op = 0, last_op = 0;
+                if (pad && lead > 0) o.sw.ops[n++] = ((uint32_t)lead << 4) | 4u;
+                for (int k = n_runs - 1; k >= 0; k--) o.sw.ops[n++] = runs[k];
+                if (pad && tail > 0) o.sw.ops[n++] = ((uint32_t)tail << 4) | 4u;
+                o.sw.n_ops = n;
+                first_op = o.sw.ops[0];
+                last_op = o.sw.ops[n - 1];
+                if (a.meta) {
+                    const Meta m = a.meta[item];
+                    o.win_start = m.win_start;
+                    o.win_len = (int32_t)w.lr;
+                    o.clip_left = m.clip_left;
+                    o.clip_right = m.clip_right;
+                    o.aligned_len = m.aligned_len;
+                    if (a.gate && n <= 10) {  // analysis.d:69-70
+                        const uint32_t lead_s = (first_op & 15u) == 4u ? (first_op >> 4) : 0u;
+                        const uint32_t trail_s = (n > 1 && (last_op & 15u) == 4u) ? (last_op >> 4) : 0u;
+                        // analysis.d:74-80 (last op '=', leading S only) / 98-104 (first op '=', trailing S only)
+                        if (m.clip_left != 0 && m.clip_left > a.floor_len && (last_op & 15u) == 7u && trail_s == 0 && lead_s != 0 &&
+                            5 * (int64_t)f.score > 9 * (int64_t)m.clip_left)
+                            o.art |= 1;
+                        if (m.clip_right != 0 && m.clip_right > a.floor_len && (first_op & 15u) == 7u && lead_s == 0 && trail_s != 0 &&
+                            5 * (int64_t)f.score > 9 * (int64_t)m.clip_right)
+                            o.art |= 2;
+                        if (o.art) {
+                            const uint8_t before = a.rs[w.idx];
+                            a.rs[w.idx] = before | (uint8_t)(o.art << 1);
+                            art_ret = (uint32_t)o.art | ((before & 32u) ? 4u : 0u);
+                        }
+                    }
+                } else {
+                    o.win_start = 0;
+                    o.win_len = (int32_t)w.lr;
+                    o.clip_left = o.clip_right = o.aligned_len = 0;
+                }
+                a.out[item] = o;
+            }
+        }
+        if (cand) {
+            // sweep steps the path is expected to span: a cell (i, j) is computed at step j + i / R.  Columns:
+            // score/2 for clean matches, a quarter more for mismatches, + slack; rows ~ columns.  Any value is
+            // correct (a path that leaves the traced steps is re-run from step 0), this one is cheap.
+            const int span_cols = a.span_slack >= 0 ? f.score / 2 + f.score / 8 + a.span_slack : 1;
+            const int span = span_cols + span_cols / R + 2;
+            const int t_end = f.end_r + f.end_q / R;
+            int c0 = t_end + 1 - span;
+            c0 = c0 < CK_COLS ? 0 : (c0 & ~(CK_COLS - 1));
+            const int steps = t_end + 1 - c0;
+            b = 0;
+            while (steps > bucket_cols(b)) b++;
+            c.src = (uint32_t)item;
+            c.c0 = (uint32_t)c0;
+            const uint32_t slot = atomicAdd(&a.bucket_n[b], 1u);
+            if (slot < a.cap) a.cand[(uint64_t)b * a.cap + slot] = c;
+        }
+    }
+    (void)b;
+    return art_ret;
+}
+
 // ---------------------------------------------------------------- forward SW, packed int16 (two alignments per 16-lane row)
 // Same recurrence as sw_forward_kernel with every DP value scaled by 8 and held as a pair of int16:
 // low half = alignment A, high half = alignment B of the same 16-lane row, so one v_pk_* instruction
@@ -628,44 +1104,52 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // MODE 0 / 1: one octet per wave, blockIdx.x.
     for (bool first_round = true;; first_round = false) {
     int oct = blockIdx.x;
+    uint32_t srcA = 0, srcB = 0, c0A = 0, c0B = 0;
+    bool haveA = false, haveB = false;  // MODE 2: this half holds a candidate that still has to be traced
     if constexpr (P2) {
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(a.ticket, 1u);
         oct = (int)__builtin_amdgcn_readfirstlane(tk);
-        if (oct >= (int)a.tab_dev->oct_first[NUM_BUCKETS]) break;
+        // the table, from the bucket counts (wave-uniform: scalar loads)
+        int first = 0, b = -1, local = 0, n_b = 0;
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < NUM_BUCKETS; k++) {
+            const uint32_t cnt = a.bucket_n[NUM_BUCKETS - 1 - k];  // longest bucket first
+            const int octs_k = (int)((cnt + 7) / 8);
+            if (b < 0 && oct < first + octs_k) { b = NUM_BUCKETS - 1 - k; local = oct - first; n_b = (int)cnt; }
+            first += octs_k;
+            total += cnt;
+        }
+        if (oct == 0 && lane == 0 && total && a.cand_total) atomicAdd(a.cand_total, (unsigned long long)total);
+        if (b < 0) break;  // oct >= number of octets: nothing left
         if (!first_round) __syncthreads();  // the previous octet's window is no longer read
+        const Cand *cl = a.cand + (uint64_t)b * a.cand_cap;
+        const int kA = local * 8 + g * 2, kB = kA + 1;
+        if (kA < n_b) { const Cand c = cl[kA]; srcA = c.src; c0A = c.c0; haveA = true; }
+        if (kB < n_b) { const Cand c = cl[kB]; srcB = c.src; c0B = c.c0; haveB = true; }
     } else {
         if (!first_round || oct * 8 >= n_items) break;
     }
+    // MODE 2: an octet is traced, its tracebacks walked, and the members whose path left the traced steps are traced
+    // again from further back (4 snapshots, then step 0, where no path can leave) — all by the wave that drew it
+    for (int attempt = 0;; attempt++) {
     const int itemA = oct * 8 + g * 2, itemB = itemA + 1;
     Work wa, wb;
     wa.r_base = wb.r_base = 0; wa.q_base = wb.q_base = 0; wa.lq = wb.lq = 0; wa.lr = wb.lr = 0;
     wa.idx = wb.idx = 0; wa.flags = wb.flags = 0; wa.pad = wb.pad = 0;
-    uint32_t srcA = 0, srcB = 0, c0A = 0, c0B = 0;
     int stepsA = 0, stepsB = 0;  // MODE 2: sweep steps to run for each half
-    uint64_t trace_off = (uint64_t)oct * a.quad_stride;
+    const uint64_t trace_off = (uint64_t)(P2 ? (int)blockIdx.x : oct) * a.quad_stride;
     if constexpr (P2) {
-        const P2Table &tab = *a.tab_dev;
-        int b = 0;
-        while (oct >= (int)tab.oct_first[b + 1]) b++;
-        const int local = oct - (int)tab.oct_first[b];
-        trace_off = tab.trace_base[b] + (uint64_t)local * tab.stride[b];
-        const Cand *cl = a.cand + (uint64_t)tab.bucket[b] * tab.cap;
-        const int n_b = (int)tab.count[b];
-        const int kA = local * 8 + g * 2, kB = kA + 1;
         // lane 0 feeds column T0 + tau at relative step tau: the staged "window" is columns [T0, end_ref]
-        if (kA < n_b) {
-            const Cand c = cl[kA];
-            srcA = c.src; c0A = c.c0;
+        if (haveA) {
             wa = a.work[srcA];
             const Fwd f = a.fwd[srcA];
             stepsA = f.end_r + f.end_q / R - (int)c0A + 1;
             wa.lr = (uint32_t)max(0, f.end_r + 1 - (int)c0A);
             wa.r_base += c0A;
         }
-        if (kB < n_b) {
-            const Cand c = cl[kB];
-            srcB = c.src; c0B = c.c0;
+        if (haveB) {
             wb = a.work[srcB];
             const Fwd f = a.fwd[srcB];
             stepsB = f.end_r + f.end_q / R - (int)c0B + 1;
@@ -739,8 +1223,8 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         const int shA = (srcA & 1u) ? 16 : 0, shB = (srcB & 1u) ? 16 : 0;
         auto pick = [&](int k) -> uint32_t {
             uint32_t va = 0, vb = 0;
-            if (c0A) va = (ckA[k * 64] >> shA) & 0xffffu;
-            if (c0B) vb = (ckB[k * 64] >> shB) & 0xffffu;
+            if (haveA && c0A) va = (ckA[k * 64] >> shA) & 0xffffu;
+            if (haveB && c0B) vb = (ckB[k * 64] >> shB) & 0xffffu;
             return va | (vb << 16);
         };
 #pragma unroll
@@ -754,11 +1238,11 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         // the class register of a pass-1 octet holds (7 classA + classB) * 16 of ITS two alignments: take the one
         // this half resumes and pair it with the other half's
         uint32_t ra = PAD_CLASS, rb = PAD_CLASS;
-        if (c0A) {
+        if (haveA && c0A) {
             const uint32_t pr = (ckA[(2 * R + 3) * 64] & 0xffffu) >> 4;
             ra = (srcA & 1u) ? pr % 7u : pr / 7u;
         }
-        if (c0B) {
+        if (haveB && c0B) {
             const uint32_t pr = (ckB[(2 * R + 3) * 64] & 0xffffu) >> 4;
             rb = (srcB & 1u) ? pr % 7u : pr / 7u;
         }
@@ -1018,7 +1502,69 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                 a.fwd[itemB] = f;
             }
         }
+        if constexpr (MODE == 1) {
+            if (a.sel.enabled) {
+                // every lane of a group holds both results after the butterfly: lane 0 finishes alignment A, lane 1 B
+                uint32_t art = 0;
+                const int item = lig ? itemB : itemA;
+                if (lig < 2 && item < n_items) {
+                    const uint64_t cc = lig ? cb : ca;
+                    Fwd f;
+                    f.score = (int32_t)(cc >> 32) / PK_SCALE;
+                    f.end_r = cc ? (int32_t)(0xffff - ((cc >> 16) & 0xffff)) : 0;
+                    f.end_q = cc ? (int32_t)(0xffff - (cc & 0xffff)) : 0;
+                    f.pad = 0;
+                    art = select_one(a.sel, item, lig ? wb : wa, f, R, a.q_nib, a.r_nib, a.sc.rules);
+                }
+                if (a.sel.stats) add_artifact_stats(a.sel.stats, art, blockIdx.x);
+            }
+        }
+        break;
+    } else {
+        // ---- tracebacks of the octet's members, by lanes 0..7 (member e = group e / 2, half e & 1) of this wave
+        __threadfence();  // the trace this wave has just stored is what its lanes read back
+        const int gg = (lane & 7) >> 1, hh = lane & 1;
+        const uint32_t sA = (uint32_t)__shfl((int)srcA, gg * 16, 64), sB = (uint32_t)__shfl((int)srcB, gg * 16, 64);
+        const uint32_t tA = (uint32_t)__shfl((int)c0A, gg * 16, 64), tB = (uint32_t)__shfl((int)c0B, gg * 16, 64);
+        const int hA = __shfl((int)haveA, gg * 16, 64), hB = __shfl((int)haveB, gg * 16, 64);
+        uint32_t code = 0;
+        if (lane < 8 && (hh ? hB : hA)) {
+            TbArgs tb;
+            tb.work = a.work;
+            tb.meta = a.meta;
+            tb.fwd = a.fwd;
+            tb.n_items = 0;
+            tb.R = R;
+            tb.q_nib = a.q_nib;
+            tb.r_nib = a.r_nib;
+            tb.trace = a.trace;
+            tb.quad_stride = a.quad_stride;
+            tb.sc = a.sc;
+            tb.out = a.out;
+            tb.rs = a.rs;
+            tb.stats = a.stats;
+            tb.floor_len = a.floor_len;
+            tb.gate = a.gate;
+            tb.early_out = a.early_out;
+            tb.packed = 1;
+            tb.ltrace = nullptr;
+            tb.lhalf = 0;
+            tb.count_dev = nullptr;
+            tb.item_base = 0;
+            code = traceback_path(tb, (int)(hh ? sB : sA), (int)(hh ? tB : tA), a.trace + trace_off, gg, hh, 0);
+        }
+        if (a.stats) add_artifact_stats(a.stats, code, blockIdx.x);
+        const unsigned long long inc = __ballot(code & 8u);
+        if (inc == 0ull) break;
+        // the members whose path left the traced steps stay, with T0 further back; the others are done
+        haveA = haveA && ((inc >> (2 * g)) & 1ull);
+        haveB = haveB && ((inc >> (2 * g + 1)) & 1ull);
+        c0A = (attempt == 0 && c0A > 4u * CK_COLS) ? c0A - 4u * CK_COLS : 0u;
+        c0B = (attempt == 0 && c0B > 4u * CK_COLS) ? c0B - 4u * CK_COLS : 0u;
+        if (lane == 0 && a.rerun_total) atomicAdd(a.rerun_total, (unsigned long long)__popcll(inc));
+        __syncthreads();  // the octet's window is staged again
     }
+    }  // attempts at this octet
     }  // octets of this wave
 }
 
@@ -1131,596 +1677,25 @@ __global__ __launch_bounds__(64) void sw_long_kernel(LongArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- traceback + artifact gates
-struct TbArgs {
-    const Work *work;
-    const Meta *meta;       // nullptr for level 1
-    const Fwd *fwd;
-    int32_t n_items;
-    int32_t R;
-    const uint8_t *q_nib, *r_nib;
-    const uint32_t *trace;
-    uint64_t quad_stride;
-    ScoreTab sc;
-    fadehip_aln *out;       // [n_items] at this launch's base
-    uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
-    unsigned long long *stats;  // level 2: stats.d:45-54 [3] art_sup, [4] art, [6] aln_l, [7] aln_r are added here
-    int32_t floor_len;
-    int32_t gate;           // 1: apply analysis.d:69-83,98-107
-    int32_t early_out;      // 1: a path that leaves the traced steps with > 10 ops already is not re-run (see below)
-    int32_t packed;         // trace layout: 0 sw_forward_kernel (quads), 1 packed kernels (octets), 2 sw_long_kernel (per thread)
-    const uint8_t *ltrace;  // packed == 2: cell (i, j) of item k is nibble j & 1 of ltrace[(i * lhalf + j / 2) * n_items + k]
-    int32_t lhalf;          // packed == 2: bytes per trace row
-    // two-pass path: thread k serves a candidate whose trace starts at sweep step c0; results go to out[src]
-    const Cand *cand;
-    Cand *incomplete;       // candidates whose path leaves the traced steps ...
-    uint32_t *incomplete_n; // ... are listed here (with the T0 they had) and re-run from further back
-    const P2Table *tab_dev; // with cand: thread k serves slot k & 7 of wave k >> 3 of the table plan_kernel built
-    const uint32_t *count_dev;  // without cand: items on the list (nullptr = n_items is exact), as in SwArgs
-    uint32_t item_base;
-};
-
-__device__ __forceinline__ uint32_t trace_nibble(const uint32_t *tq, int R, int g, int i, int j) {
-    const int lig = i / R, r = i - lig * R;
-    const int t = j + lig;
-    const int k0 = ((t & 3) * R + r) * 4;
-    const uint32_t wv = tq[((uint64_t)(t >> 2) * (R >> 1) + (k0 >> 5)) * 64 + (g * 16 + lig)];
-    return (wv >> (28 - (k0 & 31))) & 15u;
-}
-
-// Packed trace: [block of 4 steps][R dwords][64 lanes]; dword k of a block holds, for s = 0..3, the cell of step
-// 4*blk + s in row (k + s) % R — four cells of one DP diagonal — at nibble 3 - s of the low / high half (A / B).
-// A traceback that walks a diagonal therefore stays in one dword for up to four steps.
-__device__ __forceinline__ uint32_t trace_nibble_pk(const uint32_t *to, int R, int g, int half, int i, int j) {
-    const int lig = i / R, r = i - lig * R;
-    const int t = j + lig;
-    const int s = t & 3;
-    int k = r - s;
-    if (k < 0) k += R;
-    const uint32_t wv = to[((uint64_t)(t >> 2) * R + k) * 64 + (g * 16 + lig)];
-    return (wv >> (16 * half + 4 * (3 - s))) & 15u;
-}
-
-// 8 consecutive nibbles starting at nibble index n0 of a packed sequence: the two aligned dwords that hold them
-struct Nib8 {
-    uint64_t word;
-    uint64_t byte0;  // byte index of the word's first byte
-};
-__device__ __forceinline__ Nib8 load_nib8(const uint8_t *p, uint64_t n0) {
-    Nib8 r;
-    r.byte0 = (n0 >> 1) & ~3ull;
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r.byte0);
-    const uint32_t lo = q[0];
-    // 8 nibbles starting in byte (n0 >> 1) end at most 4 bytes later: the second dword is needed unless they fit
-    const uint32_t hi = (((n0 + 7) >> 1) - r.byte0 >= 4) ? q[1] : 0u;
-    r.word = (uint64_t)lo | ((uint64_t)hi << 32);
-    return r;
-}
-__device__ __forceinline__ uint32_t nib8_at(const Nib8 &w, uint64_t n) {
-    const uint32_t byte = (uint32_t)((w.word >> (8 * ((n >> 1) - w.byte0))) & 0xffu);
-    return (n & 1) ? (byte & 15u) : (byte >> 4);
-}
-
-// one alignment; returns the artifact bits it set (bit0 left, bit1 right) | 4 if the read is supplementary
+// the single-pass kernels' and sw_long_kernel's traceback: a thread per alignment of the launch, traced from step 0
 __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int item) {
-    int src = item, c0 = 0;
-    uint64_t trace_off;
-    if (a.cand) {
-        const P2Table &tab = *a.tab_dev;
-        const int oct = item >> 3;
-        int b = 0;
-        if (oct >= (int)tab.oct_first[NUM_BUCKETS]) return 0u;
-        while (oct >= (int)tab.oct_first[b + 1]) b++;
-        const int local = oct - (int)tab.oct_first[b];
-        const int k = local * 8 + (item & 7);
-        if (k >= (int)tab.count[b]) return 0u;
-        const Cand c = a.cand[(uint64_t)tab.bucket[b] * tab.cap + k];
-        src = (int)c.src;
-        c0 = (int)c.c0;
-        trace_off = tab.trace_base[b] + (uint64_t)local * tab.stride[b];
-    } else {
-        int n_items = a.n_items;
-        if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
-        if (item >= n_items) return 0u;
-        trace_off = (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
-    }
-    const Work w = a.work[src];
-    const Fwd f = a.fwd[src];
-    const int R = a.R;
-    const int g = a.packed ? ((item >> 1) & 3) : (item & 3);
-    const int half = item & 1;
-    const uint32_t *tq = a.trace + trace_off;
-    const int lq = (int)w.lq;
-    const bool rcq = w.flags & 1u;
-    const int32_t open = a.sc.open, ext = a.sc.ext;
-    const bool hdir_f_first = rule(a.sc.rules, FADEHIP_RULE_HDIR_DIAG_F_E), eq_by_char = rule(a.sc.rules, FADEHIP_RULE_EQ_BY_CHAR);
-    const bool pad = rule(a.sc.rules, FADEHIP_RULE_PAD_SOFTCLIP);
-    const int op_ref_only = rule(a.sc.rules, FADEHIP_RULE_SAM_GAP_LETTERS) ? 2 : 1, op_query_only = 3 - op_ref_only;  // A.5: 'D' / 'I'
-
-    // Appendix A.4 traceback.  The value of the current cell is carried along (h), so the
-    // ZERO stop needs no stored flag.
-    uint32_t ring[FADEHIP_MAX_OPS];
-    uint32_t first_gen = 0;  // first generated run == last run of the CIGAR
-    int n_runs = 0;
-    int cur_op = -1;
-    uint32_t cur_len = 0;
-    int i = f.end_q, j = f.end_r, state = 0;
-    int32_t h = f.score;
-    bool done = false, left_range = false;  // path ended (H reached 0) / path left the traced steps
-    auto emit = [&](int op) {
-        if (op == cur_op) cur_len++;
-        else {
-            if (cur_op >= 0) {
-                const uint32_t v = (cur_len << 4) | (uint32_t)cur_op;
-                if (n_runs == 0) first_gen = v;
-                ring[n_runs & (FADEHIP_MAX_OPS - 1)] = v;
-                n_runs++;
-            }
-            cur_op = op; cur_len = 1;
-        }
-    };
-    auto in_range = [&](int ii, int jj) { return ii >= 0 && jj >= 0 && !(c0 > 0 && jj + ii / R < c0); };
-    auto nibble = [&](int ii, int jj) -> uint32_t {
-        if (a.packed == 2) {
-            const uint32_t v = a.ltrace[((uint64_t)ii * (uint32_t)a.lhalf + (uint32_t)(jj >> 1)) * (uint32_t)a.n_items + (uint32_t)item];
-            return (jj & 1) ? (v >> 4) : (v & 15u);
-        }
-        return a.packed ? trace_nibble_pk(tq, R, g, half, ii, jj - c0) : trace_nibble(tq, R, g, ii, jj);
-    };
-    constexpr int DIAG_BATCH = 8;
-    while (i >= 0 && j >= 0) {
-        if (c0 > 0 && j + i / R < c0) { left_range = true; break; }  // cell (i, j) was computed at step j + i/R
-        if (state == 0) {
-            // A path is mostly diagonal runs, and every step of this walk is a chain of dependent global loads
-            // (trace nibble, query base, window base).  Fetch the next DIAG_BATCH cells of the diagonal at once and
-            // consume them while the flags say "diagonal": one memory round trip per 8 steps instead of per step.
-            uint32_t nbk[DIAG_BATCH], qck[DIAG_BATCH], rck[DIAG_BATCH];
-            bool vk[DIAG_BATCH];
-            // the batch's 8 query and 8 window bases are 8 consecutive nibbles each: two aligned dwords per
-            // sequence instead of 8 byte loads (this kernel is bound by its scattered memory transactions)
-            const int nv = min(DIAG_BATCH, min(i, j) + 1);  // cells of the batch inside the matrix
-            const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - i) : (uint64_t)w.q_base + (uint32_t)(i - (nv - 1));
-            const uint64_t rn_lo = w.r_base + (uint64_t)(j - (nv - 1));
-            const Nib8 qw = load_nib8(a.q_nib, qn_lo), rw = load_nib8(a.r_nib, rn_lo);
-#pragma unroll
-            for (int k = 0; k < DIAG_BATCH; k++) {
-                const int ii = i - k, jj = j - k;
-                vk[k] = in_range(ii, jj);
-                nbk[k] = 0; qck[k] = 0; rck[k] = 0;
-                if (vk[k]) {
-                    nbk[k] = nibble(ii, jj);
-                    const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
-                    qck[k] = rcq ? lut4(COMP_LUT, qraw) : qraw;
-                    rck[k] = nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k));
-                }
-            }
-            bool stop = false;
-#pragma unroll
-            for (int k = 0; k < DIAG_BATCH; k++) {
-                if (stop) continue;
-                if (!vk[k]) { stop = true; continue; }          // the outer loop re-checks bounds and range
-                if (h == 0) { done = true; stop = true; continue; }
-                if (nbk[k] & 8u) {                               // H != D: H == F (query-only) has priority over E (A.4; bit 4 = "H != E" the other way)
-                    state = ((nbk[k] & 4u) != 0) == hdir_f_first ? 1 : 2;
-                    stop = true;
-                    continue;
-                }
-                const uint32_t cq = lut4(CLASS_LUT, qck[k]), cr = lut4(CLASS_LUT, rck[k]);
-                const int32_t wsc = (cq == 5 || cr == 5) ? 0 : (cq == cr ? a.sc.match : a.sc.mismatch);
-                h -= wsc;
-                emit((eq_by_char ? (qck[k] == rck[k] && qck[k] != 0) : wsc > 0) ? 7 : 8);  // '=' : 'X' by residue equality (A.4)
-                i--; j--;
-            }
-            if (done) break;
-            continue;
-        }
-        const uint32_t nb = nibble(i, j);
-        if (state == 1) {  // E: consumes reference only -> 'D'
-            if (nb & 2u) { h += open; state = 0; } else h += ext;
-            j--;
-            emit(op_ref_only);
-        } else {           // F: consumes query only -> 'I'
-            if (nb & 1u) { h += open; state = 0; } else h += ext;
-            i--;
-            emit(op_query_only);
-        }
-    }
-    if (cur_op >= 0) {
-        const uint32_t v = (cur_len << 4) | (uint32_t)cur_op;
-        if (n_runs == 0) first_gen = v;
-        ring[n_runs & (FADEHIP_MAX_OPS - 1)] = v;
-        n_runs++;
-    }
-
-    if (left_range && !(state == 0 && h == 0) && a.early_out && n_runs + ((pad && lq - 1 - f.end_q > 0) ? 1 : 0) > 10) {
-        // The path continues before step T0, but it already has more than 10 ops and can only gain more:
-        // analysis.d:69-70 rejects it whatever the rest looks like.  Report it like an untraced alignment.
-        fadehip_aln o;
-        o.read_idx = (int32_t)w.idx;
-        o.art = 0;
-        o.sw.score = f.score;
-        o.sw.end_query = f.end_q;
-        o.sw.end_ref = f.end_r;
-        o.sw.beg_query = o.sw.beg_ref = -1;
-        o.sw.n_ops = 0;
-#pragma unroll
-        for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
-        const Meta m = a.meta[src];
-        o.win_start = m.win_start;
-        o.win_len = (int32_t)w.lr;
-        o.clip_left = m.clip_left;
-        o.clip_right = m.clip_right;
-        o.aligned_len = m.aligned_len;
-        a.out[src] = o;
-        return 0u;
-    }
-    if (left_range && !(state == 0 && h == 0)) {
-        // the path continues before step T0: this candidate is re-run from the start of the sweep
-        const uint32_t k = atomicAdd(a.incomplete_n, 1u);
-        Cand again;
-        again.src = (uint32_t)src;
-        again.c0 = (uint32_t)c0;
-        a.incomplete[k] = again;
-        return 0u;
-    }
-    uint32_t art_ret = 0;
-    fadehip_aln o;
-    o.read_idx = (int32_t)w.idx;
-    o.art = 0;
-    o.sw.score = f.score;
-    o.sw.end_query = f.end_q;
-    o.sw.end_ref = f.end_r;
-    o.sw.beg_query = i + 1;
-    o.sw.beg_ref = j + 1;
-    // Appendix A.6: [beg_query S] + runs (front = last generated) + [(lq-1-end_query) S]
-    int n = 0;
-    uint32_t first_op = 0, last_op = 0;
-#pragma unroll
-    for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
-    if (pad && o.sw.beg_query > 0) {
-        first_op = ((uint32_t)o.sw.beg_query << 4) | 4u;
-        o.sw.ops[0] = first_op;
-        n = 1;
-    }
-    for (int k = 0; k < n_runs; k++) {  // k-th run of the CIGAR = generated run n_runs-1-k
-        if (k < FADEHIP_MAX_OPS) {
-            const uint32_t v = ring[(n_runs - 1 - k) & (FADEHIP_MAX_OPS - 1)];
-            if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = v;
-            if (n == 0) first_op = v;
-        }
-        n++;
-    }
-    if (n_runs > 0) last_op = first_gen;
-    const int tail = lq - 1 - f.end_q;
-    if (pad && tail > 0) {
-        last_op = ((uint32_t)tail << 4) | 4u;
-        if (n < FADEHIP_MAX_OPS) o.sw.ops[n] = last_op;
-        n++;
-    }
-    o.sw.n_ops = n;
-
-    if (a.meta) {
-        const Meta m = a.meta[src];
-        o.win_start = m.win_start;
-        o.win_len = (int32_t)w.lr;
-        o.clip_left = m.clip_left;
-        o.clip_right = m.clip_right;
-        o.aligned_len = m.aligned_len;
-        if (a.gate && n >= 1 && n <= 10) {  // analysis.d:69-70
-            const uint32_t lead_s = (first_op & 15u) == 4u ? (first_op >> 4) : 0u;
-            const uint32_t trail_s = (n > 1 && (last_op & 15u) == 4u) ? (last_op >> 4) : 0u;
-            // analysis.d:34,74-80: left clip longer than the floor, last op '=', score > 1.8*clip
-            // (float cutoff == integer 5*score > 9*clip, SURVEY.md §8d), result has leading S only
-            if (m.clip_left != 0 && m.clip_left > a.floor_len && (last_op & 15u) == 7u &&
-                5 * (int64_t)f.score > 9 * (int64_t)m.clip_left && trail_s == 0 && lead_s != 0)
-                o.art |= 1;
-            // analysis.d:34,98-104
-            if (m.clip_right != 0 && m.clip_right > a.floor_len && (first_op & 15u) == 7u &&
-                5 * (int64_t)f.score > 9 * (int64_t)m.clip_right && lead_s == 0 && trail_s != 0)
-                o.art |= 2;
-            if (o.art) {  // readstatus.d: bit1 art_left, bit2 art_right
-                const uint8_t before = a.rs[w.idx];
-                a.rs[w.idx] = before | (uint8_t)(o.art << 1);
-                art_ret = (uint32_t)o.art | ((before & 32u) ? 4u : 0u);
-            }
-        }
-    } else {
-        o.win_start = 0;
-        o.win_len = (int32_t)w.lr;
-        o.clip_left = o.clip_right = o.aligned_len = 0;
-    }
-    a.out[src] = o;
-    return art_ret;
+    int n_items = a.n_items;
+    if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
+    if (item >= n_items) return 0u;
+    const uint64_t trace_off = (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
+    return traceback_path(a, item, 0, a.trace + trace_off, a.packed ? ((item >> 1) & 3) : (item & 3), item & 1, item);
 }
 
 __global__ void traceback_kernel(TbArgs a) {
     const uint32_t r = traceback_one(a, (int)(blockIdx.x * blockDim.x + threadIdx.x));
-    if (a.stats) {
-        // stats.d:45-54, the artifact part: per-wave popcounts, one atomic per wave and non-zero counter
-        const unsigned long long m_art = __ballot(r & 3u), m_sup = __ballot((r & 3u) && (r & 4u)), m_l = __ballot(r & 1u),
-                                 m_r = __ballot(r & 2u);
-        if ((threadIdx.x & 63) == 0 && m_art) {
-            unsigned long long *st = a.stats + 8 * (blockIdx.x % STAT_PARTS);
-            atomicAdd(&st[4], (unsigned long long)__popcll(m_art));
-            if (m_sup) atomicAdd(&st[3], (unsigned long long)__popcll(m_sup));
-            if (m_l) atomicAdd(&st[6], (unsigned long long)__popcll(m_l));
-            if (m_r) atomicAdd(&st[7], (unsigned long long)__popcll(m_r));
-        }
-    }
+    if (a.stats) add_artifact_stats(a.stats, r, blockIdx.x);
 }
 
-// ---------------------------------------------------------------- pass-2 selection
-// After pass 1 every alignment has score and end cell.  Level 2: only alignments that can still become an
-// artifact call need a CIGAR — left: clip > floor, 5*score > 9*clip and the end cell in the last query row
-// (analysis.d:74-80 needs the last op to be '=' with no trailing S); right: clip > floor, 5*score > 9*clip and
-// end cell above the last row (analysis.d:102-104 needs a trailing S).  Everything else gets its record
-// here with n_ops = 0 ("not traced").  Level 1 (meta == nullptr) traces everything.
-struct SelArgs {
-    const Work *work;
-    const Meta *meta;
-    const Fwd *fwd;
-    int32_t n_items;
-    int32_t floor_len;
-    int32_t trace_all;
-    int32_t R;
-    int32_t span_slack;     // columns added to the expected path span (24; tests shrink it to force re-runs)
-    Cand *cand;             // [NUM_BUCKETS][cap]
-    uint32_t cap;
-    uint32_t *bucket_n;     // [NUM_BUCKETS]
-    fadehip_aln *out;
-    // exact-diagonal shortcut (below): finishes a candidate here, so it needs what traceback_kernel has
-    const uint8_t *q_nib, *r_nib;
-    uint8_t *rs;
-    unsigned long long *stats;
-    int32_t gate;
-    int32_t match;          // score of a matching pair; 0 switches the shortcut off
-    uint32_t rules;         // FADEHIP_RULE_*
-    const uint32_t *count_dev;  // items on the class list (nullptr = n_items is exact); this launch covers [item_base, item_base + n_items)
-    uint32_t item_base;
-};
-
-// 128-thread blocks: a class list has ~10^5 items, and the shortcut's diagonal check is a chain of dependent loads
-// that wants every CU busy (1024-thread blocks left 60 % of them idle: 52 us instead of 20)
-constexpr int SELECT_BLOCK = 128;
-__global__ __launch_bounds__(SELECT_BLOCK) void select_kernel(SelArgs a) {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ uint32_t s_cnt[NUM_BUCKETS], s_base[NUM_BUCKETS];
-    if (threadIdx.x < NUM_BUCKETS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    int b = -1;
-    uint32_t local_slot = 0;
-    uint32_t art_ret = 0;  // artifact bits set here (bit0 left, bit1 right) | 4 if the read is supplementary
-    Cand c;
-    c.src = 0;
-    c.c0 = 0;
-    int n_items = a.n_items;
-    if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
-    if (item < n_items) {
-        const Work w = a.work[item];
-        const Fwd f = a.fwd[item];
-        bool cand = true;
-        if (a.meta && !a.trace_all) {
-            const Meta m = a.meta[item];
-            const bool left = m.clip_left > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_left &&
-                              f.end_q == (int32_t)w.lq - 1;
-            const bool right = m.clip_right > a.floor_len && 5 * (int64_t)f.score > 9 * (int64_t)m.clip_right &&
-                               f.end_q < (int32_t)w.lq - 1;
-            // (without A.6's soft-clip padding no result CIGAR has an S op and analysis.d:78-80 / 102-104 never hold)
-            cand = (left || right) && rule(a.rules, FADEHIP_RULE_PAD_SOFTCLIP);
-            if (!cand) {
-                fadehip_aln o;
-                o.read_idx = (int32_t)w.idx;
-                o.art = 0;
-                o.win_start = m.win_start;
-                o.win_len = (int32_t)w.lr;
-                o.clip_left = m.clip_left;
-                o.clip_right = m.clip_right;
-                o.aligned_len = m.aligned_len;
-                o.sw.score = f.score;
-                o.sw.end_query = f.end_q;
-                o.sw.end_ref = f.end_r;
-                o.sw.beg_query = -1;
-                o.sw.beg_ref = -1;
-                o.sw.n_ops = 0;
-                for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
-                a.out[item] = o;
-            }
-        }
-        // Exact-diagonal shortcut.  If score = match * L and the L cells of the diagonal that ends in the end cell all
-        // score `match`, the traceback is forced: H along that diagonal is at least match * (L - k) (the matches chain
-        // up from any cell >= 0) and at most that (H(end) is the given score and every step towards it adds `match`),
-        // so every cell equals its diagonal predecessor + match — the direction the traceback tries first — and the
-        // cell before the run is 0, where it stops.  CIGAR = [beg_query S] L= [tail S] with no DP re-computation;
-        // this is the planted artifact (an exact reverse-complement copy), by far the most common candidate.
-        if (cand && a.match > 0 && f.score > 0) {
-            const int L = f.score / a.match;
-            if (L * a.match == f.score && L <= f.end_q + 1 && L <= f.end_r + 1) {
-                const bool rcq = w.flags & 1u;
-                const int lq = (int)w.lq;
-                const uint32_t n_match_classes = rule(a.rules, FADEHIP_RULE_N_MATCHES_N) ? 5u : 4u;
-                const bool pad = rule(a.rules, FADEHIP_RULE_PAD_SOFTCLIP);
-                bool ok = true;
-                for (int k0 = 0; k0 < L && ok; k0 += 8) {
-                    const int nv = min(8, L - k0);
-                    const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - f.end_q + k0)
-                                               : (uint64_t)w.q_base + (uint32_t)(f.end_q - k0 - (nv - 1));
-                    const uint64_t rn_lo = w.r_base + (uint64_t)(f.end_r - k0 - (nv - 1));
-                    const Nib8 qw = load_nib8(a.q_nib, qn_lo), rw = load_nib8(a.r_nib, rn_lo);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (k < nv) {
-                            const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
-                            const uint32_t cq = lut4(CLASS_LUT, rcq ? lut4(COMP_LUT, qraw) : qraw);
-                            const uint32_t cr = lut4(CLASS_LUT, nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k)));
-                            ok = ok && cq == cr && cq < n_match_classes;  // same letter of A,C,G,T,N: the pair scores `match`
-                        }
-                    }
-                }
-                if (ok) {
-                    cand = false;
-                    fadehip_aln o;
-                    o.read_idx = (int32_t)w.idx;
-                    o.art = 0;
-                    o.sw.score = f.score;
-                    o.sw.end_query = f.end_q;
-                    o.sw.end_ref = f.end_r;
-                    o.sw.beg_query = f.end_q - L + 1;
-                    o.sw.beg_ref = f.end_r - L + 1;
-                    for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
-                    const int lead = o.sw.beg_query, tail = lq - 1 - f.end_q;
-                    int n = 0;
-                    if (pad && lead > 0) o.sw.ops[n++] = ((uint32_t)lead << 4) | 4u;
-                    o.sw.ops[n++] = ((uint32_t)L << 4) | 7u;
-                    if (pad && tail > 0) o.sw.ops[n++] = ((uint32_t)tail << 4) | 4u;
-                    o.sw.n_ops = n;
-                    if (a.meta) {
-                        const Meta m = a.meta[item];
-                        o.win_start = m.win_start;
-                        o.win_len = (int32_t)w.lr;
-                        o.clip_left = m.clip_left;
-                        o.clip_right = m.clip_right;
-                        o.aligned_len = m.aligned_len;
-                        if (a.gate) {
-                            // analysis.d:74-80 (last op '=', leading S only) / 98-104 (first op '=', trailing S only)
-                            if (m.clip_left != 0 && m.clip_left > a.floor_len && tail == 0 && lead > 0 &&
-                                5 * (int64_t)f.score > 9 * (int64_t)m.clip_left)
-                                o.art |= 1;
-                            if (m.clip_right != 0 && m.clip_right > a.floor_len && lead == 0 && tail > 0 &&
-                                5 * (int64_t)f.score > 9 * (int64_t)m.clip_right)
-                                o.art |= 2;
-                            if (o.art) {
-                                const uint8_t before = a.rs[w.idx];
-                                a.rs[w.idx] = before | (uint8_t)(o.art << 1);
-                                art_ret = (uint32_t)o.art | ((before & 32u) ? 4u : 0u);
-                            }
-                        }
-                    } else {
-                        o.win_start = 0;
-                        o.win_len = (int32_t)w.lr;
-                        o.clip_left = o.clip_right = o.aligned_len = 0;
-                    }
-                    a.out[item] = o;
-                }
-            }
-        }
-        if (cand) {
-            // sweep steps the path is expected to span: a cell (i, j) is computed at step j + i / R.  Columns:
-            // score/2 for clean matches, a quarter more for mismatches, + slack; rows ~ columns.  Any value is
-            // correct (a path that leaves the traced steps is re-run from step 0), this one is cheap.
-            const int span_cols = a.span_slack >= 0 ? f.score / 2 + f.score / 8 + a.span_slack : 1;
-            const int span = span_cols + span_cols / a.R + 2;
-            const int t_end = f.end_r + f.end_q / a.R;
-            int c0 = t_end + 1 - span;
-            c0 = c0 < CK_COLS ? 0 : (c0 & ~(CK_COLS - 1));
-            const int steps = t_end + 1 - c0;
-            b = 0;
-            while (steps > bucket_cols(b)) b++;
-            c.src = (uint32_t)item;
-            c.c0 = (uint32_t)c0;
-            local_slot = atomicAdd(&s_cnt[b], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < NUM_BUCKETS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bucket_n[threadIdx.x], s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (b >= 0) a.cand[(uint64_t)b * a.cap + s_base[b] + local_slot] = c;
-    if (a.stats) {
-        // stats.d:45-54 for the calls made by the shortcut (as traceback_kernel does for its own)
-        const unsigned long long m_art = __ballot(art_ret & 3u), m_sup = __ballot((art_ret & 3u) && (art_ret & 4u)),
-                                 m_l = __ballot(art_ret & 1u), m_r = __ballot(art_ret & 2u);
-        if ((threadIdx.x & 63) == 0 && m_art) {
-            unsigned long long *st = a.stats + 8 * (blockIdx.x % STAT_PARTS);
-            atomicAdd(&st[4], (unsigned long long)__popcll(m_art));
-            if (m_sup) atomicAdd(&st[3], (unsigned long long)__popcll(m_sup));
-            if (m_l) atomicAdd(&st[6], (unsigned long long)__popcll(m_l));
-            if (m_r) atomicAdd(&st[7], (unsigned long long)__popcll(m_r));
-        }
-    }
-}
-
-// ---------------------------------------------------------------- pass-2 planning (device side)
-// The selection's bucket counts never leave the device: one wave turns them into the table the pass-2 launch and
-// its traceback read (which octet belongs to which bucket, where its trace scratch starts).  The launches themselves
-// are sized from upper bounds; if the trace scratch the table needs exceeds what the slot holds, the table stays
-// empty and the need is left in `plan` for the host (fadehip_annotate_collect grows the scratch and runs the batch
-// again: DESIGN.md §4).
+// ---------------------------------------------------------------- run totals kept on the device
 struct PlanOut {            // in the slot's counter block, read by the host after the run
-    uint32_t overflow;      // some plan did not fit the trace scratch
-    uint32_t bound_violated;  // a device-side count exceeded the bound its launch was sized from
-    unsigned long long need_dwords;  // largest trace scratch any plan asked for
-    unsigned long long cand_total;   // candidates traced (all classes and rounds)
-    unsigned long long rerun_total;  // candidates listed for a re-run
+    unsigned long long cand_total;   // candidates traced by pass 2 (all classes)
+    unsigned long long rerun_total;  // candidates traced again because their path left the traced steps
 };
-struct PlanArgs {
-    const uint32_t *bucket_n;   // [NUM_BUCKETS] from select_kernel; nullptr for a re-run round
-    uint32_t *incomplete_n;     // re-run round: number of listed candidates (reset to 0 here)
-    const Cand *incomplete;     // re-run round: the list ...
-    Cand *again;                // ... copied here with T0 moved `back` steps towards 0
-    int32_t back;
-    int32_t steps_max[NUM_BUCKETS];
-    int32_t n_buckets;          // NUM_BUCKETS, or 1 for a re-run round
-    int32_t R;
-    uint32_t cap;               // entries per bucket of the candidate array
-    uint32_t oct_bound;         // octets the pass-2 launch and its traceback were sized for
-    unsigned long long trace_cap_dwords;
-    P2Table *tab;
-    PlanOut *plan;
-};
-
-__global__ __launch_bounds__(256) void plan_kernel(PlanArgs a) {
-    __shared__ uint32_t s_n;
-    if (a.bucket_n == nullptr) {
-        if (threadIdx.x == 0) s_n = *a.incomplete_n;
-        __syncthreads();
-        const uint32_t m = s_n;
-        for (uint32_t k = threadIdx.x; k < m; k += blockDim.x) {
-            Cand c = a.incomplete[k];
-            c.c0 = (int)c.c0 > a.back ? c.c0 - (uint32_t)a.back : 0u;
-            a.again[k] = c;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    P2Table t;
-    t.cap = a.cap;
-    t.pad = 0;
-    uint64_t off = 0;
-    uint32_t oct = 0, total = 0;
-    for (int k = 0; k < NUM_BUCKETS; k++) {
-        const int b = a.n_buckets - 1 - k;  // longest bucket first
-        t.oct_first[k] = oct;
-        t.count[k] = 0;
-        t.bucket[k] = 0;
-        t.trace_base[k] = 0;
-        t.stride[k] = 0;
-        if (b < 0) continue;
-        const uint32_t cnt = a.bucket_n ? a.bucket_n[b] : s_n;
-        if (!cnt) continue;
-        const uint64_t stride = (uint64_t)((a.steps_max[b] + 3) / 4) * (uint64_t)a.R * 64u;
-        t.count[k] = cnt;
-        t.bucket[k] = (uint32_t)b;
-        t.trace_base[k] = off;
-        t.stride[k] = stride;
-        const uint32_t octs_b = (cnt + 7) / 8;
-        off += (uint64_t)octs_b * stride;
-        oct += octs_b;
-        total += cnt;
-    }
-    t.oct_first[NUM_BUCKETS] = oct;
-    if (a.bucket_n == nullptr) {
-        *a.incomplete_n = 0;
-        if (total) atomicAdd(&a.plan->rerun_total, (unsigned long long)total);
-    } else if (total) atomicAdd(&a.plan->cand_total, (unsigned long long)total);
-    if (off > a.plan->need_dwords) a.plan->need_dwords = off;
-    bool ok = true;
-    if (off > a.trace_cap_dwords) { a.plan->overflow = 1; ok = false; }
-    if (oct > a.oct_bound) { a.plan->bound_violated = 1; ok = false; }
-    if (!ok) {
-        for (int k = 0; k <= NUM_BUCKETS; k++) t.oct_first[k] = 0;
-        for (int k = 0; k < NUM_BUCKETS; k++) t.count[k] = 0;
-    }
-    *a.tab = t;
-}
 
 // level 1 builds its class lists on the host: their counts go where the gate would have left them
 __global__ void set_counts_kernel(uint32_t *dst, uint32_t v) { *dst = v; }

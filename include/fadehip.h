@@ -217,11 +217,14 @@ int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out);
 int fadehip_sync(fadehip_ctx *ctx);
 
 /* Measurement (after results / collect of that run): device time of the last run on `slot`, from hipEvents recorded
- * on the slot's stream around the kernels.  ms[0] gate, ms[1] the dominant kernel (the score pass; the single forward kernel
- * under FADEHIP_KERNEL=pk|int32), ms[2] everything after it up to the artifact gates (selection, traced pass 2,
- * traceback, re-runs), ms[3] whole run.  counts[0] alignments, counts[1] DP cells, counts[2] trace scratch
- * bytes, counts[3] algorithmic bytes of the dominant kernel. */
-int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[4]);
+ * on the slot's stream around the kernels.  ms[0] gate, ms[1] the dominant kernel (the score pass; the single forward
+ * kernel under FADEHIP_KERNEL=pk|int32), ms[2] everything after it up to the artifact gates (selection, plan, traced
+ * pass 2, traceback, re-run rounds), ms[3] whole run.  With several slots in flight these are durations on a shared
+ * device.  counts[0] alignments, counts[1] DP cells, counts[2] trace scratch bytes of the largest pass-2 plan,
+ * counts[3] algorithmic bytes of the dominant kernel as SURVEY.md §8(d) defines them (packed query + packed window +
+ * 16 B descriptor + 64 B result slot per alignment), counts[4] bytes of wave snapshots the score pass leaves for
+ * pass 2 (int16 H and E-hat per query row every 32 sweep steps), counts[5] candidates traced by pass 2. */
+int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[6]);
 
 /* Sum counters over the ranks' devices with one ncclAllReduce (RCCL) — single process, one ctx
  * per device.  counters is [n_ctx][count] in, every row holds the sum on return. */

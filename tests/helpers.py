@@ -67,6 +67,23 @@ def make_pairs(rng, n, lq_range=(20, 260), lr_range=(30, 900), kinds=("random", 
             r[rng.random(lr) < 0.2] = ord("N")
         elif kind == "iupac":
             q, r = rand_seq(rng, lq, IUPAC), rand_seq(rng, lr, IUPAC)
+        elif kind == "lowcomplexity":  # two-letter sequences related by block indels: co-optimal paths, i.e. ties between
+            # the gap directions and between opening and extending a gap (what Appendix A.4's rules decide)
+            two = np.frombuffer(b"AC", dtype=np.uint8)
+            lr = int(rng.integers(40, 200))
+            r = two[rng.integers(0, 2, size=lr)]
+            a = int(rng.integers(0, lr // 2))
+            ql = list(r[a:a + int(rng.integers(20, 120))])
+            for _ in range(int(rng.integers(1, 4))):
+                if len(ql) < 12:
+                    break
+                p = int(rng.integers(3, len(ql) - 3))
+                L = int(rng.integers(1, 6))
+                if rng.random() < 0.5:
+                    del ql[p:p + L]
+                else:
+                    ql[p:p] = list(two[rng.integers(0, 2, size=L)])
+            q = np.array(ql, dtype=np.uint8)
         elif kind == "refspecial":  # N / IUPAC columns only in the reference: the query stays pure A,C,G,T
             r = rand_seq(rng, lr)
             a = int(rng.integers(0, max(1, lr - 10)))

@@ -61,39 +61,30 @@ def test_ref_span_bound_too_small_is_an_error_not_a_fault(ctx):
     assert int(st[0]) == 5000
 
 
-def test_trace_scratch_overflow_reruns_the_batch(monkeypatch, capfd):
-    """The launches of pass 2 are sized before its candidates are known.  When the device-side plan needs more trace
-    scratch than the slot holds, results() grows it and runs the batch again: same bytes as a run that had room."""
+@pytest.mark.parametrize("waves", ["1", "7"])
+def test_pass2_persistent_launch_of_any_size(monkeypatch, waves):
+    """Pass 2 is one persistent launch whose waves draw octets from a ticket counter, trace them into their own scratch,
+    walk the tracebacks and re-trace the paths that left their steps.  Its size is a guess made before the candidates
+    are known; any size must give the same bytes — here a single wave (and seven) serving thousands of candidates."""
     cfg, g, b = synth.make_config("C5", 30_000, contig_len=400_000)
-    big = fade_amd.Context(device=0)
-    big.genome_upload(g.names, g.ascii_contigs())
     monkeypatch.setenv("FADEHIP_NO_SHORTCUT", "1")  # every candidate goes through pass 2
-    rs0, aln0, st0 = big.annotate(b, cfg["floor_len"], cfg["window"])
-    monkeypatch.setenv("FADEHIP_TRACE_INIT", "65536")
-    monkeypatch.setenv("FADEHIP_DEBUG", "1")
+    monkeypatch.setenv("FADEHIP_SPAN_SLACK", "0")    # ... and many paths leave their traced steps
+    big = fade_amd.Context(device=0)
+    monkeypatch.setenv("FADEHIP_P2_WAVES", waves)
     small = fade_amd.Context(device=0)
     try:
-        small.genome_upload(g.names, g.ascii_contigs())
-        capfd.readouterr()
+        for c in (big, small):
+            c.genome_upload(g.names, g.ascii_contigs())
+        rs0, aln0, st0 = big.annotate(b, cfg["floor_len"], cfg["window"])
+        assert big.last_profile(0)["candidates"] > 2000
         rs1, aln1, st1 = small.annotate(b, cfg["floor_len"], cfg["window"])
-        assert "batch re-run" in capfd.readouterr().err
         assert np.array_equal(rs0, rs1) and list(st0) == list(st1) and _key(aln0) == _key(aln1)
-        # the scratch stays grown: the next batch runs once
-        rs2, aln2, st2 = small.annotate(b, cfg["floor_len"], cfg["window"])
-        assert "batch re-run" not in capfd.readouterr().err
-        assert np.array_equal(rs0, rs2) and _key(aln0) == _key(aln2)
-        # level 1 (everything is traced) through the same plan / overflow path
+        assert small.last_profile(0)["trace_bytes"] < big.last_profile(0)["trace_bytes"]
         from helpers import concat, make_pairs
         qs, rs_ = make_pairs(np.random.default_rng(11), 400, kinds=("related", "planted", "random"))
         qc, qo = concat(qs)
         rc, ro = concat(rs_)
-        tiny = fade_amd.Context(device=0)
-        try:
-            got = tiny.sw_batch_packed(qc, qo, rc, ro)
-            assert "batch re-run" in capfd.readouterr().err
-        finally:
-            tiny.close()
-        assert got.tobytes() == big.sw_batch_packed(qc, qo, rc, ro).tobytes()
+        assert small.sw_batch_packed(qc, qo, rc, ro).tobytes() == big.sw_batch_packed(qc, qo, rc, ro).tobytes()
     finally:
         small.close()
         big.close()

@@ -122,7 +122,8 @@ def test_mixed_read_lengths_and_classes(ctx, oracle):
     assert len(tags) > 100
 
 
-def test_trace_chunking_and_batch_split_invariance(oracle):
+def test_trace_chunking_and_batch_split_invariance(oracle, monkeypatch):
+    monkeypatch.setenv("FADEHIP_NO_SHORTCUT", "1")  # every candidate through pass 2, so that every chunk has a plan
     cfg, g, b = synth.make_config("C2", 20_000, contig_len=200_000)
     contigs = g.ascii_contigs()
     big = fade_amd.Context(device=0)
@@ -135,7 +136,8 @@ def test_trace_chunking_and_batch_split_invariance(oracle):
     small.genome_upload(g.names, contigs)
     rs2, aln2, stats2 = small.annotate(b, cfg["floor_len"], cfg["window"])
     assert np.array_equal(rs, rs2) and key(aln2) == ref and list(stats) == list(stats2)
-    assert small.last_profile(0)["trace_bytes"] >= big.last_profile(0)["trace_bytes"] * 0.9
+    # trace_bytes of the profile = the largest pass-2 plan of the run: a chunk's is smaller than the whole list's
+    assert 0 < small.last_profile(0)["trace_bytes"] <= big.last_profile(0)["trace_bytes"]
     # the same reads in two halves, on the two slots: every read's result is independent of its batch
     n = len(rs)
     h1, h2 = synth.take(b, np.arange(0, n // 2)), synth.take(b, np.arange(n // 2, n))

@@ -40,8 +40,9 @@ def test_level1_under_rule(oracle, name, rules):
     # ties are what the A.3 / A.4 rules decide: homopolymers, tandem repeats and related pairs with gaps make many
     qs, rs = make_pairs(rng, 1400, kinds=("random", "planted", "homopolymer", "tandem", "nrich", "iupac", "related"))
     qs2, rs2 = make_pairs(rng, 300, lq_range=(120, 260), lr_range=(300, 900), kinds=("tandem", "related", "homopolymer"))
-    qc, qo = concat(qs + qs2)
-    rc, ro = concat(rs + rs2)
+    qs3, rs3 = make_pairs(rng, 4000, kinds=("lowcomplexity",))
+    qc, qo = concat(qs + qs2 + qs3)
+    rc, ro = concat(rs + rs2 + rs3)
     c = fade_amd.Context(device=0, rules=rules)
     try:
         got = c.sw_batch_packed(qc, qo, rc, ro)
