@@ -15,9 +15,12 @@
 #include "hts_lite.hpp"
 #include "../../../include/fadehip.h"
 
+#include <atomic>
 #include <chrono>
+#include <climits>
 #include <cstdlib>
 #include <deque>
+#include <functional>
 
 #ifndef FADE_VERSION
 #define FADE_VERSION "v0.5.0-mi355x"
@@ -160,57 +163,123 @@ private:
 };
 
 // ------------------------------------------------------------------ one batch in flight
+// Pinned batch blocks (fadehip_batch_bytes / fadehip_batch_bind) are recycled: upload is one hipMemcpyAsync from them.
+struct BlockPool {
+    struct Block { void *p; size_t cap; };
+    fadehip_ctx *ctx = nullptr;
+    std::mutex m;
+    std::vector<Block> free_;
+    void *acquire(size_t bytes, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t k = 0; k < free_.size(); k++)
+                if (free_[k].cap >= bytes) {
+                    Block b = free_[k];
+                    free_.erase(free_.begin() + (long)k);
+                    *cap = b.cap;
+                    return b.p;
+                }
+        }
+        void *p = nullptr;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (fadehip_host_alloc(ctx, want, &p)) throw std::runtime_error(std::string("pinned allocation: ") + fadehip_last_error(ctx));
+        *cap = want;
+        return p;
+    }
+    void release(void *p, size_t cap) {
+        if (!p) return;
+        std::lock_guard<std::mutex> l(m);
+        free_.push_back({p, cap});
+    }
+    void drain() {
+        for (auto &b : free_) fadehip_host_free(ctx, b.p);
+        free_.clear();
+    }
+};
+
 struct Chunk {
     std::vector<Rec> recs;
-    // SoA views handed to the device
-    std::vector<int32_t> tid, pos, l_seq;
-    std::vector<uint16_t> flag;
-    std::vector<uint8_t> has_sa, seq, rs;
-    std::vector<uint32_t> cigar_off, cigar_ops, seq_off;
-    std::vector<fadehip_aln> aln;
-    fadehip_anno_out out;
+    // anno.d:61-65: an unmapped record, or one without an S op, gets rs = 0 and nothing else: such records are not sent.
+    std::vector<uint32_t> sent;  // indices (into recs) of the records that are
+    fadehip_read_batch b;        // bound into `block`
+    void *block = nullptr;
+    size_t block_cap = 0;
+    // what the writer stage needs of the results, copied out of the slot's pinned result block
+    std::vector<uint8_t> rs_sent;
+    std::vector<fadehip_aln> art;  // the artifact calls (art != 0); read_idx indexes `sent`
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n_oversize = 0;
     int dev = 0, slot = 0;
 };
 
-static void pack_chunk(Chunk &c, Pool &pool) {
+static inline bool needs_device(const Rec &r) {
+    if (r.flag() & 4) return false;
+    for (int k = 0; k < r.n_cigar(); k++)
+        if ((r.cigar_op(k) & 15u) == 4u) return true;
+    return false;
+}
+
+// records -> the batch block, in parallel: count per range, prefix, fill
+static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
     const size_t n = c.recs.size();
-    c.tid.resize(n); c.pos.resize(n); c.l_seq.resize(n); c.flag.resize(n); c.has_sa.resize(n);
-    c.cigar_off.resize(n + 1); c.seq_off.resize(n + 1);
-    // The device reads a record's bases only to re-align it, which takes a mapped record with an S op (anno.d:61):
-    // every other record gets an empty slice of the sequence array — a tenth of the bytes to pack and to move over PCIe.
-    auto needs_seq = [](const Rec &r) {
-        if (r.flag() & 4) return false;
-        for (int k = 0; k < r.n_cigar(); k++)
-            if ((r.cigar_op(k) & 15u) == 4u) return true;
-        return false;
-    };
-    size_t nc = 0, ns = 0;
-    for (size_t i = 0; i < n; i++) {
-        const Rec &r = c.recs[i];
-        c.cigar_off[i] = (uint32_t)nc;
-        c.seq_off[i] = (uint32_t)ns;
-        nc += (size_t)r.n_cigar();
-        if (needs_seq(r)) ns += ((size_t)r.l_seq() + 1) / 2;
-    }
-    c.cigar_off[n] = (uint32_t)nc;
-    c.seq_off[n] = (uint32_t)ns;
-    c.cigar_ops.resize(nc ? nc : 1);
-    c.seq.resize(ns ? ns : 1);
-    const size_t nt = (size_t)pool.size();
+    const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)pool.size(), n / 4096 + 1));
+    struct Range { size_t n_sent = 0, n_cig = 0, n_seq = 0; int64_t span = 0; };
+    std::vector<Range> rg(nt + 1);
+    std::vector<uint8_t> need(n);
     pool.parallel_for(nt, [&](size_t t) {
+        Range r;
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+            const Rec &rec = c.recs[i];
+            need[i] = needs_device(rec) ? 1 : 0;
+            if (!need[i]) continue;
+            r.n_sent++;
+            r.n_cig += (size_t)rec.n_cigar();
+            r.n_seq += ((size_t)rec.l_seq() + 1) / 2;
+            r.span = std::max(r.span, cigar_ref_len(rec));
+        }
+        rg[t + 1] = r;
+    });
+    int64_t span = 1;
+    for (size_t t = 1; t <= nt; t++) {
+        span = std::max(span, rg[t].span);
+        rg[t].n_sent += rg[t - 1].n_sent;
+        rg[t].n_cig += rg[t - 1].n_cig;
+        rg[t].n_seq += rg[t - 1].n_seq;
+    }
+    const size_t ns = rg[nt].n_sent, ncig = rg[nt].n_cig, nseq = rg[nt].n_seq;
+    if (nseq >= ((size_t)1 << 31)) throw std::runtime_error("batch too large: lower --batch");
+    c.block = blocks.acquire(fadehip_batch_bytes((int32_t)ns, (int64_t)ncig, (int64_t)nseq), &c.block_cap);
+    if (fadehip_batch_bind(c.block, (int32_t)ns, (int64_t)ncig, (int64_t)nseq, &c.b)) throw std::runtime_error(fadehip_last_error(nullptr));
+    c.sent.resize(ns);
+    int32_t *tid = const_cast<int32_t *>(c.b.tid), *pos = const_cast<int32_t *>(c.b.pos), *lseq = const_cast<int32_t *>(c.b.l_seq);
+    uint16_t *flag = const_cast<uint16_t *>(c.b.flag);
+    uint8_t *has_sa = const_cast<uint8_t *>(c.b.has_sa), *seq = const_cast<uint8_t *>(c.b.seq_packed);
+    uint32_t *coff = const_cast<uint32_t *>(c.b.cigar_off), *soff = const_cast<uint32_t *>(c.b.seq_off), *cops = const_cast<uint32_t *>(c.b.cigar_ops);
+    pool.parallel_for(nt, [&](size_t t) {
+        size_t k = rg[t].n_sent, nc = rg[t].n_cig, nq = rg[t].n_seq;
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+            if (!need[i]) continue;
             const Rec &r = c.recs[i];
-            c.tid[i] = r.tid();
-            c.pos[i] = r.pos();
-            c.l_seq[i] = r.l_seq();
-            c.flag[i] = (uint16_t)r.flag();
-            c.has_sa[i] = r.aux_exists("SA") ? 1 : 0;  // anno.d:73
-            if (r.n_cigar()) memcpy(&c.cigar_ops[c.cigar_off[i]], r.cigar_bytes(), 4 * (size_t)r.n_cigar());
-            if (c.seq_off[i + 1] > c.seq_off[i]) memcpy(&c.seq[c.seq_off[i]], r.seq(), ((size_t)r.l_seq() + 1) / 2);
+            c.sent[k] = (uint32_t)i;
+            tid[k] = r.tid();
+            pos[k] = r.pos();
+            lseq[k] = r.l_seq();
+            flag[k] = (uint16_t)r.flag();
+            has_sa[k] = r.aux_exists("SA") ? 1 : 0;  // anno.d:73
+            coff[k] = (uint32_t)nc;
+            soff[k] = (uint32_t)nq;
+            const size_t cb = 4 * (size_t)r.n_cigar(), sb = ((size_t)r.l_seq() + 1) / 2;
+            if (cb) memcpy(cops + nc, r.cigar_bytes(), cb);
+            if (sb) memcpy(seq + nq, r.seq(), sb);
+            nc += (size_t)r.n_cigar();
+            nq += sb;
+            k++;
         }
     });
-    c.rs.assign(n ? n : 1, 0);
-    c.aln.resize(n ? n : 1);
+    coff[ns] = (uint32_t)ncig;
+    soff[ns] = (uint32_t)nseq;
+    c.b.n_skipped = (int32_t)(n - ns);
+    c.b.ref_span_bound = (int32_t)std::min<int64_t>(span, INT32_MAX);
 }
 
 static std::string cigar_string(const uint32_t *ops, int n) {
@@ -226,18 +295,20 @@ static std::string cigar_string(const uint32_t *ops, int n) {
 static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
     const size_t n = c.recs.size();
     static const uint8_t comp[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};  // util.d:18-20
-    // artifact strings first (few), then rs for everyone, keeping the reference's tag order rs, am, as, ar, ab
+    // rs of every record (0 for the ones anno.d:61-65 settles without the device), then the artifact strings (few),
+    // keeping the reference's tag order rs, am, as, ar, ab
+    std::vector<uint8_t> rs(n, 0);
+    for (size_t k = 0; k < c.sent.size(); k++) rs[c.sent[k]] = c.rs_sent[k];
     std::vector<int> art_of(n, -1);
-    for (int k = 0; k < c.out.n_aln; k++)
-        if (c.aln[k].art) art_of[(size_t)c.aln[k].read_idx] = k;
+    for (size_t k = 0; k < c.art.size(); k++) art_of[c.sent[(size_t)c.art[k].read_idx]] = (int)k;
     const size_t nt = (size_t)pool.size();
     pool.parallel_for(nt, [&](size_t t) {
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
             Rec &r = c.recs[i];
-            r.aux_update_uint("rs", c.rs[i]);  // anno.d:63,94
+            r.aux_update_uint("rs", rs[i]);  // anno.d:63,94
             const int k = art_of[i];
             if (k < 0) continue;
-            const fadehip_aln &a = c.aln[(size_t)k];
+            const fadehip_aln &a = c.art[(size_t)k];
             const int lq = r.l_seq();
             std::string seq((size_t)lq, 'N'), qrc((size_t)lq, 'N'), bq((size_t)lq, '!');
             const uint8_t *sq = r.seq(), *ql = r.qual();
@@ -292,12 +363,36 @@ struct StageClock {
     void stop() { t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// joins the stage threads on every way out of annotate_main (an exception past a joinable std::thread is std::terminate)
+struct StageThreads {
+    std::vector<std::thread> th;
+    std::function<void()> unblock;  // closes the queues so that the stages can finish
+    ~StageThreads() {
+        if (unblock) unblock();
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+    }
+};
+
 static int annotate_main(const std::string &cl, const Opts &o) {
     StageClock ck_total, ck_fasta, ck_upload, ck_read, ck_pack, ck_submit, ck_collect, ck_tags, ck_write;
     ck_total.start();
     // anno.d:18-19 (htslib log format)
     fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
     const int nthreads = o.threads > 0 ? o.threads : std::max(1u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u);
+    const int ngpu = std::max(1, o.gpus);
+    std::vector<fadehip_ctx *> ctxs((size_t)ngpu, nullptr);
+    std::vector<BlockPool> blocks((size_t)ngpu);
+    struct CtxGuard {
+        std::vector<fadehip_ctx *> &c;
+        std::vector<BlockPool> &b;
+        ~CtxGuard() {
+            for (size_t k = 0; k < c.size(); k++) {
+                if (c[k]) b[k].drain();
+                fadehip_destroy(c[k]);
+            }
+        }
+    } ctx_guard{ctxs, blocks};
     Pool pool(nthreads);
     try {
         Pool rpool0(nthreads);
@@ -331,19 +426,33 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n");
             return 1;
         }
-        const int ngpu = std::max(1, o.gpus);
-        std::vector<fadehip_ctx *> ctxs((size_t)ngpu, nullptr);
+        // --gpus N uses devices 0..N-1; FADE_DEVICE_MAP="0,0" (tests on a one-GPU box) maps the N contexts elsewhere
+        std::vector<int> devmap((size_t)ngpu);
+        for (int d = 0; d < ngpu; d++) devmap[(size_t)d] = d;
+        bool distinct_devices = true;
+        if (const char *dm = getenv("FADE_DEVICE_MAP")) {
+            int d = 0;
+            for (const char *q = dm; *q && d < ngpu; d++) {
+                devmap[(size_t)d] = atoi(q);
+                q = strchr(q, ',');
+                if (!q) break;
+                q++;
+            }
+            for (int a = 0; a < ngpu; a++)
+                for (int b2 = a + 1; b2 < ngpu; b2++)
+                    if (devmap[(size_t)a] == devmap[(size_t)b2]) distinct_devices = false;
+        }
         fadehip_params prm;
-        fadehip_params_default(&prm);
+        fadehip_params_default(&prm);  // max_ref_len 2^20: any window the kernels can serve, whatever -w is
         prm.max_batch_reads = std::max(o.batch, 1);
         auto die = [&](fadehip_ctx *c, const char *what) {
             fprintf(stderr, "[E::fade annotate] %s: %s\n", what, fadehip_last_error(c));
-            for (auto *x : ctxs) fadehip_destroy(x);
             return 1;
         };
         ck_upload.start();
         for (int d = 0; d < ngpu; d++) {
-            if (fadehip_create(&ctxs[(size_t)d], d, &prm)) return die(nullptr, "cannot open the GPU path");
+            if (fadehip_create(&ctxs[(size_t)d], devmap[(size_t)d], &prm)) return die(nullptr, "cannot open the GPU path");
+            blocks[(size_t)d].ctx = ctxs[(size_t)d];
             if (fadehip_genome_upload(ctxs[(size_t)d], (int)lens.size(), lens.data(), ptrs.data())) return die(ctxs[(size_t)d], "genome upload");
         }
         ck_upload.stop();
@@ -354,18 +463,27 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         Pool wpool0(nthreads);
         Writer writer(stdout, fmt, hdr, &wpool0);
 
-        // three stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack, device, tags] -> [writer: format,
-        // BGZF deflate].  Each stage has its own pool; chunks keep their input order.
-        BoundedQueue<std::unique_ptr<Chunk>> q_in(2), q_out(2);
+        // Stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack into a pinned block, upload + run (both return
+        // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
+        // pool; chunks keep their input order.  The device calls are asynchronous, so this one thread keeps every slot
+        // of every device busy: batch k goes to device k % N, slot (k / N) % kSlotsInUse.
+        BoundedQueue<std::unique_ptr<Chunk>> q_in(2), q_out(3);
         std::string stage_err;
         std::mutex err_m;
         auto set_stage_err = [&](const std::string &e) {
             std::lock_guard<std::mutex> l(err_m);
             if (stage_err.empty()) stage_err = e;
         };
-        std::thread t_reader([&] {
+        std::atomic<bool> abort_stages{false};
+        StageThreads stages;
+        stages.unblock = [&] {
+            abort_stages = true;
+            q_in.close();
+            q_out.close();
+        };
+        stages.th.emplace_back([&] {
             try {
-                for (;;) {
+                while (!abort_stages) {
                     std::unique_ptr<Chunk> c(new Chunk());
                     ck_read.start();
                     const size_t got = reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
@@ -378,10 +496,17 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             }
             q_in.close();
         });
-        std::thread t_writer([&] {
+        stages.th.emplace_back([&] {
             std::unique_ptr<Chunk> c;
             try {
-                while (q_out.pop(c)) { ck_write.start(); writer.write(c->recs); ck_write.stop(); }
+                while (q_out.pop(c)) {
+                    ck_tags.start();
+                    apply_tags(*c, hdr, wpool0);
+                    ck_tags.stop();
+                    ck_write.start();
+                    writer.write(c->recs);
+                    ck_write.stop();
+                }
             } catch (const std::exception &e) {
                 set_stage_err(e.what());
                 while (q_out.pop(c)) {}
@@ -390,22 +515,28 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         std::deque<std::unique_ptr<Chunk>> inflight;
         int64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         std::vector<std::vector<int64_t>> per_dev((size_t)ngpu, std::vector<int64_t>(8, 0));
+        int64_t n_oversize = 0;
         bool failed = false;
         auto finish = [&](std::unique_ptr<Chunk> c) -> int {
-            c->out.rs = c->rs.data();
-            c->out.aln = c->aln.data();
-            c->out.aln_cap = (int)c->aln.size();
+            fadehip_anno_view v;
             ck_collect.start();
-            const int crc = fadehip_annotate_collect(ctxs[(size_t)c->dev], c->slot, &c->out);
+            const int crc = fadehip_annotate_results(ctxs[(size_t)c->dev], c->slot, &v);
+            if (!crc) {
+                // the slot's result block is reused by its next batch: keep what the writer stage needs
+                c->rs_sent.assign(v.rs, v.rs + v.n_reads);
+                c->art.clear();
+                for (int k = 0; k < v.n_aln; k++)
+                    if (v.aln[k].art) c->art.push_back(v.aln[k]);
+                for (int k = 0; k < 8; k++) per_dev[(size_t)c->dev][(size_t)k] += v.stats[k];
+                n_oversize += v.n_oversize;
+            }
             ck_collect.stop();
+            blocks[(size_t)c->dev].release(c->block, c->block_cap);
+            c->block = nullptr;
             if (crc) {
-                fprintf(stderr, "[E::fade annotate] collect: %s\n", fadehip_last_error(ctxs[(size_t)c->dev]));
+                fprintf(stderr, "[E::fade annotate] results: %s\n", fadehip_last_error(ctxs[(size_t)c->dev]));
                 return 1;
             }
-            for (int k = 0; k < 8; k++) per_dev[(size_t)c->dev][(size_t)k] += c->out.stats[k];
-            ck_tags.start();
-            apply_tags(*c, hdr, pool);
-            ck_tags.stop();
             q_out.push(std::move(c));
             return 0;
         };
@@ -415,17 +546,17 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             c->dev = (int)(seq_no % (size_t)ngpu);
             c->slot = (int)((seq_no / (size_t)ngpu) % kSlotsInUse);
             seq_no++;
+            // one batch per (device, slot): the batch that had this slot is fetched before the slot is handed the next
+            while (!failed && inflight.size() >= (size_t)ngpu * kSlotsInUse) {
+                if (finish(std::move(inflight.front()))) failed = true;
+                inflight.pop_front();
+            }
+            if (failed) break;
             ck_pack.start();
-            pack_chunk(*c, pool);
+            pack_chunk(*c, pool, blocks[(size_t)c->dev]);
             ck_pack.stop();
-            fadehip_read_batch b;
-            memset(&b, 0, sizeof b);
-            b.n_reads = (int)c->recs.size();
-            b.tid = c->tid.data(); b.pos = c->pos.data(); b.flag = c->flag.data(); b.has_sa = c->has_sa.data();
-            b.l_seq = c->l_seq.data(); b.cigar_off = c->cigar_off.data(); b.cigar_ops = c->cigar_ops.data();
-            b.seq_off = c->seq_off.data(); b.seq_packed = c->seq.data();
             ck_submit.start();
-            const int src = fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &b, o.floor_len, o.window);
+            const int src = fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &c->b, o.floor_len, o.window);
             ck_submit.stop();
             if (src) {
                 fprintf(stderr, "[E::fade annotate] submit: %s\n", fadehip_last_error(ctxs[(size_t)c->dev]));
@@ -433,49 +564,48 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 break;
             }
             inflight.push_back(std::move(c));
-            // one batch per slot in flight: the oldest is collected while the newest computes
-            while (!failed && inflight.size() > (size_t)ngpu * (kSlotsInUse - 1)) {
-                if (finish(std::move(inflight.front()))) failed = true;
-                inflight.pop_front();
-            }
         }
         while (!failed && !inflight.empty()) {
             if (finish(std::move(inflight.front()))) failed = true;
             inflight.pop_front();
         }
-        if (failed) {  // drain the reader so that it can exit
+        if (failed) {  // let the reader run out so that it can exit
+            abort_stages = true;
             while (q_in.pop(c)) {}
         }
         q_out.close();
-        t_reader.join();
-        t_writer.join();
+        for (auto &t : stages.th) t.join();
+        stages.unblock = nullptr;
         if (!stage_err.empty()) {
             fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str());
             failed = true;
         }
-        if (failed) {
-            for (auto *x : ctxs) fadehip_destroy(x);
-            return 1;
-        }
+        if (failed) return 1;
         writer.close();
+        if (n_oversize)
+            fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read longer than %d bases or window longer than %d\n",
+                    (long long)n_oversize, FADEHIP_MAX_LONG_QUERY, prm.max_ref_len);
         // the one collective of the path: sum the stats.d counters over the devices (RCCL over xGMI)
-        if (ngpu > 1) {
+        if (ngpu > 1 && distinct_devices) {
             std::vector<int64_t> flat((size_t)ngpu * 8);
             for (int d = 0; d < ngpu; d++) std::copy(per_dev[(size_t)d].begin(), per_dev[(size_t)d].end(), flat.begin() + d * 8);
             if (fadehip_stats_allreduce(ctxs.data(), ngpu, flat.data(), 8)) return die(ctxs[0], "stats all-reduce");
             std::copy(flat.begin(), flat.begin() + 8, totals);
-        } else std::copy(per_dev[0].begin(), per_dev[0].end(), totals);
+        } else {
+            // (several contexts mapped onto one device by FADE_DEVICE_MAP: RCCL takes one rank per device, sum here)
+            for (int d = 0; d < ngpu; d++)
+                for (int k = 0; k < 8; k++) totals[k] += per_dev[(size_t)d][(size_t)k];
+        }
         if (o.stats) {  // stats.d:56-72 layout
             const double rc = (double)std::max<int64_t>(totals[0], 1);
             fprintf(stderr, "read count:\t%lld\nClipped %%:\t%g\n%% With Supplementary alns:\t%g\nArtifact rate:\t%g\n"
                             "%% With Supplementary alns and artifacts:\t%g\nArtifact rate left only:\t%g\nArtifact rate right only:\t%g\n",
                     (long long)totals[0], totals[1] / rc, totals[2] / rc, totals[4] / rc, totals[3] / rc, totals[6] / rc, totals[7] / rc);
         }
-        for (auto *x : ctxs) fadehip_destroy(x);
         ck_total.stop();
         if (o.timing)
             fprintf(stderr, "[timing] total %.3f s: fasta %.3f, create+genome upload %.3f | reader stage %.3f | pack %.3f, "
-                            "submit %.3f, collect %.3f, tags %.3f | writer stage %.3f (stages overlap)\n",
+                            "submit %.3f, results %.3f | writer stage: tags %.3f, write %.3f (stages overlap)\n",
                     ck_total.t, ck_fasta.t, ck_upload.t, ck_read.t, ck_pack.t, ck_submit.t, ck_collect.t, ck_tags.t, ck_write.t);
     } catch (const std::exception &e) {
         fprintf(stderr, "[E::fade annotate] %s\n", e.what());

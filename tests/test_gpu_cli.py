@@ -87,3 +87,64 @@ def test_cli_flag_errors_and_help():
     assert _run([]).returncode == 0
     p = _run(["annotate", "--stats", "--batch", "100", os.path.join(GOLD, "anno_c1.sam"), os.path.join(GOLD, "anno_c1.fa")])
     assert p.returncode == 0 and b"read count:\t600" in p.stderr
+
+
+def test_cli_gpus_2_on_one_device_equals_gpus_1(tmp_path):
+    """`fade annotate --gpus 2`: batches dealt round-robin to two fadehip contexts, two slots each, all driven by one
+    asynchronous host thread.  On a one-GPU box FADE_DEVICE_MAP=0,0 puts both contexts on device 0 (their stats are
+    then summed on the host: RCCL takes one rank per device).  Output identical to --gpus 1, --stats included."""
+    from fade_amd import synth
+    cfg, g, b = synth.make_config("C5", 6000, contig_len=150_000)
+    names = [b"r%d" % (i // 2) for i in range(6000)]
+    b["qname"] = names
+    sam = tmp_path / "in.sam"
+    fa = tmp_path / "ref.fa"
+    sam.write_text(samutil.batch_to_sam(b, g.names, [int(x) for x in g.lengths], names))
+    fa.write_bytes(g.fasta_bytes())
+    base = ["annotate", "--stats", "--batch", "500", "--min-length", "5", "-w", "100"]
+    one = _run(base + [str(sam), str(fa)])
+    two = _run(base + ["--gpus", "2", str(sam), str(fa)], env=dict(os.environ, FADE_DEVICE_MAP="0,0"))
+    assert one.returncode == 0 and two.returncode == 0, one.stderr.decode() + two.stderr.decode()
+    strip_pg = lambda out: [l for l in out.decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
+    assert strip_pg(one.stdout) == strip_pg(two.stdout) and len(strip_pg(one.stdout)) > 6000
+    stats = lambda err: err.decode().split("read count:")[1]
+    assert stats(one.stderr) == stats(two.stderr) and stats(one.stderr).startswith("\t6000\n")
+
+
+@pytest.mark.parametrize("tag", ["anno_c1", "anno_c2", "anno_c5"])
+def test_cli_chain_annotate_extract_out(tmp_path, tag):
+    """The path and its consumers chained on device-produced tags: `fade annotate -b` (GPU) -> `fade extract`
+    (source/remap.d:29-85) and -> `fade out` / `fade out -c` (source/filter.d:15-91,190-266), each checked line by
+    line against its pure-Python restatement (oracle/pyremap.py, oracle/pyfilter.py) run on the annotate output."""
+    from oracle import pyfilter, pyremap
+    exp, floor_len, window = _expected(tag)
+    sam, fa = os.path.join(GOLD, tag + ".sam"), os.path.join(GOLD, tag + ".fa")
+    pa = _run(["annotate", "--min-length", str(floor_len), "-w", str(window), sam, fa])
+    assert pa.returncode == 0, pa.stderr.decode()
+    anno = tmp_path / "anno.sam"
+    anno.write_bytes(pa.stdout)
+    header, recs = samutil.parse_sam(pa.stdout.decode())
+    _check_records(recs, exp)
+    names = [h.split("\t")[1][3:] for h in header if h.startswith("@SQ")]
+    contig0 = names[0]
+    # extract
+    pe = _run(["extract", str(anno)])
+    assert pe.returncode == 0, pe.stderr.decode()
+    got = [l for l in pe.stdout.decode().splitlines() if not l.startswith("@")]
+    assert got == pyremap.extract_records(recs, names) and len(got) >= 10
+    # out, name-sorted branch (the golden inputs keep mates adjacent) and -c
+    for args, clip in (([], False), (["-c"], True)):
+        po = _run(["out"] + args + [str(anno)])
+        assert po.returncode == 0, po.stderr.decode()
+        lines = [l for l in po.stdout.decode().splitlines() if not l.startswith("@")]
+        want, stats = pyfilter.fade_out(recs, contig0, clip=clip)
+        assert lines == want and po.stderr.decode().endswith(stats)
+    # BAM all the way on pipes: annotate -b | out -b, and annotate -b | extract: same records as through the SAM files
+    cmd = "%s annotate -b --min-length %d -w %d %s %s | %s out - " % (FADE, floor_len, window, sam, fa, FADE)
+    pipe = subprocess.run(cmd, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert pipe.returncode == 0, pipe.stderr.decode()
+    strip = lambda text: [l for l in text.splitlines() if not l.startswith("@")]
+    assert strip(pipe.stdout.decode()) == pyfilter.fade_out(recs, contig0, clip=False)[0]
+    cmd = "%s annotate -b --min-length %d -w %d %s %s | %s extract -" % (FADE, floor_len, window, sam, fa, FADE)
+    pipe = subprocess.run(cmd, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert pipe.returncode == 0 and strip(pipe.stdout.decode()) == got, pipe.stderr.decode()
