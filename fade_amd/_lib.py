@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfadehip.so")
+LIB_PATH = os.environ.get("FADEHIP_LIB") or os.path.join(HERE, "libfadehip.so")  # FADEHIP_LIB: A/B builds of the same ABI
 
 MAX_OPS = 16
 NUM_SLOTS = 4

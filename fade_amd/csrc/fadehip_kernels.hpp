@@ -134,7 +134,11 @@ struct Cand {           // pass-2 work item: which alignment, and the sweep step
 // Pass 1 snapshots the whole wave state (H, E-hat of every row, the three values in flight between lanes and
 // the reference-class shift register) after every 32 steps of the anti-diagonal sweep, so pass 2 can resume
 // the sweep at any multiple of 32 exactly as if it had never stopped.
-constexpr int CK_SHIFT = 5, CK_COLS = 1 << CK_SHIFT;
+#ifndef FADEHIP_CK_SHIFT
+#define FADEHIP_CK_SHIFT 7
+#endif
+constexpr int CK_SHIFT = FADEHIP_CK_SHIFT, CK_COLS = 1 << CK_SHIFT;  // snapshot stride (a multiple of the 32-step key window)
+static_assert(CK_SHIFT >= 5 && CK_SHIFT <= 9, "snapshots fall on key-window ends");
 __host__ __device__ constexpr int ck_dwords(int R) { return 2 * R + 4; }  // per lane per snapshot
 constexpr int NUM_BUCKETS = 10;                       // pass-2 lists by number of sweep steps to re-compute
 __host__ __device__ constexpr int bucket_cols(int b) {
@@ -868,47 +872,66 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
             const int lq = (int)w.lq;
             const bool n_eq_n = rule(rules, FADEHIP_RULE_N_MATCHES_N), eq_by_char = rule(rules, FADEHIP_RULE_EQ_BY_CHAR);
             const bool pad = rule(rules, FADEHIP_RULE_PAD_SOFTCLIP);
-            constexpr int MAX_RUNS = FADEHIP_MAX_OPS - 2;
-            uint32_t runs[MAX_RUNS];  // generated from the end cell backwards
+            // Up to four runs of = / X are kept, in registers (r0 = the run nearest the start of the alignment): a forced
+            // diagonal with more mismatching stretches than that goes to pass 2 like a gapped path.  Nothing here is
+            // indexed dynamically, so the score pass needs no scratch memory.
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
             int n_runs = 0, cur_op = -1;
             uint32_t cur_len = 0;
             int P = f.score, L = 0;
             bool ok = false, give_up = false;
             const int kmax = min(f.end_q, f.end_r) + 1;  // cells of the diagonal inside the matrix
-            for (int k0 = 0; k0 < kmax && !ok && !give_up; k0 += 8) {
-                const int nv = min(8, kmax - k0);
-                const uint64_t qn_lo = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - f.end_q + k0)
-                                           : (uint64_t)w.q_base + (uint32_t)(f.end_q - k0 - (nv - 1));
-                const uint64_t rn_lo = w.r_base + (uint64_t)(f.end_r - k0 - (nv - 1));
-                const Nib8 qw = load_nib8(q_nib, qn_lo), rw = load_nib8(r_nib, rn_lo);
+            auto push_run = [&](uint32_t v) {
+                r3 = r2; r2 = r1; r1 = r0; r0 = v;
+                n_runs++;
+            };
+            // 32 cells per round trip: the loads of four 8-cell pieces are issued together
+            for (int k0 = 0; k0 < kmax && !ok && !give_up; k0 += 32) {
+                Nib8 qw[4], rw[4];
+                uint64_t qlo[4], rlo[4];
+                int nv[4];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (k < nv && !ok && !give_up) {
-                        const uint32_t qraw = nib8_at(qw, rcq ? qn_lo + (uint32_t)k : qn_lo + (uint32_t)(nv - 1 - k));
-                        const uint32_t qc = rcq ? lut4(COMP_LUT, qraw) : qraw, rc = nib8_at(rw, rn_lo + (uint32_t)(nv - 1 - k));
-                        const uint32_t cq = lut4(CLASS_LUT, qc), cr = lut4(CLASS_LUT, rc);
-                        const int wsc = (cq == 5 || cr == 5) ? 0 : ((cq == cr && (cq != 4 || n_eq_n)) ? a.match : a.mismatch);
-                        const int op = (eq_by_char ? (qc == rc && qc != 0) : wsc > 0) ? 7 : 8;
-                        if (op == cur_op) cur_len++;
-                        else {
-                            if (cur_op >= 0) {
-                                if (n_runs < MAX_RUNS) runs[n_runs] = (cur_len << 4) | (uint32_t)cur_op;
-                                n_runs++;
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k0 + 8 * u;
+                    nv[u] = max(0, min(8, kmax - kk));
+                    qlo[u] = rlo[u] = 0;
+                    qw[u].word = rw[u].word = 0;
+                    qw[u].byte0 = rw[u].byte0 = 0;
+                    if (nv[u] > 0) {
+                        qlo[u] = rcq ? (uint64_t)w.q_base + (uint32_t)(lq - 1 - f.end_q + kk)
+                                     : (uint64_t)w.q_base + (uint32_t)(f.end_q - kk - (nv[u] - 1));
+                        rlo[u] = w.r_base + (uint64_t)(f.end_r - kk - (nv[u] - 1));
+                        qw[u] = load_nib8(q_nib, qlo[u]);
+                        rw[u] = load_nib8(r_nib, rlo[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (k < nv[u] && !ok && !give_up) {
+                            const uint32_t qraw = nib8_at(qw[u], rcq ? qlo[u] + (uint32_t)k : qlo[u] + (uint32_t)(nv[u] - 1 - k));
+                            const uint32_t qc = rcq ? lut4(COMP_LUT, qraw) : qraw, rc = nib8_at(rw[u], rlo[u] + (uint32_t)(nv[u] - 1 - k));
+                            const uint32_t cq = lut4(CLASS_LUT, qc), cr = lut4(CLASS_LUT, rc);
+                            const int wsc = (cq == 5 || cr == 5) ? 0 : ((cq == cr && (cq != 4 || n_eq_n)) ? a.match : a.mismatch);
+                            const int op = (eq_by_char ? (qc == rc && qc != 0) : wsc > 0) ? 7 : 8;
+                            if (op == cur_op) cur_len++;
+                            else {
+                                if (cur_op >= 0) push_run((cur_len << 4) | (uint32_t)cur_op);
+                                cur_op = op;
+                                cur_len = 1;
                             }
-                            cur_op = op;
-                            cur_len = 1;
+                            P -= wsc;
+                            L = k0 + 8 * u + k + 1;
+                            if (P == 0) ok = true;
+                            else if (P < 0) give_up = true;
                         }
-                        P -= wsc;
-                        L = k0 + k + 1;
-                        if (P == 0) ok = true;
-                        else if (P < 0) give_up = true;
                     }
                 }
             }
             if (ok) {
-                if (n_runs < MAX_RUNS) runs[n_runs] = (cur_len << 4) | (uint32_t)cur_op;
-                n_runs++;
-                if (n_runs > MAX_RUNS) ok = false;
+                push_run((cur_len << 4) | (uint32_t)cur_op);
+                if (n_runs > 4) ok = false;
             }
             if (ok) {
                 cand = false;
@@ -920,16 +943,29 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
                 o.sw.end_ref = f.end_r;
                 o.sw.beg_query = f.end_q - L + 1;
                 o.sw.beg_ref = f.end_r - L + 1;
-                for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
                 const int lead = o.sw.beg_query, tail = lq - 1 - f.end_q;
-                int n = 0;
-                uint32_t first_op = 0, last_op = 0;
-                if (pad && lead > 0) o.sw.ops[n++] = ((uint32_t)lead << 4) | 4u;
-                for (int k = n_runs - 1; k >= 0; k--) o.sw.ops[n++] = runs[k];
-                if (pad && tail > 0) o.sw.ops[n++] = ((uint32_t)tail << 4) | 4u;
+                // [lead S] r0 .. r(n_runs-1) [tail S], assembled by shifting (no dynamic index)
+                uint32_t e0 = r0, e1 = r1, e2 = r2, e3 = r3, e4 = 0, e5 = 0;
+                int n = n_runs;
+                const uint32_t tail_op = ((uint32_t)tail << 4) | 4u;
+                if (pad && tail > 0) {
+                    if (n == 1) e1 = tail_op;
+                    else if (n == 2) e2 = tail_op;
+                    else if (n == 3) e3 = tail_op;
+                    else e4 = tail_op;
+                    n++;
+                }
+                if (pad && lead > 0) {
+                    e5 = e4; e4 = e3; e3 = e2; e2 = e1; e1 = e0;
+                    e0 = ((uint32_t)lead << 4) | 4u;
+                    n++;
+                }
+                o.sw.ops[0] = e0; o.sw.ops[1] = e1; o.sw.ops[2] = e2; o.sw.ops[3] = e3; o.sw.ops[4] = e4; o.sw.ops[5] = e5;
+#pragma unroll
+                for (int k = 6; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
                 o.sw.n_ops = n;
-                first_op = o.sw.ops[0];
-                last_op = o.sw.ops[n - 1];
+                const uint32_t first_op = e0;
+                const uint32_t last_op = n == 1 ? e0 : n == 2 ? e1 : n == 3 ? e2 : n == 4 ? e3 : n == 5 ? e4 : e5;
                 if (a.meta) {
                     const Meta m = a.meta[item];
                     o.win_start = m.win_start;
@@ -1401,8 +1437,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             bestA[r] = 0;
         }
         // snapshot of the wave state after step 32(k+1)-1
-        const int sn = blk0 >> 3;
-        if (blk_end == blk0 + 8 && sn < a.n_ck) {
+        constexpr int WIN_PER_CK = CK_COLS / 32;
+        const int sn = ((blk0 >> 3) + 1) / WIN_PER_CK - 1;
+        if (blk_end == blk0 + 8 && ((blk0 >> 3) + 1) % WIN_PER_CK == 0 && sn < a.n_ck) {
             constexpr int CKD = ck_dwords(R);
             uint32_t *cp = ckw + (uint64_t)sn * (CKD * 64);
 #pragma unroll
@@ -1559,8 +1596,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         // the members whose path left the traced steps stay, with T0 further back; the others are done
         haveA = haveA && ((inc >> (2 * g)) & 1ull);
         haveB = haveB && ((inc >> (2 * g + 1)) & 1ull);
-        c0A = (attempt == 0 && c0A > 4u * CK_COLS) ? c0A - 4u * CK_COLS : 0u;
-        c0B = (attempt == 0 && c0B > 4u * CK_COLS) ? c0B - 4u * CK_COLS : 0u;
+        constexpr uint32_t BACK = CK_COLS >= 128 ? (uint32_t)CK_COLS : 128u;  // a multiple of the snapshot stride
+        c0A = (attempt == 0 && c0A > BACK) ? c0A - BACK : 0u;
+        c0B = (attempt == 0 && c0B > BACK) ? c0B - BACK : 0u;
         if (lane == 0 && a.rerun_total) atomicAdd(a.rerun_total, (unsigned long long)__popcll(inc));
         __syncthreads();  // the octet's window is staged again
     }

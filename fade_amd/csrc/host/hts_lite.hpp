@@ -205,15 +205,28 @@ struct Rec {
     size_t qual_off() const { return seq_off() + ((size_t)l_seq() + 1) / 2; }
     const uint8_t *qual() const { return d.data() + qual_off(); }
     size_t aux_off() const { return qual_off() + (size_t)l_seq(); }
-    // the fixed fields must describe a layout that fits the record (a corrupt length would send every accessor out of bounds)
-    bool layout_ok() const { return d.size() >= 32 && l_seq() >= 0 && l_qname() >= 1 && aux_off() <= d.size(); }
+    // The fixed fields must describe a layout that fits the record, and the aux area must be a sequence of whole fields
+    // that ends exactly at the end of the record: every accessor, the tag updates and the SAM formatter index with these
+    // lengths, so a truncated or crafted record is rejected here, once, when it is read.
+    bool layout_ok() const {
+        if (!(d.size() >= 32 && l_seq() >= 0 && l_qname() >= 1 && aux_off() <= d.size())) return false;
+        size_t p = aux_off();
+        while (p < d.size()) {
+            if (p + 3 > d.size()) return false;
+            const size_t fs = aux_field_size(p + 2);
+            if (!fs) return false;
+            p += 2 + fs;
+        }
+        return p == d.size();
+    }
 
-    // size in bytes of the aux field whose type byte is at p (p points at the type), 0 on corruption
+    // size in bytes of the aux field whose type byte is at p (type byte included), 0 if the field is malformed or does
+    // not fit inside the record
     size_t aux_field_size(size_t p) const {
         if (p >= d.size()) return 0;
         const uint8_t t = d[p];
-        int s = aux_type_size(t);
-        if (s) return 1 + (size_t)s;
+        const int s = aux_type_size(t);
+        if (s) return p + 1 + (size_t)s <= d.size() ? 1 + (size_t)s : 0;
         if (t == 'Z' || t == 'H') {
             size_t q = p + 1;
             while (q < d.size() && d[q]) q++;
@@ -221,9 +234,11 @@ struct Rec {
         }
         if (t == 'B') {
             if (p + 6 > d.size()) return 0;
-            int es = aux_type_size(d[p + 1]);
-            uint32_t n = rd<uint32_t>(p + 2);
-            return es ? 6 + (size_t)es * n : 0;
+            const int es = aux_type_size(d[p + 1]);
+            const uint64_t n = rd<uint32_t>(p + 2);
+            if (!es) return 0;
+            const uint64_t fs = 6 + (uint64_t)es * n;  // 64-bit: a 32-bit count times 8 overflows size_t nowhere, uint32 everywhere
+            return fs <= (uint64_t)(d.size() - p) ? (size_t)fs : 0;
         }
         return 0;
     }
@@ -741,6 +756,9 @@ public:
             uint16_t bs;
             memcpy(&bs, h + 16, 2);
             const size_t bsize = (size_t)bs + 1;
+            // header (12 + XLEN) + at least an empty deflate stream + CRC32 + ISIZE: a smaller BSIZE would put the
+            // trailer reads below in front of the block
+            if (bsize < 12 + (size_t)xlen + 8) throw std::runtime_error("corrupt BGZF block (BSIZE smaller than its own header and trailer)");
             const size_t o = comp_.size();
             comp_.resize(o + bsize);
             if (src_->read(comp_.data() + o, bsize) != bsize) throw std::runtime_error("truncated BGZF block");
@@ -752,6 +770,7 @@ public:
         for (size_t k = 0; k < offs_.size(); k++) {
             uint32_t v;
             memcpy(&v, comp_.data() + offs_[k].off + offs_[k].size - 4, 4);
+            if (v > 65536) throw std::runtime_error("corrupt BGZF block (ISIZE beyond 64 KiB)");  // the format's limit: 512 blocks cannot ask for more than 32 MiB
             isz[k] = v;
             ooff[k + 1] = ooff[k] + v;
         }

@@ -11,13 +11,15 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_C2"
+config = sys.argv[2] if len(sys.argv) > 2 else "C2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
+calib = os.path.join(root, "gpurun_out", "prof_calib")
 
 
 def load(d):
-    f = glob.glob(os.path.join(base, d, "*", "*_counter_collection.csv"))[0]
+    f = glob.glob(os.path.join(calib if d.startswith("calib") else base, d, "*", "*_counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -28,8 +30,9 @@ def load(d):
 calib_bytes = 2 << 30
 wcal = [v["WRITE_SIZE"] for k, v in cw.items() if "calib_write" in k][0] * 1024 / calib_bytes
 fcal = [v["FETCH_SIZE"] for k, v in cf.items() if "calib_read" in k][0] * 1024 / calib_bytes
-out = {"source": "rocprofv3 --pmc (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu --slots 1`, MI355X",
-       "workload": "C2: 1000000 x 150 bp PE reads per GPU per step, -w 100",
+out = {"source": "rocprofv3 --pmc (separate passes) on `python3 bench.py --config %s --steps 2 --warmup 1 --no-cpu --slots 1`, MI355X; "
+                 "per-launch averages over all launches of the run" % config,
+       "workload": config,
        "units": "FETCH_SIZE/WRITE_SIZE are KiB; corrected as MI355X_MICROARCH.md §HBM prescribes and as calibrated here",
        "calibration": {"known_bytes": calib_bytes, "WRITE_SIZE_reported_over_true": wcal,
                        "FETCH_SIZE_reported_over_true": fcal},
@@ -47,7 +50,9 @@ for k in fetch:
         e["valu_busy_frac"] = s["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)  # quad-cycles; 1024 SIMDs
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(root, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
-shutil.copy(glob.glob(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
+shutil.copy(glob.glob(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(root, "profiles", tag + "_kernel_stats_1slot.csv"))
+shutil.copy(glob.glob(os.path.join(base, "stats2", "*", "*_kernel_stats.csv"))[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(base, "bench_under_rocprof.json"), os.path.join(root, "profiles", tag + "_bench_under_rocprof.json"))
 for d, f in (("fetch", f1), ("write", f2), ("calib_fetch", f3), ("calib_write", f4), ("sq", f5)):
     shutil.copy(f, os.path.join(root, "profiles", "%s_pmc_%s.csv" % (tag, d)))
 for k, e in out["kernels"].items():

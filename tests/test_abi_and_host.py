@@ -158,3 +158,15 @@ def test_compact_sequences_keeps_exactly_the_records_the_gate_reads():
             assert np.array_equal(c["seq_packed"][cs[i]:cs[i + 1]], b["seq_packed"][so[i]:so[i + 1]])
             kept += 1
     assert 0 < kept < len(b["pos"]) // 2 and cs[-1] == len(c["seq_packed"])
+
+
+def test_corrupt_bam_and_bgzf_inputs_are_rejected_under_sanitizers():
+    """host/hts_lite.hpp against truncated / crafted records and blocks, built with ASan + UBSan
+    (fade_amd/csrc/host/selftest/hts_selftest.cpp): aux fields that overrun the record, 'B' arrays with huge counts,
+    an rs tag cut short, BSIZE smaller than the block's own header, ISIZE beyond 64 KiB."""
+    import subprocess
+    csrc = os.path.join(ROOT, "fade_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-s", "build/hts_selftest"])
+    p = subprocess.run([os.path.join(csrc, "build", "hts_selftest")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
+    assert b"all corrupt-input cases rejected cleanly" in p.stdout

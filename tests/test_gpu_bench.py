@@ -1,0 +1,42 @@
+"""bench.py's own launch logic on the GPU box: `--gpus N` outside torchrun must start N fresh ranks (before anything has
+touched the GPU), report n_gpus = N and reduce the stats over all of them.  Two ranks share the box's one GPU here, so
+the collective runs over gloo (FADE_BENCH_BACKEND); on a multi-GPU node the same code path uses RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()  # ONE json line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_ranks_and_reduces_over_them():
+    small = ["--steps", "2", "--warmup", "1", "--batch-reads", "20000", "--no-cpu"]
+    one = _bench(["--gpus", "1"] + small)
+    two = _bench(["--gpus", "2"] + small, env={"FADE_BENCH_BACKEND": "gloo", "MASTER_PORT": "29611"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    per_step = 20000 * 10
+    assert one["stats"]["read_count"] == 2 * per_step and two["stats"]["read_count"] == 2 * 2 * per_step
+    assert two["stats"]["art"] > one["stats"]["art"] > 0  # rank 1 annotates its own shard (other seeds)
+    for r in (one, two):
+        assert r["roofline"]["kernel"].startswith("sw_pk_kernel<10,1>") and 0 < r["roofline"]["frac"] < 0.05
+        assert abs(r["roofline"]["bytes_per_unit"] - 316) < 10  # 75 + 161 + 16 + 64
+        assert r["value"] > 0 and r["value_resident"] > 0 and r["cpu_baseline"] is None
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
+    assert p.returncode == 2 and b"WORLD_SIZE" in p.stderr
