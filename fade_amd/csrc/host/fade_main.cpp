@@ -397,6 +397,40 @@ static int annotate_main(const std::string &cl, const Opts &o) {
     try {
         Pool rpool0(nthreads);
         Reader reader(o.pos[1], &rpool0);   // anno.d:22 (the reader stage inflates / parses on its own pool)
+        // (the reader starts at once: the first batches inflate while the FASTA loads and the genome goes to HBM)
+        // Stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack into a pinned block, upload + run (both return
+        // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
+        // pool; chunks keep their input order.  The device calls are asynchronous, so this one thread keeps every slot
+        // of every device busy: batch k goes to device k % N, slot (k / N) % kSlotsInUse.
+        BoundedQueue<std::unique_ptr<Chunk>> q_in(2), q_out(3);
+        std::string stage_err;
+        std::mutex err_m;
+        auto set_stage_err = [&](const std::string &e) {
+            std::lock_guard<std::mutex> l(err_m);
+            if (stage_err.empty()) stage_err = e;
+        };
+        std::atomic<bool> abort_stages{false};
+        StageThreads stages;
+        stages.unblock = [&] {
+            abort_stages = true;
+            q_in.close();
+            q_out.close();
+        };
+        stages.th.emplace_back([&] {
+            try {
+                while (!abort_stages) {
+                    std::unique_ptr<Chunk> c(new Chunk());
+                    ck_read.start();
+                    const size_t got = reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
+                    ck_read.stop();
+                    if (got == 0) break;
+                    q_in.push(std::move(c));
+                }
+            } catch (const std::exception &e) {
+                set_stage_err(e.what());
+            }
+            q_in.close();
+        });
         ck_fasta.start();
         Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
         ck_fasta.stop();
@@ -463,40 +497,13 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         Pool wpool0(nthreads);
         Writer writer(stdout, fmt, hdr, &wpool0);
 
-        // Stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack into a pinned block, upload + run (both return
-        // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
-        // pool; chunks keep their input order.  The device calls are asynchronous, so this one thread keeps every slot
-        // of every device busy: batch k goes to device k % N, slot (k / N) % kSlotsInUse.
-        BoundedQueue<std::unique_ptr<Chunk>> q_in(2), q_out(3);
-        std::string stage_err;
-        std::mutex err_m;
-        auto set_stage_err = [&](const std::string &e) {
-            std::lock_guard<std::mutex> l(err_m);
-            if (stage_err.empty()) stage_err = e;
-        };
-        std::atomic<bool> abort_stages{false};
-        StageThreads stages;
-        stages.unblock = [&] {
+        StageThreads wstage;  // declared after the writer it uses: joined before the writer goes away
+        wstage.unblock = [&] {
             abort_stages = true;
             q_in.close();
             q_out.close();
         };
-        stages.th.emplace_back([&] {
-            try {
-                while (!abort_stages) {
-                    std::unique_ptr<Chunk> c(new Chunk());
-                    ck_read.start();
-                    const size_t got = reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
-                    ck_read.stop();
-                    if (got == 0) break;
-                    q_in.push(std::move(c));
-                }
-            } catch (const std::exception &e) {
-                set_stage_err(e.what());
-            }
-            q_in.close();
-        });
-        stages.th.emplace_back([&] {
+        wstage.th.emplace_back([&] {
             std::unique_ptr<Chunk> c;
             try {
                 while (q_out.pop(c)) {
@@ -574,7 +581,9 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             while (q_in.pop(c)) {}
         }
         q_out.close();
+        for (auto &t : wstage.th) t.join();
         for (auto &t : stages.th) t.join();
+        wstage.unblock = nullptr;
         stages.unblock = nullptr;
         if (!stage_err.empty()) {
             fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str());

@@ -18,7 +18,7 @@ from fade_amd import synth  # noqa: E402
 NT16 = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
 
 
-def write_sam(path, batch, g):
+def write_sam(path, batch, g, append=False, name_base=0):
     n = len(batch["pos"])
     lq = int(batch["l_seq"][0])
     b = batch["seq_packed"].reshape(n, -1)
@@ -29,18 +29,19 @@ def write_sam(path, batch, g):
     quals = (batch["qual"].reshape(n, lq) + 33).astype(np.uint8)
     ops = "MIDNSHP=X"
     co = batch["cigar_off"]
-    with open(path, "wb") as f:
-        f.write(b"@HD\tVN:1.6\tSO:unsorted\n")
-        for nm, ln in zip(g.names, g.lengths):
-            f.write(b"@SQ\tSN:%s\tLN:%d\n" % (nm.encode(), ln))
-        f.write(b"@PG\tID:synth\tPN:fade_amd.synth\n")
+    with open(path, "ab" if append else "wb") as f:
+        if not append:
+            f.write(b"@HD\tVN:1.6\tSO:unsorted\n")
+            for nm, ln in zip(g.names, g.lengths):
+                f.write(b"@SQ\tSN:%s\tLN:%d\n" % (nm.encode(), ln))
+            f.write(b"@PG\tID:synth\tPN:fade_amd.synth\n")
         out = []
         for i in range(n):
             c = batch["cigar_ops"][co[i]:co[i + 1]]
             cig = "".join("%d%s" % (int(o) >> 4, ops[int(o) & 15]) for o in c) or "*"
             tid = int(batch["tid"][i])
             out.append(b"r%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s%s\n" % (
-                i // 2, int(batch["flag"][i]), g.names[tid].encode() if tid >= 0 else b"*", int(batch["pos"][i]) + 1,
+name_base + i // 2, int(batch["flag"][i]), g.names[tid].encode() if tid >= 0 else b"*", int(batch["pos"][i]) + 1,
                 60 if tid >= 0 else 0, cig.encode(), seqs[i].tobytes(), quals[i].tobytes(),
                 b"\tSA:Z:chr1,1,+,50M,60,0;" if batch["has_sa"][i] else b""))
             if len(out) >= 100000:
@@ -55,33 +56,54 @@ def main():
     tmp = os.environ.get("TMPDIR", "/tmp")
     cfg = synth.config("C2")
     g = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s"])
     t0 = time.time()
-    b = synth.make_reads(g, n, 100, **cfg)
     fa, sam, bam = os.path.join(tmp, "e2e.fa"), os.path.join(tmp, "e2e.sam"), os.path.join(tmp, "e2e.bam")
     open(fa, "wb").write(g.fasta_bytes())
-    write_sam(sam, b, g)
-    print("inputs written in %.1f s" % (time.time() - t0), flush=True)
+    # the reads in pieces of 1 M (memory), appended to one SAM, then converted to an un-annotated BAM
+    done = 0
+    while done < n:
+        m = min(1_000_000, n - done)
+        b = synth.make_reads(g, m, 100 + done // 1_000_000, **cfg)
+        write_sam(sam, b, g, append=done > 0, name_base=done // 2)
+        done += m
+    with open(bam, "wb") as fo:
+        subprocess.check_call([os.path.join(ROOT, "tools", "sam2bam"), sam], stdout=fo)
+    print("inputs written in %.1f s (%d reads, BAM %d bytes)" % (time.time() - t0, n, os.path.getsize(bam)), flush=True)
     fade = os.path.join(ROOT, "fade_amd", "fade")
-    base = [fade, "annotate", "--timing", "-t", str(threads), "-w", str(cfg["window"]), "--batch", "262144"]
+    cpu = os.path.join(ROOT, "tools", "cpu_annotate")
     res = {}
 
-    def run(tag, args, out):
-        t = time.time()
+    def run(tag, exe, args, out, t):
+        base = [exe, "annotate", "--timing", "-t", str(t), "-w", str(cfg["window"]), "--batch", "262144"]
+        t1 = time.time()
         with open(out, "wb") as fo:
             p = subprocess.run(base + args, stdout=fo, stderr=subprocess.PIPE)
-        dt = time.time() - t
+        dt = time.time() - t1
         assert p.returncode == 0, p.stderr.decode()
-        res[tag] = dict(seconds=dt, reads_per_s=n / dt, out_bytes=os.path.getsize(out),
+        res[tag] = dict(seconds=dt, reads_per_s=n / dt, out_bytes=os.path.getsize(out), threads=t,
                         timing=[l for l in p.stderr.decode().splitlines() if l.startswith("[timing]")])
         print(tag, res[tag], flush=True)
 
-    run("sam_to_bam", ["-b", sam, fa], bam)  # also produces the BAM input for the next runs
-    run("bam_to_bam", ["-b", bam, fa], os.path.join(tmp, "e2e.out.bam"))
-    run("bam_to_ubam", ["-u", bam, fa], os.path.join(tmp, "e2e.out.ubam"))
-    run("bam_to_sam", [bam, fa], os.path.join(tmp, "e2e.out.sam"))
+    out_gpu, out_cpu = os.path.join(tmp, "e2e.gpu.bam"), os.path.join(tmp, "e2e.cpu.bam")
+    run("gpu_bam_to_bam", fade, ["-b", bam, fa], out_gpu, threads)
+    run("gpu_bam_to_ubam", fade, ["-u", bam, fa], os.path.join(tmp, "e2e.out.ubam"), threads)
+    run("gpu_sam_to_bam", fade, ["-b", sam, fa], os.path.join(tmp, "e2e.out2.bam"), threads)
+    # the CPU comparator: the same reader / writer around the striped AVX2 restatement of annotateTask
+    run("cpu_bam_to_bam", cpu, ["-b", bam, fa], out_cpu, threads)
+    if threads != 32:
+        run("cpu_bam_to_bam_32_threads", cpu, ["-b", bam, fa], out_cpu, 32)
+    res["gpu_over_cpu_same_threads"] = res["gpu_bam_to_bam"]["reads_per_s"] / res["cpu_bam_to_bam"]["reads_per_s"]
+    # same records from both (the BGZF payloads: everything but the header's @PG CL field)
+    if n <= 4_000_000:
+        import gzip
+        a, c = gzip.decompress(open(out_gpu, "rb").read()), gzip.decompress(open(out_cpu, "rb").read())
+        la, lc = int.from_bytes(a[4:8], "little"), int.from_bytes(c[4:8], "little")
+        res["gpu_and_cpu_records_identical"] = a[8 + la:] == c[8 + lc:]
+        assert res["gpu_and_cpu_records_identical"]
     res["n_reads"] = n
-    res["threads"] = threads
-    res["note"] = "includes loading + uploading the 100 Mbp FASTA (text -> 4-bit in HBM) once per run"
+    res["note"] = ("wall time of the whole process: HIP start-up, loading the 100 Mbp FASTA, its upload (text -> 4-bit in HBM), "
+                   "BGZF inflate, annotate, tags, BGZF deflate; GPU and CPU legs share reader / writer code and thread count")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "e2e_cli.json"), "w"), indent=1)
 
