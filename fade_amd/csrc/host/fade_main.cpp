@@ -198,7 +198,11 @@ struct BlockPool {
 };
 
 struct Chunk {
-    std::vector<Rec> recs;
+    std::vector<Rec> recs;       // SAM input: parsed records
+    RecordBlock blk;             // BAM input: records framed in place in the inflated bytes (no per-record copy)
+    Writer::BlockOut bout;       // ... and what annotate adds to them
+    bool is_block = false;
+    size_t n_records() const { return is_block ? blk.size() : recs.size(); }
     // anno.d:61-65: an unmapped record, or one without an S op, gets rs = 0 and nothing else: such records are not sent.
     std::vector<uint32_t> sent;  // indices (into recs) of the records that are
     fadehip_read_batch b;        // bound into `block`
@@ -212,7 +216,8 @@ struct Chunk {
     int dev = 0, slot = 0;
 };
 
-static inline bool needs_device(const Rec &r) {
+template <class R>
+static inline bool needs_device(const R &r) {
     if (r.flag() & 4) return false;
     for (int k = 0; k < r.n_cigar(); k++)
         if ((r.cigar_op(k) & 15u) == 4u) return true;
@@ -220,8 +225,9 @@ static inline bool needs_device(const Rec &r) {
 }
 
 // records -> the batch block, in parallel: count per range, prefix, fill
-static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
-    const size_t n = c.recs.size();
+template <class Get>
+static void pack_chunk_t(Chunk &c, Pool &pool, BlockPool &blocks, const Get &get) {
+    const size_t n = c.n_records();
     const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)pool.size(), n / 4096 + 1));
     struct Range { size_t n_sent = 0, n_cig = 0, n_seq = 0; int64_t span = 0; };
     std::vector<Range> rg(nt + 1);
@@ -229,7 +235,7 @@ static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
     pool.parallel_for(nt, [&](size_t t) {
         Range r;
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
-            const Rec &rec = c.recs[i];
+            const auto &rec = get(i);
             need[i] = needs_device(rec) ? 1 : 0;
             if (!need[i]) continue;
             r.n_sent++;
@@ -259,7 +265,7 @@ static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
         size_t k = rg[t].n_sent, nc = rg[t].n_cig, nq = rg[t].n_seq;
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
             if (!need[i]) continue;
-            const Rec &r = c.recs[i];
+            const auto &r = get(i);
             c.sent[k] = (uint32_t)i;
             tid[k] = r.tid();
             pos[k] = r.pos();
@@ -281,6 +287,10 @@ static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
     c.b.n_skipped = (int32_t)(n - ns);
     c.b.ref_span_bound = (int32_t)std::min<int64_t>(span, INT32_MAX);
 }
+static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
+    if (c.is_block) pack_chunk_t(c, pool, blocks, [&](size_t i) { return c.blk.view(i); });
+    else pack_chunk_t(c, pool, blocks, [&](size_t i) -> const Rec & { return c.recs[i]; });
+}
 
 static std::string cigar_string(const uint32_t *ops, int n) {
     std::string s;
@@ -291,67 +301,134 @@ static std::string cigar_string(const uint32_t *ops, int n) {
     return s;
 }
 
-// analysis.d:84-92 / 108-118 + anno.d:94-107
-static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
-    const size_t n = c.recs.size();
+// The four strings of an artifact call: analysis.d:84-92 / 108-118 + anno.d:98-107 (am, as, ar, ab; "left;right").
+template <class R>
+static void artifact_strings(const R &r, const fadehip_aln &a, const Header &h, std::string out[4]) {
     static const uint8_t comp[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};  // util.d:18-20
-    // rs of every record (0 for the ones anno.d:61-65 settles without the device), then the artifact strings (few),
-    // keeping the reference's tag order rs, am, as, ar, ab
+    const int lq = r.l_seq();
+    std::string seq((size_t)lq, 'N'), qrc((size_t)lq, 'N'), bq((size_t)lq, '!');
+    const uint8_t *sq = r.seq(), *ql = r.qual();
+    for (int j = 0; j < lq; j++) {
+        const int code = (sq[j >> 1] >> ((~j & 1) << 2)) & 15;
+        seq[(size_t)j] = NT16_STR[code];
+        qrc[(size_t)(lq - 1 - j)] = NT16_STR[comp[code]];  // util.d:23-34
+        bq[(size_t)j] = (char)(ql[j] + 33);
+    }
+    const int nops = std::min(a.sw.n_ops, FADEHIP_MAX_OPS);
+    const std::string cig = cigar_string(a.sw.ops, nops);
+    const int64_t apos = a.win_start + a.sw.beg_ref;
+    const int64_t pos = r.pos();
+    std::string am = (r.tid() >= 0 && r.tid() < (int)h.names.size() ? h.names[(size_t)r.tid()] : std::string("*"));
+    am += ',';
+    append_int(am, apos);
+    am += ',';
+    am += cig;
+    std::string l[4], rr[4];
+    if (a.art & 1) {  // analysis.d:84-92
+        const int64_t clip = a.clip_left;
+        const int64_t overlap = apos >= pos - clip ? apos - (pos - clip) : 0;
+        const int64_t lead = (a.sw.ops[0] & 15) == 4 ? (a.sw.ops[0] >> 4) : 0;
+        const int64_t plen = std::min<int64_t>(lq, (lq - lead) + overlap);
+        l[0] = am; l[1] = seq.substr(0, (size_t)plen); l[2] = qrc.substr((size_t)(lq - plen)); l[3] = bq.substr(0, (size_t)plen);
+    }
+    if (a.art & 2) {  // analysis.d:108-118
+        const int64_t clip = a.clip_right;
+        int64_t res_al = 0;
+        for (int q = 0; q < nops; q++) {
+            const uint32_t op = a.sw.ops[q] & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) res_al += a.sw.ops[q] >> 4;
+        }
+        const int64_t lhs = pos + a.aligned_len + clip, rhs = apos + res_al;
+        const int64_t overlap = lhs >= rhs ? lhs - rhs : 0;
+        const int64_t trail = (a.sw.ops[nops - 1] & 15) == 4 ? (a.sw.ops[nops - 1] >> 4) : 0;
+        const int64_t plen = std::min<int64_t>(lq, (lq - trail) + overlap);
+        rr[0] = am; rr[1] = seq.substr((size_t)(lq - plen)); rr[2] = qrc.substr(0, (size_t)plen); rr[3] = bq.substr((size_t)(lq - plen));
+    }
+    for (int k = 0; k < 4; k++) out[k] = l[k] + ";" + rr[k];  // anno.d:100-106
+}
+
+static void tag_owned_record(Rec &r, uint8_t rs, const fadehip_aln *a, const Header &h) {
+    r.aux_update_uint("rs", rs);  // anno.d:63,94
+    if (!a) return;
+    std::string t[4];
+    artifact_strings(r, *a, h, t);
+    r.aux_update_str("am", t[0]);  // anno.d:100
+    r.aux_update_str("as", t[1]);  // anno.d:102
+    r.aux_update_str("ar", t[2]);  // anno.d:104
+    r.aux_update_str("ab", t[3]);  // anno.d:106
+}
+
+// anno.d:94-107 over a chunk: rs for every record (0 for the ones anno.d:61-65 settles without the device), the artifact
+// strings for the few that have them, keeping the reference's tag order rs, am, as, ar, ab
+static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
+    const size_t n = c.n_records();
     std::vector<uint8_t> rs(n, 0);
     for (size_t k = 0; k < c.sent.size(); k++) rs[c.sent[k]] = c.rs_sent[k];
     std::vector<int> art_of(n, -1);
     for (size_t k = 0; k < c.art.size(); k++) art_of[c.sent[(size_t)c.art[k].read_idx]] = (int)k;
     const size_t nt = (size_t)pool.size();
+    if (!c.is_block) {
+        pool.parallel_for(nt, [&](size_t t) {
+            for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++)
+                tag_owned_record(c.recs[i], rs[i], art_of[i] >= 0 ? &c.art[(size_t)art_of[i]] : nullptr, h);
+        });
+        return;
+    }
+    // Records framed in place: the new tags become a suffix behind the record's bytes (htslib appends an absent tag).
+    // A record that already carries one of the five tags (annotating an annotated file) is rebuilt as a whole instead,
+    // with htslib's update-in-place semantics.
+    Writer::BlockOut &o = c.bout;
+    o.sfx_off.assign(n + 1, 0);
+    o.owned.clear();
+    std::vector<std::string> art_str(c.art.size() * 4);
+    std::vector<std::vector<std::pair<uint32_t, Rec>>> owned_t(nt);
     pool.parallel_for(nt, [&](size_t t) {
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
-            Rec &r = c.recs[i];
-            r.aux_update_uint("rs", rs[i]);  // anno.d:63,94
-            const int k = art_of[i];
-            if (k < 0) continue;
-            const fadehip_aln &a = c.art[(size_t)k];
-            const int lq = r.l_seq();
-            std::string seq((size_t)lq, 'N'), qrc((size_t)lq, 'N'), bq((size_t)lq, '!');
-            const uint8_t *sq = r.seq(), *ql = r.qual();
-            for (int j = 0; j < lq; j++) {
-                const int code = (sq[j >> 1] >> ((~j & 1) << 2)) & 15;
-                seq[(size_t)j] = NT16_STR[code];
-                qrc[(size_t)(lq - 1 - j)] = NT16_STR[comp[code]];  // util.d:23-34
-                bq[(size_t)j] = (char)(ql[j] + 33);
+            const RecView v = c.blk.view(i);
+            bool has_ours = false;
+            for (size_t p = v.aux_off(); p + 3 <= v.nbytes();) {
+                const size_t fs = v.aux_field_size(p + 2);
+                if (!fs) break;
+                const uint8_t a0 = v.bytes()[p], a1 = v.bytes()[p + 1];
+                has_ours |= (a0 == 'r' && a1 == 's') || (a0 == 'a' && (a1 == 'm' || a1 == 's' || a1 == 'r' || a1 == 'b'));
+                p += 2 + fs;
             }
-            const int nops = std::min(a.sw.n_ops, FADEHIP_MAX_OPS);
-            const std::string cig = cigar_string(a.sw.ops, nops);
-            const int64_t apos = a.win_start + a.sw.beg_ref;
-            const int64_t pos = r.pos();
-            std::string am = (r.tid() >= 0 && r.tid() < (int)h.names.size() ? h.names[(size_t)r.tid()] : std::string("*"));
-            am += ',';
-            append_int(am, apos);
-            am += ',';
-            am += cig;
-            std::string l[4], rr[4];
-            if (a.art & 1) {  // analysis.d:84-92
-                const int64_t clip = a.clip_left;
-                const int64_t overlap = apos >= pos - clip ? apos - (pos - clip) : 0;
-                const int64_t lead = (a.sw.ops[0] & 15) == 4 ? (a.sw.ops[0] >> 4) : 0;
-                const int64_t plen = std::min<int64_t>(lq, (lq - lead) + overlap);
-                l[0] = am; l[1] = seq.substr(0, (size_t)plen); l[2] = qrc.substr((size_t)(lq - plen)); l[3] = bq.substr(0, (size_t)plen);
+            const fadehip_aln *a = art_of[i] >= 0 ? &c.art[(size_t)art_of[i]] : nullptr;
+            if (has_ours) {
+                Rec r;
+                r.d.assign(v.bytes(), v.bytes() + v.nbytes());
+                tag_owned_record(r, rs[i], a, h);
+                owned_t[t].emplace_back((uint32_t)i, std::move(r));
+                continue;
             }
-            if (a.art & 2) {  // analysis.d:108-118
-                const int64_t clip = a.clip_right;
-                int64_t res_al = 0;
-                for (int q = 0; q < nops; q++) {
-                    const uint32_t op = a.sw.ops[q] & 15;
-                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) res_al += a.sw.ops[q] >> 4;
+            size_t len = 4;  // "rs" 'C' value
+            if (a) {
+                std::string *st = &art_str[(size_t)art_of[i] * 4];
+                artifact_strings(v, *a, h, st);
+                for (int k = 0; k < 4; k++) len += 3 + st[k].size() + 1;
+            }
+            o.sfx_off[i + 1] = (uint32_t)len;
+        }
+    });
+    for (auto &v : owned_t)
+        for (auto &e : v) o.owned.push_back(std::move(e));
+    for (size_t i = 0; i < n; i++) o.sfx_off[i + 1] += o.sfx_off[i];
+    o.sfx.resize(o.sfx_off[n]);
+    pool.parallel_for(nt, [&](size_t t) {
+        static const char names[4][2] = {{'a', 'm'}, {'a', 's'}, {'a', 'r'}, {'a', 'b'}};
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+            if (o.sfx_off[i + 1] == o.sfx_off[i]) continue;
+            uint8_t *d = o.sfx.data() + o.sfx_off[i];
+            d[0] = 'r'; d[1] = 's'; d[2] = 'C'; d[3] = rs[i];  // bam_aux_update_int of a ubyte: the smallest type
+            d += 4;
+            if (art_of[i] >= 0) {
+                const std::string *st = &art_str[(size_t)art_of[i] * 4];
+                for (int k = 0; k < 4; k++) {
+                    d[0] = (uint8_t)names[k][0]; d[1] = (uint8_t)names[k][1]; d[2] = 'Z';
+                    memcpy(d + 3, st[k].c_str(), st[k].size() + 1);
+                    d += 3 + st[k].size() + 1;
                 }
-                const int64_t lhs = pos + a.aligned_len + clip, rhs = apos + res_al;
-                const int64_t overlap = lhs >= rhs ? lhs - rhs : 0;
-                const int64_t trail = (a.sw.ops[nops - 1] & 15) == 4 ? (a.sw.ops[nops - 1] >> 4) : 0;
-                const int64_t plen = std::min<int64_t>(lq, (lq - trail) + overlap);
-                rr[0] = am; rr[1] = seq.substr((size_t)(lq - plen)); rr[2] = qrc.substr(0, (size_t)plen); rr[3] = bq.substr((size_t)(lq - plen));
             }
-            r.aux_update_str("am", l[0] + ";" + rr[0]);  // anno.d:100
-            r.aux_update_str("as", l[1] + ";" + rr[1]);  // anno.d:102
-            r.aux_update_str("ar", l[2] + ";" + rr[2]);  // anno.d:104
-            r.aux_update_str("ab", l[3] + ";" + rr[3]);  // anno.d:106
         }
     });
 }
@@ -421,7 +498,9 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 while (!abort_stages) {
                     std::unique_ptr<Chunk> c(new Chunk());
                     ck_read.start();
-                    const size_t got = reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
+                    c->is_block = reader.is_bam();
+                    const size_t got = c->is_block ? reader.read_block(c->blk, (size_t)std::max(o.batch, 1))
+                                                   : reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
                     ck_read.stop();
                     if (got == 0) break;
                     q_in.push(std::move(c));
@@ -511,7 +590,8 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                     apply_tags(*c, hdr, wpool0);
                     ck_tags.stop();
                     ck_write.start();
-                    writer.write(c->recs);
+                    if (c->is_block) writer.write_block(c->blk, c->bout);
+                    else writer.write(c->recs);
                     ck_write.stop();
                 }
             } catch (const std::exception &e) {

@@ -181,71 +181,77 @@ inline int aux_type_size(uint8_t t) {
     }
 }
 
-struct Rec {
-    std::vector<uint8_t> d;
-
-    template <class T> T rd(size_t off) const { T v; memcpy(&v, d.data() + off, sizeof(T)); return v; }
-    template <class T> void wr(size_t off, T v) { memcpy(d.data() + off, &v, sizeof(T)); }
+// The read-only view of one BAM record (the bytes after block_size), shared by the owning Rec and the in-place RecView:
+// D provides data() / size().
+template <class D>
+struct RecApi {
+    const uint8_t *bytes() const { return static_cast<const D *>(this)->data(); }
+    size_t nbytes() const { return static_cast<const D *>(this)->size(); }
+    template <class T> T rd(size_t off) const { T v; memcpy(&v, bytes() + off, sizeof(T)); return v; }
     int32_t tid() const { return rd<int32_t>(0); }
     int32_t pos() const { return rd<int32_t>(4); }
-    int l_qname() const { return d[8]; }
-    int mapq() const { return d[9]; }
+    int l_qname() const { return bytes()[8]; }
+    int mapq() const { return bytes()[9]; }
     int n_cigar() const { return rd<uint16_t>(12); }
     int flag() const { return rd<uint16_t>(14); }
     int32_t l_seq() const { return rd<int32_t>(16); }
     int32_t mtid() const { return rd<int32_t>(20); }
     int32_t mpos() const { return rd<int32_t>(24); }
     int32_t tlen() const { return rd<int32_t>(28); }
-    const char *qname() const { return (const char *)d.data() + 32; }
+    const char *qname() const { return (const char *)bytes() + 32; }
     size_t cigar_off() const { return 32 + (size_t)l_qname(); }
-    const uint8_t *cigar_bytes() const { return d.data() + cigar_off(); }
+    const uint8_t *cigar_bytes() const { return bytes() + cigar_off(); }
     uint32_t cigar_op(int k) const { return rd<uint32_t>(cigar_off() + 4 * (size_t)k); }
     size_t seq_off() const { return cigar_off() + 4 * (size_t)n_cigar(); }
-    const uint8_t *seq() const { return d.data() + seq_off(); }
+    const uint8_t *seq() const { return bytes() + seq_off(); }
     size_t qual_off() const { return seq_off() + ((size_t)l_seq() + 1) / 2; }
-    const uint8_t *qual() const { return d.data() + qual_off(); }
+    const uint8_t *qual() const { return bytes() + qual_off(); }
     size_t aux_off() const { return qual_off() + (size_t)l_seq(); }
     // The fixed fields must describe a layout that fits the record, and the aux area must be a sequence of whole fields
     // that ends exactly at the end of the record: every accessor, the tag updates and the SAM formatter index with these
     // lengths, so a truncated or crafted record is rejected here, once, when it is read.
     bool layout_ok() const {
-        if (!(d.size() >= 32 && l_seq() >= 0 && l_qname() >= 1 && aux_off() <= d.size())) return false;
+        const size_t n = nbytes();
+        if (!(n >= 32 && l_seq() >= 0 && l_qname() >= 1 && aux_off() <= n)) return false;
         size_t p = aux_off();
-        while (p < d.size()) {
-            if (p + 3 > d.size()) return false;
+        while (p < n) {
+            if (p + 3 > n) return false;
             const size_t fs = aux_field_size(p + 2);
             if (!fs) return false;
             p += 2 + fs;
         }
-        return p == d.size();
+        return p == n;
     }
-
     // size in bytes of the aux field whose type byte is at p (type byte included), 0 if the field is malformed or does
     // not fit inside the record
     size_t aux_field_size(size_t p) const {
-        if (p >= d.size()) return 0;
+        const size_t n = nbytes();
+        const uint8_t *d = bytes();
+        if (p >= n) return 0;
         const uint8_t t = d[p];
         const int s = aux_type_size(t);
-        if (s) return p + 1 + (size_t)s <= d.size() ? 1 + (size_t)s : 0;
+        if (s) return p + 1 + (size_t)s <= n ? 1 + (size_t)s : 0;
         if (t == 'Z' || t == 'H') {
             size_t q = p + 1;
-            while (q < d.size() && d[q]) q++;
-            return q < d.size() ? q - p + 1 : 0;
+            while (q < n && d[q]) q++;
+            return q < n ? q - p + 1 : 0;
         }
         if (t == 'B') {
-            if (p + 6 > d.size()) return 0;
+            if (p + 6 > n) return 0;
             const int es = aux_type_size(d[p + 1]);
-            const uint64_t n = rd<uint32_t>(p + 2);
+            const uint64_t cnt = rd<uint32_t>(p + 2);
             if (!es) return 0;
-            const uint64_t fs = 6 + (uint64_t)es * n;  // 64-bit: a 32-bit count times 8 overflows size_t nowhere, uint32 everywhere
-            return fs <= (uint64_t)(d.size() - p) ? (size_t)fs : 0;
+            const uint64_t fs = 6 + (uint64_t)es * cnt;  // 64-bit: a 32-bit count times 8 overflows size_t nowhere, uint32 everywhere
+            return fs <= (uint64_t)(n - p) ? (size_t)fs : 0;
         }
         return 0;
     }
     // offset of the tag's 2-byte name, or npos
     size_t aux_find(const char tag[2]) const {
+        const size_t n = nbytes();
+        const uint8_t *d = bytes();
         size_t p = aux_off();
-        while (p + 3 <= d.size()) {
+        while (p + 3 <= n) {
             size_t fs = aux_field_size(p + 2);
             if (!fs) break;
             if (d[p] == (uint8_t)tag[0] && d[p + 1] == (uint8_t)tag[1]) return p;
@@ -254,6 +260,23 @@ struct Rec {
         return std::string::npos;
     }
     bool aux_exists(const char tag[2]) const { return aux_find(tag) != std::string::npos; }
+};
+
+// a record framed in place in a block of inflated BAM bytes (RecordBlock): no copy, no allocation
+struct RecView : RecApi<RecView> {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    RecView() = default;
+    RecView(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+};
+
+struct Rec : RecApi<Rec> {
+    std::vector<uint8_t> d;
+    const uint8_t *data() const { return d.data(); }
+    size_t size() const { return d.size(); }
+    template <class T> void wr(size_t off, T v) { memcpy(d.data() + off, &v, sizeof(T)); }
     void aux_append(const char tag[2], uint8_t type, const void *data, size_t len) {
         size_t o = d.size();
         d.resize(o + 3 + len);
@@ -307,7 +330,8 @@ private:
     }
 };
 
-inline int64_t cigar_ref_len(const Rec &r) {
+template <class R>
+inline int64_t cigar_ref_len(const R &r) {
     int64_t n = 0;
     for (int k = 0; k < r.n_cigar(); k++) {
         uint32_t c = r.cigar_op(k), op = c & 15;
@@ -476,7 +500,8 @@ inline void sam_parse(const char *line, size_t len, const Header &h, Rec &r) {
     }
 }
 
-inline void sam_format(const Rec &r, const Header &h, std::string &s) {
+template <class R>
+inline void sam_format(const R &r, const Header &h, std::string &s) {
     s.append(r.qname());
     s += '\t';
     append_int(s, r.flag());
@@ -516,15 +541,15 @@ inline void sam_format(const Rec &r, const Header &h, std::string &s) {
     else for (int k = 0; k < lseq; k++) s += (char)(ql[k] + 33);
     size_t p = r.aux_off();
     char buf[64];
-    while (p + 3 <= r.d.size()) {
+    while (p + 3 <= r.nbytes()) {
         const size_t fs = r.aux_field_size(p + 2);
         if (!fs) break;
         s += '\t';
-        s += (char)r.d[p];
-        s += (char)r.d[p + 1];
+        s += (char)r.bytes()[p];
+        s += (char)r.bytes()[p + 1];
         s += ':';
-        const uint8_t t = r.d[p + 2];
-        const uint8_t *v = r.d.data() + p + 3;
+        const uint8_t t = r.bytes()[p + 2];
+        const uint8_t *v = r.bytes() + p + 3;
         switch (t) {
             case 'A': s += "A:"; s += (char)v[0]; break;
             case 'c': s += "i:"; append_int(s, (int8_t)v[0]); break;
@@ -742,6 +767,18 @@ public:
             out_.drop_front(pos_);
             pos_ = 0;
         }
+        return inflate_append(out_);
+    }
+    // hands the bytes inflated but not yet read over to `dst` (appended)
+    void take_rest(RawBuf &dst) {
+        const size_t k = out_.size() - pos_, o = dst.size();
+        dst.resize(o + k);
+        if (k) memcpy(dst.data() + o, out_.data() + pos_, k);
+        out_.clear();
+        pos_ = 0;
+    }
+    // inflate the next batch of blocks onto the end of `out_` (the reader's own buffer or a RecordBlock's)
+    bool inflate_append(RawBuf &out_) {
         comp_.clear();
         offs_.clear();
         const size_t kBatch = 512;
@@ -815,6 +852,15 @@ private:
     std::atomic<bool> bad_{false};
 };
 
+// A batch of BAM records framed in place in the inflated bytes they arrived in: no per-record copy or allocation.
+struct RecordBlock {
+    RawBuf buf;
+    std::vector<uint32_t> off, len;  // record i = buf[off[i], off[i] + len[i])  (the bytes after its block_size)
+    size_t size() const { return off.size(); }
+    RecView view(size_t i) const { return RecView(buf.data() + off[i], len[i]); }
+    uint8_t *mut(size_t i) { return buf.data() + off[i]; }
+};
+
 // ------------------------------------------------------------------ reader (SAM text or BAM)
 class Reader {
 public:
@@ -837,8 +883,55 @@ public:
     }
     const Header &header() const { return hdr_; }
     bool is_bam() const { return bam_; }
+    // BAM only: the next up-to-max_n records, framed in place in blk.buf; returns their number (0 at end of file)
+    size_t read_block(RecordBlock &blk, size_t max_n) {
+        if (!bam_) throw std::runtime_error("read_block needs BAM input");
+        blk.buf.clear();
+        blk.off.clear();
+        blk.len.clear();
+        if (!block_mode_) {  // bytes inflated while the header was read
+            bgzf_->take_rest(carry_);
+            block_mode_ = true;
+        }
+        blk.buf.resize(carry_.size());
+        if (carry_.size()) memcpy(blk.buf.data(), carry_.data(), carry_.size());
+        carry_.clear();
+        size_t pos = 0;
+        for (;;) {
+            const uint8_t *b = blk.buf.data();
+            const size_t av = blk.buf.size();
+            while (blk.off.size() < max_n && pos + 4 <= av) {
+                uint32_t bs;
+                memcpy(&bs, b + pos, 4);
+                if (bs < 32) throw std::runtime_error("corrupt BAM record");
+                if (pos + 4 + (size_t)bs > av) break;
+                if (pos + 4 > 0xffffffffull) throw std::runtime_error("record block beyond 4 GiB: lower --batch");
+                blk.off.push_back((uint32_t)(pos + 4));
+                blk.len.push_back(bs);
+                pos += 4 + (size_t)bs;
+            }
+            if (blk.off.size() == max_n) break;
+            if (!bgzf_->inflate_append(blk.buf)) {
+                if (pos < blk.buf.size()) throw std::runtime_error("truncated BAM record");
+                break;
+            }
+        }
+        // what follows the last framed record belongs to the next block
+        const size_t rest = blk.buf.size() - pos;
+        carry_.resize(rest);
+        if (rest) memcpy(carry_.data(), blk.buf.data() + pos, rest);
+        blk.buf.resize(pos);
+        const size_t cnt = blk.off.size(), nt = (size_t)pool_->size() * 4;
+        pool_->parallel_for(nt, [&](size_t t) {
+            for (size_t i = cnt * t / nt; i < cnt * (t + 1) / nt; i++)
+                if (!blk.view(i).layout_ok()) bad_layout_ = true;
+        });
+        if (bad_layout_) throw std::runtime_error("corrupt BAM record (field lengths exceed the record)");
+        return cnt;
+    }
     // reads up to max_n records into out (appending); returns number read
     size_t read_chunk(std::vector<Rec> &out, size_t max_n) {
+        if (block_mode_) throw std::runtime_error("read_chunk after read_block");
         size_t n = 0;
         if (bam_) {
             // frame the records in the inflated buffer (serial, 4 bytes per record), copy them out in parallel
@@ -972,6 +1065,8 @@ private:
     bool bam_ = false;
     Header hdr_;
     std::atomic<bool> bad_layout_{false};
+    RawBuf carry_;          // read_block: inflated bytes behind the last framed record
+    bool block_mode_ = false;
     std::string text_;      // SAM text not yet handed out (complete lines from text_pos_ on)
     size_t text_pos_ = 0;
     bool text_eof_ = false;
@@ -1028,6 +1123,62 @@ public:
                 const uint32_t bs = (uint32_t)recs[i].d.size();
                 memcpy(raw_.data() + off[i], &bs, 4);
                 memcpy(raw_.data() + off[i] + 4, recs[i].d.data(), bs);
+            }
+        });
+        flush_blocks(false);
+    }
+    // What a stage adds to a RecordBlock's records: appended aux bytes per record (sfx_off[i] .. sfx_off[i + 1] of sfx),
+    // and whole replacement records for the few that had to be rebuilt (`owned`, any order).
+    struct BlockOut {
+        std::vector<uint32_t> sfx_off;
+        std::vector<uint8_t> sfx;
+        std::vector<std::pair<uint32_t, Rec>> owned;
+    };
+    void write_block(const RecordBlock &blk, const BlockOut &o) {
+        const size_t n = blk.size();
+        std::vector<int32_t> own(o.owned.empty() ? 0 : n, -1);
+        for (size_t k = 0; k < o.owned.size(); k++) own[o.owned[k].first] = (int32_t)k;
+        auto sfx_len = [&](size_t i) { return o.sfx_off.empty() ? 0u : o.sfx_off[i + 1] - o.sfx_off[i]; };
+        auto sfx_ptr = [&](size_t i) { return o.sfx.data() + (o.sfx_off.empty() ? 0u : o.sfx_off[i]); };
+        if (fmt_ == OutFmt::SAM) {
+            const size_t nt = (size_t)pool_->size();
+            std::vector<std::string> parts(nt);
+            pool_->parallel_for(nt, [&](size_t t) {
+                const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+                std::string &s = parts[t];
+                s.reserve((hi - lo) * 400);
+                std::vector<uint8_t> tmp;
+                for (size_t i = lo; i < hi; i++) {
+                    if (!own.empty() && own[i] >= 0) sam_format(o.owned[(size_t)own[i]].second, hdr_, s);
+                    else if (sfx_len(i) == 0) sam_format(blk.view(i), hdr_, s);
+                    else {
+                        tmp.resize((size_t)blk.len[i] + sfx_len(i));
+                        memcpy(tmp.data(), blk.buf.data() + blk.off[i], blk.len[i]);
+                        memcpy(tmp.data() + blk.len[i], sfx_ptr(i), sfx_len(i));
+                        sam_format(RecView(tmp.data(), tmp.size()), hdr_, s);
+                    }
+                }
+            });
+            for (auto &s : parts) fwrite(s.data(), 1, s.size(), f_);
+            return;
+        }
+        std::vector<size_t> off(n + 1);
+        off[0] = raw_.size();
+        for (size_t i = 0; i < n; i++)
+            off[i + 1] = off[i] + 4 + ((!own.empty() && own[i] >= 0) ? o.owned[(size_t)own[i]].second.d.size() : (size_t)blk.len[i] + sfx_len(i));
+        raw_.resize(off[n]);
+        const size_t nt = (size_t)pool_->size() * 4;
+        pool_->parallel_for(nt, [&](size_t t) {
+            for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+                uint8_t *dst = raw_.data() + off[i];
+                const uint32_t bs = (uint32_t)(off[i + 1] - off[i] - 4);
+                memcpy(dst, &bs, 4);
+                if (!own.empty() && own[i] >= 0) {
+                    memcpy(dst + 4, o.owned[(size_t)own[i]].second.d.data(), bs);
+                } else {
+                    memcpy(dst + 4, blk.buf.data() + blk.off[i], blk.len[i]);
+                    if (sfx_len(i)) memcpy(dst + 4 + blk.len[i], sfx_ptr(i), sfx_len(i));
+                }
             }
         });
         flush_blocks(false);

@@ -148,3 +148,34 @@ def test_cli_chain_annotate_extract_out(tmp_path, tag):
     cmd = "%s annotate -b --min-length %d -w %d %s %s | %s extract -" % (FADE, floor_len, window, sam, fa, FADE)
     pipe = subprocess.run(cmd, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert pipe.returncode == 0 and strip(pipe.stdout.decode()) == got, pipe.stderr.decode()
+
+
+@pytest.mark.parametrize("tag", ["anno_c1", "anno_c2", "anno_c5", "anno_floor0"])
+def test_cli_bam_input_in_place_records(tmp_path, tag):
+    """BAM input takes the in-place path: records are framed in the inflated bytes (no per-record copy), new tags go
+    out as a suffix behind the record.  Same records as from SAM input, to SAM and to BAM; a second pass over the
+    annotated BAM (tags present: records rebuilt with htslib's update-in-place semantics) changes nothing."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s", "sam2bam"])
+    exp, floor_len, window = _expected(tag)
+    sam, fa = os.path.join(GOLD, tag + ".sam"), os.path.join(GOLD, tag + ".fa")
+    bam = tmp_path / "in.bam"
+    with open(bam, "wb") as fo:
+        subprocess.check_call([os.path.join(ROOT, "tools", "sam2bam"), sam], stdout=fo)
+    base = ["annotate", "--min-length", str(floor_len), "-w", str(window), "--batch", "97"]  # several blocks, records straddling them
+    from_sam = _run(base + [sam, fa])
+    from_bam = _run(base + [str(bam), fa])
+    assert from_sam.returncode == 0 and from_bam.returncode == 0, from_bam.stderr.decode()
+    strip = lambda out: [l for l in out.decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
+    assert strip(from_bam.stdout) == strip(from_sam.stdout)
+    _check_records(samutil.parse_sam(from_bam.stdout.decode())[1], exp)
+    to_bam = _run(base + ["-b", str(bam), fa])
+    assert to_bam.returncode == 0, to_bam.stderr.decode()
+    _, _, rb = samutil.bam_to_sam_records(to_bam.stdout)
+    _check_records(rb, exp)
+    assert all(r["tags"]["rs.bamtype"] == "C" for r in rb)
+    again = tmp_path / "anno.bam"
+    again.write_bytes(to_bam.stdout)
+    second = _run(base + ["-b", str(again), fa])
+    assert second.returncode == 0, second.stderr.decode()
+    _, _, rb2 = samutil.bam_to_sam_records(second.stdout)
+    assert rb2 == rb
