@@ -85,9 +85,12 @@ int annotateHip(string cl, string[] args, ubyte con, int artifact_floor_length, 
         seqOff[$ - 1] = cast(uint) seq.length;
         rs.length = chunk.length;
         aln.length = chunk.length;
+        // (ABI 2: the arrays may also live in ONE pinned block laid out by fadehip_batch_bind, with the records
+        // anno.d:61-65 settles left out and counted in n_skipped -- what fade_main.cpp's pack_chunk does; this sketch
+        // keeps the simple form: every record, arrays from anywhere)
         fadehip_read_batch b = {
             cast(int) chunk.length, tid.ptr, pos.ptr, flag.ptr, hasSa.ptr, lseq.ptr, cigarOff.ptr,
-            cigarOps.ptr, seqOff.ptr, seq.ptr
+            cigarOps.ptr, seqOff.ptr, seq.ptr, 0, 0
         };
         fadehip_anno_out o;
         o.rs = rs.ptr;

@@ -1,4 +1,4 @@
-/// extern(C) binding of include/fadehip.h (ABI version 1) for the D host of blachlylab/fade.
+/// extern(C) binding of include/fadehip.h (ABI version 2) for the D host of blachlylab/fade.
 ///
 /// NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no D compiler (ldc2, dmd, gdc, dub are
 /// all absent) and none of FADE's dependencies, so this file has never been compiled or run.  It mirrors
@@ -8,11 +8,11 @@ module fadehip;
 
 extern (C) nothrow @nogc:
 
-enum FADEHIP_ABI_VERSION = 1;
+enum FADEHIP_ABI_VERSION = 2;
 enum FADEHIP_MAX_OPS = 16;
 enum FADEHIP_MAX_QUERY = 512;
 enum FADEHIP_MAX_LONG_QUERY = 32768;
-enum FADEHIP_NUM_SLOTS = 2;
+enum FADEHIP_NUM_SLOTS = 4;
 
 enum : int
 {
@@ -36,11 +36,24 @@ struct fadehip_params
     int ext = 2;
     int match = 2;
     int mismatch = -3;
-    int max_ref_len = 8192;
+    int max_ref_len = 1 << 20;
     int max_batch_reads = 1 << 20;
     long trace_bytes = 0;
     int trace_all = 0;
-    int reserved = 0;
+    uint rules = FADEHIP_RULES_DEFAULT; /// FADEHIP_RULE_* : the assumptions about libparasail that could not be checked
+}
+
+/// same bits as oracle/fade_oracle.h FO_RULE_* (SURVEY.md Appendix A)
+enum : uint
+{
+    FADEHIP_RULE_END_MIN_REF_THEN_QUERY = 1u << 0,
+    FADEHIP_RULE_HDIR_DIAG_F_E = 1u << 1,
+    FADEHIP_RULE_GAP_TIE_EXTENDS = 1u << 2,
+    FADEHIP_RULE_EQ_BY_CHAR = 1u << 3,
+    FADEHIP_RULE_SAM_GAP_LETTERS = 1u << 4,
+    FADEHIP_RULE_PAD_SOFTCLIP = 1u << 5,
+    FADEHIP_RULE_N_MATCHES_N = 1u << 6,
+    FADEHIP_RULES_DEFAULT = 0x7f
 }
 
 /// what source/analysis.d:69-113 reads from a dparasail result
@@ -65,6 +78,8 @@ struct fadehip_read_batch
     const(uint)* cigar_ops;
     const(uint)* seq_off;
     const(ubyte)* seq_packed;
+    int n_skipped; /// records left out because anno.d:61-65 gives them rs = 0 (unmapped, no S op)
+    int ref_span_bound; /// max cigar.alignedLength over the batch, 0 = let the library scan the CIGARs
 }
 
 struct fadehip_aln
@@ -85,6 +100,19 @@ struct fadehip_anno_out
     int aln_cap;
     int n_aln;
     long[8] stats;
+    int n_oversize;
+    int reserved;
+}
+
+/// zero-copy results: views into the slot's pinned result block, valid until the slot is uploaded again
+struct fadehip_anno_view
+{
+    const(ubyte)* rs;
+    const(fadehip_aln)* aln;
+    int n_reads, n_aln;
+    long[8] stats;
+    int n_oversize;
+    int reserved;
 }
 
 void fadehip_params_default(fadehip_params* p);
@@ -94,6 +122,8 @@ void fadehip_destroy(fadehip_ctx* ctx);
 const(char)* fadehip_last_error(const(fadehip_ctx)* ctx);
 int fadehip_host_alloc(fadehip_ctx* ctx, size_t bytes, void** out_);
 int fadehip_host_free(fadehip_ctx* ctx, void* p);
+size_t fadehip_batch_bytes(int n_reads, long n_cigar_ops, long n_seq_bytes);
+int fadehip_batch_bind(void* base, int n_reads, long n_cigar_ops, long n_seq_bytes, fadehip_read_batch* b);
 int fadehip_sw_batch(fadehip_ctx* ctx, int n, const(ubyte)* q, const(long)* q_off,
         const(ubyte)* r, const(long)* r_off, fadehip_sw_result* out_);
 int fadehip_genome_upload(fadehip_ctx* ctx, int n_contigs, const(long)* lengths, const(ubyte*)* seqs);
@@ -101,7 +131,8 @@ int fadehip_annotate_upload(fadehip_ctx* ctx, int slot, const(fadehip_read_batch
 int fadehip_annotate_run(fadehip_ctx* ctx, int slot, int floor_len, int window);
 int fadehip_annotate_submit(fadehip_ctx* ctx, int slot, const(fadehip_read_batch)* batch,
         int floor_len, int window);
+int fadehip_annotate_results(fadehip_ctx* ctx, int slot, fadehip_anno_view* out_);
 int fadehip_annotate_collect(fadehip_ctx* ctx, int slot, fadehip_anno_out* out_);
 int fadehip_sync(fadehip_ctx* ctx);
-int fadehip_last_run_profile(fadehip_ctx* ctx, int slot, float* ms4, long* counts4);
+int fadehip_last_run_profile(fadehip_ctx* ctx, int slot, float* ms4, long* counts6);
 int fadehip_stats_allreduce(fadehip_ctx** ctxs, int n_ctx, long* counters, int count);

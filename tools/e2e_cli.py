@@ -74,11 +74,11 @@ def main():
     cpu = os.path.join(ROOT, "tools", "cpu_annotate")
     res = {}
 
-    def run(tag, exe, args, out, t):
+    def run(tag, exe, args, out, t, env=None):
         base = [exe, "annotate", "--timing", "-t", str(t), "-w", str(cfg["window"]), "--batch", "262144"]
         t1 = time.time()
         with open(out, "wb") as fo:
-            p = subprocess.run(base + args, stdout=fo, stderr=subprocess.PIPE)
+            p = subprocess.run(base + args, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
         dt = time.time() - t1
         assert p.returncode == 0, p.stderr.decode()
         res[tag] = dict(seconds=dt, reads_per_s=n / dt, out_bytes=os.path.getsize(out), threads=t,
@@ -87,6 +87,8 @@ def main():
 
     out_gpu, out_cpu = os.path.join(tmp, "e2e.gpu.bam"), os.path.join(tmp, "e2e.cpu.bam")
     run("gpu_bam_to_bam", fade, ["-b", bam, fa], out_gpu, threads)
+    run("gpu_bam_to_bam_effort1", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), threads, env={"FADE_BGZF_EFFORT": "1"})
+    run("gpu_bam_to_bam_32_threads", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), 32)
     run("gpu_bam_to_ubam", fade, ["-u", bam, fa], os.path.join(tmp, "e2e.out.ubam"), threads)
     run("gpu_sam_to_bam", fade, ["-b", sam, fa], os.path.join(tmp, "e2e.out2.bam"), threads)
     # the CPU comparator: the same reader / writer around the striped AVX2 restatement of annotateTask
