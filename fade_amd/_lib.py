@@ -15,6 +15,7 @@ MAX_OPS = 16
 NUM_SLOTS = 4
 ABI_VERSION = 2
 RULES_DEFAULT = 0x7f
+REF_CONSUMING_OPS = (0, 2, 3, 7, 8)  # include/fadehip.h FADEHIP_REF_CONSUMING_OPS (dhtslib Cigar.alignedLength: M, D, N, =, X)
 ROW_CLASSES = (4, 6, 8, 10, 12, 14, 16, 20, 24, 32)  # query rows per lane of the wave kernels (fadehip_kernels.hpp class_rows)
 
 

@@ -159,7 +159,7 @@ class Context:
         sub = synth.take(batch, idx)
         sub["n_skipped"] = int(len(keep) - len(idx))
         if ref_span_bound:
-            ref = np.isin(ops & 15, (0, 2, 3, 7, 8)) * (ops >> 4).astype(np.int64)
+            ref = np.isin(ops & 15, _lib.REF_CONSUMING_OPS) * (ops >> 4).astype(np.int64)
             cr = np.concatenate([[0], np.cumsum(ref)])
             al = cr[co[1:]] - cr[co[:-1]]
             sub["ref_span_bound"] = int(al[idx].max()) if len(idx) else 1
@@ -328,7 +328,7 @@ def format_tags(batch, contig_names, rs, aln):
             left = ["%s,%d,%s" % (name, apos, cigar_str(ops)), seq[:plen], q_seq[lq - plen:], bq[:plen]]
         if art & 2:  # analysis.d:108-118
             clip = int(a["clip_right"])
-            res_aligned = sum(o >> 4 for o in ops if (o & 15) in (0, 2, 3, 7, 8))
+            res_aligned = sum(o >> 4 for o in ops if (o & 15) in _lib.REF_CONSUMING_OPS)
             lhs = pos + int(a["aligned_len"]) + clip
             rhs = apos + res_aligned
             overlap = lhs - rhs if lhs >= rhs else 0

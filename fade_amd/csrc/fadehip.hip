@@ -621,7 +621,7 @@ inline CigarSummary summarize_cigar(const uint32_t *ops, uint32_t c0, uint32_t c
     for (uint32_t k = c0; k < c1; k++) {
         const uint32_t op = ops[k] & 15u, len = ops[k] >> 4;
         if (op == 4) r.n_soft++;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.aligned += len;
+        if (FADEHIP_OP_CONSUMES_REF(op)) r.aligned += len;
         if (op == 5) continue;
         const bool is_sc = (op == 4);
         if (first && !is_sc) first = false;

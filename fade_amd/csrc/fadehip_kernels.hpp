@@ -188,7 +188,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         for (uint32_t k = c0; k < c1; k++) {
             const uint32_t op = a.cigar_ops[k] & 15u, len = a.cigar_ops[k] >> 4;
             if (op == 4) n_soft++;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) aligned += len;
+            if (FADEHIP_OP_CONSUMES_REF(op)) aligned += len;
             if (op == 5) continue;  // util.d:44-45 skips hard clips
             const bool is_sc = (op == 4);
             if (first && !is_sc) first = false;

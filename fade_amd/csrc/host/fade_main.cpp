@@ -336,7 +336,7 @@ static void artifact_strings(const R &r, const fadehip_aln &a, const Header &h, 
         int64_t res_al = 0;
         for (int q = 0; q < nops; q++) {
             const uint32_t op = a.sw.ops[q] & 15;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) res_al += a.sw.ops[q] >> 4;
+            if (FADEHIP_OP_CONSUMES_REF(op)) res_al += a.sw.ops[q] >> 4;
         }
         const int64_t lhs = pos + a.aligned_len + clip, rhs = apos + res_al;
         const int64_t overlap = lhs >= rhs ? lhs - rhs : 0;

@@ -39,6 +39,12 @@ extern "C" {
 #define FADEHIP_MAX_QUERY 512 /* longest query of the wave kernels (8 alignments per wavefront) */
 #define FADEHIP_MAX_LONG_QUERY 32768 /* longer queries, up to this, take a thread-per-alignment kernel (slow path) */
 #define FADEHIP_NUM_SLOTS 4   /* batches in flight per ctx (each slot has its own stream, device buffers and pinned result block) */
+/* The CIGAR ops dhtslib's Cigar.alignedLength sums (analysis.d:53,111-113; filter.d:27,61): M, D, N, =, X — bit k set for
+ * BAM op code k.  One definition for the gate kernel, the host-side bounds and the tag formatters (the oracle restates it
+ * as fo_cigar_aligned_length).  [The dhtslib commit FADE pins is not available here; if its alignedLength also counted I,
+ * this constant is the only place to change.] */
+#define FADEHIP_REF_CONSUMING_OPS 0x18Du
+#define FADEHIP_OP_CONSUMES_REF(op) ((FADEHIP_REF_CONSUMING_OPS >> ((op) & 15u)) & 1u)
 
 enum {
     FADEHIP_OK = 0,

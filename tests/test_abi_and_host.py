@@ -170,3 +170,13 @@ def test_corrupt_bam_and_bgzf_inputs_are_rejected_under_sanitizers():
     p = subprocess.run([os.path.join(csrc, "build", "hts_selftest")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
     assert b"all corrupt-input cases rejected cleanly" in p.stdout
+
+
+def test_ref_consuming_op_set_has_one_definition():
+    """dhtslib's Cigar.alignedLength (M, D, N, =, X) is one constant in include/fadehip.h, mirrored once in _lib.py."""
+    from fade_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fadehip.h")).read()
+    mask = int(re.search(r"#define FADEHIP_REF_CONSUMING_OPS (0x[0-9A-Fa-f]+)u", hdr).group(1), 16)
+    assert tuple(k for k in range(16) if (mask >> k) & 1) == _lib.REF_CONSUMING_OPS == (0, 2, 3, 7, 8)
+    for path in ("fade_amd/csrc/fadehip_kernels.hpp", "fade_amd/csrc/fadehip.hip"):
+        assert "op == 0 || op == 2 || op == 3" not in open(os.path.join(ROOT, path)).read(), path
