@@ -86,6 +86,11 @@ def main():
         print(tag, res[tag], flush=True)
 
     out_gpu, out_cpu = os.path.join(tmp, "e2e.gpu.bam"), os.path.join(tmp, "e2e.cpu.bam")
+    for t in [int(x) for x in os.environ.get("E2E_SWEEP", "").split(",") if x]:  # -t sweep of the BAM -> BAM leg only
+        run("gpu_bam_to_bam_t%d" % t, fade, ["-b", bam, fa], out_gpu, t)
+    if os.environ.get("E2E_SWEEP"):
+        json.dump(res, open(os.path.join(ROOT, "gpurun_out", "e2e_sweep.json"), "w"), indent=1)
+        return
     run("gpu_bam_to_bam", fade, ["-b", bam, fa], out_gpu, threads)
     run("gpu_bam_to_bam_effort1", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), threads, env={"FADE_BGZF_EFFORT": "1"})
     run("gpu_bam_to_bam_32_threads", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), 32)
