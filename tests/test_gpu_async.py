@@ -168,3 +168,20 @@ def test_two_contexts_on_one_device_interleaved(oracle):
     finally:
         for c in [one] + cs:
             c.close()
+
+
+def test_slot_reuse_without_fetching_results(ctx):
+    """A batch whose results are never fetched does not wedge its slot: the next upload waits for the slot's stream."""
+    cfg, g, b = synth.make_config("C2", 12_000, contig_len=200_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    first, second = synth.take(b, np.arange(0, 6000)), synth.take(b, np.arange(6000, 12_000))
+    want = ctx.annotate(second, cfg["floor_len"], cfg["window"], slot=1)
+    ctx.annotate_upload(0, first)
+    ctx.annotate_run(0, cfg["floor_len"], cfg["window"])
+    ctx.annotate_upload(0, second)  # the first batch's results are dropped
+    ctx.annotate_run(0, cfg["floor_len"], cfg["window"])
+    ctx.annotate_run(0, cfg["floor_len"], cfg["window"])  # ... and a run may be repeated on the uploaded batch
+    got = ctx.annotate_collect(0)
+    assert np.array_equal(got[0], want[0]) and list(got[2]) == list(want[2]) and _key(got[1]) == _key(want[1])
+    out = ctx.sw_batch([b"ACGTACGTAC"], [b"TTACGTACGTACTT"])  # level 1 borrows slot 0
+    assert int(out[0]["score"]) == 20

@@ -40,3 +40,17 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
     assert p.returncode == 2 and b"WORLD_SIZE" in p.stderr
+
+
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: the ranks come from torchrun, bench.py
+    must not spawn again.  Two ranks on the one GPU (gloo for the collective)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch-reads", "20000", "--no-cpu"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, FADE_BENCH_BACKEND="gloo"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["stats"]["read_count"] == 2 * 20000 * 10 and r["scaling"] == "weak"
