@@ -3,22 +3,23 @@
 // Replaces, on the device:
 //   source/anno.d:61-74        gate, parse_clips (util.d:37-62), SA -> rs base bits      gate_kernel
 //   source/analysis.d:34-64    floor, reverse complement (util.d:23-34), window, fetch   gate_kernel + loaders
-//   source/analysis.d:67       p.sw_striped(q_seq, ref_seq)  (libparasail, un-vendored)  sw_forward_kernel + traceback_kernel
-//   source/analysis.d:69-83,98-107  artifact gates, ReadStatus bits (readstatus.d:5-26) traceback_kernel
+//   source/analysis.d:67       p.sw_striped(q_seq, ref_seq)  (libparasail, un-vendored)  sw_pk_kernel<R,1|2|3> + traceback_path
+//   source/analysis.d:69-83,98-107  artifact gates, ReadStatus bits (readstatus.d:5-26) select_one, traceback_path
 //
-// Execution model: integer DP, no MFMA.  A 16-lane DPP row owns one alignment (int32 kernel,
-// 4 per wave) or two packed as int16 halves (packed kernel, 8 per wave); a lane owns R consecutive query rows
-// (16*R >= Lq) and the 16 lanes sweep the reference window as an anti-diagonal wave.  Neighbour exchange is
-// DPP row_shr:1, whose zero fill at each 16-lane row boundary IS the DP boundary condition.  The reference
-// window is staged once into LDS as pre-shifted class codes; the 4-bit/cell trace leaves the wave as fully
-// coalesced 256-byte stores.
+// Execution model: integer DP, no MFMA.  A 16-lane DPP row owns two alignments packed as int16 halves
+// (8 per wave; the int32 A/B kernel: one per row, 4 per wave); a lane owns R consecutive query rows (16*R >= Lq) and the
+// 16 lanes sweep the reference window as an anti-diagonal wave.  Neighbour exchange is DPP row_shr:1, whose zero fill at
+// each 16-lane row boundary IS the DP boundary condition.  The reference window is staged once into LDS as class-pair
+// table offsets; the 4-bit/cell trace of the traced pass leaves the wave as fully coalesced 256-byte stores.
 //
-// Default pipeline (two-pass):
-//   gate_kernel -> sw_pk_kernel<R,1> (score + end cell + wave snapshots; each wave then selects: who needs a CIGAR,
-//   from which step) -> sw_pk_kernel<R,2> (traced re-computation of those steps) -> traceback_kernel (CIGAR,
-//   FADE's gates, rs bits).  The stats.d:45-54 counters are summed on the way: gate_kernel counts reads, clipped
-//   and supplementary ones, traceback_kernel the artifact calls.  sw_pk_kernel<R,0> and sw_forward_kernel<R> are the single-pass
-//   packed / int32 variants kept for A/B measurements (FADEHIP_KERNEL=pk|int32).
+// Default pipeline (two-pass): three launches per batch and row class, nothing read back in between —
+//   gate_kernel -> sw_pk_kernel<R,1>: score + end cell + wave snapshots; the wave then finishes each of its alignments
+//   that needs no traceback (select_one: non-candidates, forced gap-free diagonals) and buckets the rest
+//   -> sw_pk_kernel<R,2> (<R,3> with non-default A.4 rules), ONE persistent launch: traced re-computation of the
+//   candidates' last steps, their tracebacks (traceback_path: CIGAR, FADE's gates, rs bits), re-tracing of the paths that
+//   left their steps.  The stats.d:45-54 counters are summed on the way.  sw_pk_kernel<R,0> + traceback_kernel and
+//   sw_forward_kernel<R> are the single-pass packed / int32 variants kept for A/B measurements (FADEHIP_KERNEL=pk|int32);
+//   sw_long_kernel + traceback_kernel serve queries beyond 512 bases and windows beyond 8000.
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>

@@ -779,8 +779,8 @@ public:
         out_.clear();
         pos_ = 0;
     }
-    // inflate the next batch of blocks onto the end of `out_` (the reader's own buffer or a RecordBlock's)
-    bool inflate_append(RawBuf &out_) {
+    // inflate the next batch of blocks onto the end of `dst` (the reader's own buffer or a RecordBlock's)
+    bool inflate_append(RawBuf &dst) {
         // The compressed side is double-buffered: while the blocks of one gulp inflate (in parallel), a helper thread
         // reads the next gulp from the file behind the bytes carried over (the block the previous gulp ended in).
         RawBuf &comp_ = cbuf_[cur_];
@@ -820,8 +820,8 @@ public:
         if (have - o) memcpy(next.data(), comp_.data() + o, have - o);
         if (!eof_) pending_ = std::async(std::launch::async, [this, &next] { fetch(next); });
         cur_ ^= 1;
-        if (offs_.empty()) return inflate_append(out_);  // a gulp that ended inside its first block (cannot repeat: the gulp is 16 MiB)
-        const size_t base = out_.size();
+        if (offs_.empty()) return inflate_append(dst);  // a gulp that ended inside its first block (cannot repeat: the gulp is 16 MiB)
+        const size_t base = dst.size();
         std::vector<size_t> isz(offs_.size()), ooff(offs_.size() + 1, 0);
         for (size_t k = 0; k < offs_.size(); k++) {
             uint32_t v;
@@ -830,7 +830,7 @@ public:
             isz[k] = v;
             ooff[k + 1] = ooff[k] + v;
         }
-        out_.resize(base + ooff.back());
+        dst.resize(base + ooff.back());
         pool_->parallel_for(offs_.size(), [&](size_t k) {
             if (isz[k] == 0) return;
             const size_t hl = 12 + offs_[k].xlen;
@@ -838,7 +838,7 @@ public:
             if (!bgzf_use_zlib()) {
                 static thread_local std::unique_ptr<FastInflate> fi;
                 if (!fi) fi.reset(new FastInflate());
-                if (!fi->inflate(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, out_.data() + base + ooff[k], isz[k]))
+                if (!fi->inflate(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, dst.data() + base + ooff[k], isz[k]))
                     bad_ = true;
             } else {
                 z_stream zs;
@@ -846,7 +846,7 @@ public:
                 if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
                 zs.next_in = comp_.data() + offs_[k].off + hl;
                 zs.avail_in = (uInt)(offs_[k].size - hl - 8);
-                zs.next_out = out_.data() + base + ooff[k];
+                zs.next_out = dst.data() + base + ooff[k];
                 zs.avail_out = (uInt)isz[k];
                 const int rc = inflate(&zs, Z_FINISH);
                 inflateEnd(&zs);
@@ -855,7 +855,7 @@ public:
             // the block's CRC32 (RFC 1952 trailer), as htslib checks it
             uint32_t want;
             memcpy(&want, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
-            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out_.data() + base + ooff[k], (uInt)isz[k]) != want) bad_ = true;
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst.data() + base + ooff[k], (uInt)isz[k]) != want) bad_ = true;
         });
         if (bad_) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
         return true;
