@@ -8,7 +8,9 @@ the way the `fade` driver does — pinned batch block -> fadehip_annotate_upload
 fadehip_annotate_results — with several slots in flight, all driven by one host thread.  Records that anno.d:61-65 gives
 rs = 0 outright (unmapped, no S op) are left out of the batches by the packing step, as the driver's reader threads do;
 they are counted in `value` (they are reads the path has annotated) and in the device's read_count.
-`value` is that streamed, PCIe-inclusive rate; `value_resident` is the same path with the batches already in HBM.
+Each batch's upload is issued right after the previous run of its slot (the ABI's prefetching upload), so H2D, kernels and
+D2H of different batches overlap.  `value` is that streamed, PCIe-inclusive rate; `value_resident` is the same path with
+the batches already in HBM.
 
 One process per GPU: `python bench.py --gpus N` spawns N ranks itself (before anything touches the GPU); under
 torchrun it is one of the ranks.  Reads shard per rank with no data-path collective; the only collective is the final
@@ -164,16 +166,20 @@ def main():
                 profs.append(ctx.last_profile(slot))
             busy[slot] = False
 
+        total = n_steps * BATCHES_PER_STEP
         for _ in range(n_steps):
             for k in range(BATCHES_PER_STEP):
                 slot = seq % n_slots
-                seq += 1
                 if busy[slot]:
                     finish(slot)
-                if not resident:
-                    ctx.annotate_upload(slot, pinned[k])
+                if not resident and seq < n_slots:
+                    ctx.annotate_upload(slot, pinned[k])  # the first batch of each slot; the later ones were prefetched
                 ctx.annotate_run(slot, floor_len, window)
                 busy[slot] = True
+                # the batch of this slot's NEXT run goes up now, beside the run just enqueued (upload never waits for it)
+                if not resident and seq + n_slots < total:
+                    ctx.annotate_upload(slot, pinned[(seq + n_slots) % BATCHES_PER_STEP])
+                seq += 1
         for slot in range(n_slots):
             if busy[(seq + slot) % n_slots]:
                 finish((seq + slot) % n_slots)

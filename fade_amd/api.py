@@ -182,13 +182,15 @@ class Context:
         return out
 
     def annotate_upload(self, slot, batch):
-        """batch: a dict of numpy arrays (gathered into the slot's staging block) or a PinnedBatch (one DMA)."""
+        """batch: a dict of numpy arrays (gathered into the slot's staging block) or a PinnedBatch (one DMA).
+        Never waits for the slot's run in flight: upload the batch of the slot's NEXT run right after annotate_run."""
+        # (the arrays of the batch in flight and of the batch uploaded for the next run are both kept alive)
         if isinstance(batch, PinnedBatch):
-            self._keep[slot] = (batch, batch.n)
+            self._keep[slot] = (self._keep.get(slot, (None,))[-1], batch)
             self._chk(self._L.fadehip_annotate_upload(self._h, slot, C.byref(batch.c)))
             return
         b, keep, n = self._c_batch(batch)
-        self._keep[slot] = (keep, n)
+        self._keep[slot] = (self._keep.get(slot, (None,))[-1], keep)
         self._chk(self._L.fadehip_annotate_upload(self._h, slot, C.byref(b)))
 
     def annotate_run(self, slot, floor_len=5, window=300):
@@ -197,7 +199,7 @@ class Context:
 
     def annotate_results(self, slot):
         """Waits for the slot; rs [n], alignments [n_aln], stats [8] as views into the slot's pinned result block
-        (valid until the slot is uploaded again), plus n_oversize."""
+        (valid until the slot is run again), plus n_oversize."""
         v = _lib.AnnoView()
         self._chk(self._L.fadehip_annotate_results(self._h, slot, C.byref(v)))
         n, n_aln = v.n_reads, v.n_aln
@@ -208,7 +210,7 @@ class Context:
         return rs, aln, np.array(list(v.stats), dtype=np.int64)
 
     def annotate_collect(self, slot, copy=True):
-        """rs [n], alignments [n_aln], stats [8]; with copy=False the arrays are views that the slot's next upload
+        """rs [n], alignments [n_aln], stats [8]; with copy=False the arrays are views that the slot's next run
         invalidates."""
         rs, aln, stats = self.annotate_results(slot)
         if copy:

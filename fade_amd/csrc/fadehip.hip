@@ -60,10 +60,25 @@ struct Slot {
     // slots (gate, selection, plan, pass 2, traceback) would wait behind it for a slot each.  So the score pass runs
     // on a stream whose CU mask leaves a few CUs (one per XCD by default) to everything else.
     hipStream_t score_stream = nullptr;
-    DevBuf in;                       // device mirror of the batch block
+    // Two input buffers: while a run works on in[cur], the next batch is uploaded into in[1 - cur] on the copy stream
+    // (fadehip_annotate_upload never waits for the run in flight, so H2D leaves the slot's critical path).
+    DevBuf in[2];                    // device mirrors of a batch block
+    int cur = 0;
+    bool have_batch = false;         // a batch has been handed to run at least once (it can be run again)
+    hipEvent_t ev_copied = nullptr;  // the H2D of the pending batch, recorded on the ctx's copy stream
     Layout L;                        // layout of the batch in flight
-    PinBuf stage;                    // staging for batches that do not come as one canonical block
+    PinBuf stage[2];                 // staging for batches that do not come as one canonical block (one per input buffer)
     const uint8_t *h_base = nullptr; // host block of the batch in flight (the caller's or `stage`)
+    struct Pending {                 // the batch uploaded for the NEXT run
+        bool valid = false;
+        Layout L;
+        const uint8_t *h_base = nullptr;
+        uint32_t hist[NUM_LISTS] = {};
+        int max_lq = 0;
+        int64_t span_bound = 0;
+        int n_reads = 0, n_skipped = 0;
+        int buf = 0;
+    } next;
     DevBuf rs, fwd, aln, trace;
     DevBuf ckpt, cand;  // two-pass path
     // All small counters of a run live in one block so that one memset clears them and one copy brings them to the host.
@@ -102,7 +117,7 @@ struct Slot {
     int wave_lr_bound = 0, long_max_lq = 0, long_max_lr = 0;
     int floor_len = 0, window = 0;
     int n_reads = 0, n_skipped = 0;
-    int state = 0;  // 0 idle, 1 uploaded, 2 run enqueued, 3 results on the host
+    int state = 0;  // 0 nothing run, 2 run enqueued, 3 results on the host
     int n_aln = 0, n_oversize = 0;
     int64_t stats[8] = {};
     std::vector<hipEvent_t> ev;  // event pool
@@ -131,6 +146,10 @@ struct fadehip_ctx {
     std::vector<int64_t> h_contig_len;
     std::vector<uint64_t> h_contig_base;
     int cu_count = 0;
+    // One copy stream for the uploads of every slot (they share the DMA engine anyway).  The device multiplexes streams
+    // onto few hardware queues and streams that share one run in order: so streams are few and made when first used
+    // (a slot that is never used has none), 2 N + 1 for N slots in use.
+    hipStream_t copy_stream = nullptr;
     // FADEHIP_KERNEL = twopass (default) | pk (single-pass packed int16) | int32 (single-pass int32): A/B runs
     bool use_packed = true;
     bool two_pass = true;
@@ -597,6 +616,41 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int m
     return 0;
 }
 
+// streams, events and the pinned counter block of a slot, made when the slot is first used
+int ensure_slot(fadehip_ctx *ctx, Slot &s) {
+    if (s.stream) return 0;
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
+    HIPCHK(ctx, hipHostMalloc((void **)&s.h_zb, Slot::ZB_BYTES));
+    memset(s.h_zb, 0, Slot::ZB_BYTES);
+    if (ctx->tail_cus_per_xcd > 0 && ctx->cu_count >= 64 && ctx->cu_count % 32 == 0) {
+        // Bits 33 k + 8 j, k = 0..7, j < tail CUs per XCD: one CU in each of the 8 XCDs whether the mask counts CUs
+        // XCD-interleaved (bit i -> XCD i % 8; what MI355X does: a mask that clears bit 0 of every word instead takes
+        // eight CUs from one XCD and costs the score pass 25 %) or XCD by XCD; everything else is enabled.
+        std::vector<uint32_t> mask((size_t)ctx->cu_count / 32, 0xffffffffu);
+        for (int x = 0; x < 8 && 33 * x < ctx->cu_count; x++)
+            for (int j = 0; j < ctx->tail_cus_per_xcd && j < 3; j++) {
+                const int bit = 33 * x + 8 * j;
+                if (bit < ctx->cu_count) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+            }
+        if (const char *kv = getenv("FADEHIP_CU_MASK")) {  // experiments: comma-separated hex words, lowest CUs first
+            size_t w = 0;
+            for (const char *q = kv; *q && w < mask.size(); w++) {
+                mask[w] = (uint32_t)strtoul(q, nullptr, 16);
+                q = strchr(q, ',');
+                if (!q) break;
+                q++;
+            }
+        }
+        if (hipExtStreamCreateWithCUMask(&s.score_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            s.score_stream = nullptr;  // no CU masks on this stack: the score pass stays on the slot's stream
+        }
+    }
+    return 0;
+}
+
 int check_slot(fadehip_ctx *ctx, int slot) {
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
     if (slot < 0 || slot >= FADEHIP_NUM_SLOTS) return set_err(ctx, FADEHIP_E_INVALID, "slot %d out of range", slot);
@@ -607,7 +661,7 @@ int check_slot(fadehip_ctx *ctx, int slot) {
 template <class T>
 const T *h_arr(const Slot &s, int k) { return (const T *)(s.h_base + s.L.off[k]); }
 template <class T>
-const T *d_arr(const Slot &s, int k) { return (const T *)((const uint8_t *)s.in.p + s.L.off[k]); }
+const T *d_arr(const Slot &s, int k) { return (const T *)((const uint8_t *)s.in[s.cur].p + s.L.off[k]); }
 
 // anno.d:61 + util.d:37-62 + dhtslib alignedLength over one record's CIGAR, as gate_kernel computes them
 struct CigarSummary {
@@ -812,7 +866,7 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
     HIPCHK(ctx, hipStreamSynchronize(st));
     const uint32_t errbits = s.h_counters()[2 * NUM_LISTS];
     if (errbits) {
-        s.state = 1;
+        s.state = 0;
         if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
         if (errbits & 16u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a record whose cigar.alignedLength exceeds ref_span_bound=%lld", (long long)s.span_bound);
         if (errbits & 32u) return set_err(ctx, FADEHIP_E_STATE, "internal: a work list outgrew the bound its launches were sized from");
@@ -963,39 +1017,8 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
     static_assert(sizeof(uint32_t) * NUM_BUCKETS <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     static_assert(sizeof(PlanOut) <= 128, "PlanOut overflows its slice");
-    for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
-        Slot &s = ctx->slots[k];
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_zb, Slot::ZB_BYTES) != hipSuccess) {
-            set_err(ctx, FADEHIP_E_HIP, "stream / pinned allocation failed: %s", hipGetErrorString(hipGetLastError()));
-            return fail(FADEHIP_E_HIP);
-        }
-        memset(s.h_zb, 0, Slot::ZB_BYTES);
-        for (int c = 0; c < NUM_CLASSES; c++) s.p2_last_octs[c] = -1;
-        if (ctx->tail_cus_per_xcd > 0 && ctx->cu_count >= 64 && ctx->cu_count % 32 == 0) {
-            // Bits 33 k + 8 j, k = 0..7, j < tail CUs per XCD: one CU in each of the 8 XCDs whether the mask counts CUs
-            // XCD-interleaved (bit i -> XCD i % 8) or XCD by XCD (bit i -> XCD i / 32); everything else is enabled.
-            std::vector<uint32_t> mask((size_t)ctx->cu_count / 32, 0xffffffffu);
-            for (int x = 0; x < 8 && 33 * x < ctx->cu_count; x++)
-                for (int j = 0; j < ctx->tail_cus_per_xcd && j < 3; j++) {
-                    const int bit = 33 * x + 8 * j;
-                    if (bit < ctx->cu_count) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
-                }
-            if (const char *kv = getenv("FADEHIP_CU_MASK")) {  // experiments: comma-separated hex words, lowest CUs first
-                size_t w = 0;
-                for (const char *q = kv; *q && w < mask.size(); w++) {
-                    mask[w] = (uint32_t)strtoul(q, nullptr, 16);
-                    q = strchr(q, ',');
-                    if (!q) { w++; break; }
-                    q++;
-                }
-            }
-            if (hipExtStreamCreateWithCUMask(&s.score_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                s.score_stream = nullptr;  // no CU masks on this stack: the score pass stays on the slot's stream
-            }
-        }
-    }
+    for (int k = 0; k < FADEHIP_NUM_SLOTS; k++)
+        for (int c = 0; c < NUM_CLASSES; c++) ctx->slots[k].p2_last_octs[c] = -1;
     *out = ctx;
     return 0;
 }
@@ -1006,18 +1029,21 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
-        for (DevBuf *b : {&s.in, &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.lrows}) release(*b);
+        for (DevBuf *b : {&s.in[0], &s.in[1], &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.lrows}) release(*b);
         for (int c = 0; c < NUM_LISTS; c++) {
             release(s.work[c]);
             release(s.meta[c]);
         }
-        release(s.stage);
+        release(s.stage[0]);
+        release(s.stage[1]);
         release(s.res);
+        if (s.ev_copied) (void)hipEventDestroy(s.ev_copied);
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
         if (s.h_zb) (void)hipHostFree(s.h_zb);
         if (s.score_stream) (void)hipStreamDestroy(s.score_stream);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     release(ctx->genome);
     for (DevBuf *b : {&ctx->l1_q, &ctx->l1_r, &ctx->l1_qn, &ctx->l1_rn, &ctx->l1_bad, &ctx->l1_work, &ctx->l1_aln}) release(*b);
     release(ctx->contig_len);
@@ -1072,6 +1098,10 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
     if (n == 0) return 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Slot &s = ctx->slots[0];
+    {
+        const int erc = ensure_slot(ctx, s);
+        if (erc) return erc;
+    }
     if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));
     const int64_t q_total = q_off[n], r_total = r_off[n];
     // class-partitioned work lists, built on the host from the offsets (no sequence is touched here)
@@ -1245,12 +1275,21 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
     if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Slot &s = ctx->slots[slot];
-    if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));  // results never fetched: the slot's buffers are still in use
+    if ((rc = ensure_slot(ctx, s))) return rc;
+    // The batch goes to the input buffer the run in flight (if any) does not use, on the ctx's copy stream: upload never
+    // waits for that run, and the run's results stay valid until the slot is RUN again.
+    Slot::Pending &nx = s.next;
+    if (nx.valid) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));  // an earlier upload that was never run: same buffer
+    nx.valid = false;
     const int n = b->n_reads;
-    s.n_reads = n;
-    s.n_skipped = b->n_skipped;
-    s.state = 0;
-    if (n == 0) { s.state = 1; return 0; }
+    nx.n_reads = n;
+    nx.n_skipped = b->n_skipped;
+    nx.buf = 1 - s.cur;
+    memset(nx.hist, 0, sizeof nx.hist);
+    nx.max_lq = 0;
+    nx.span_bound = b->ref_span_bound;
+    nx.h_base = nullptr;
+    if (n == 0) { nx.valid = true; return 0; }
     if (!b->tid || !b->pos || !b->flag || !b->has_sa || !b->l_seq || !b->cigar_off || !b->seq_off ||
         (b->cigar_off[n] && !b->cigar_ops) || (b->seq_off[n] && !b->seq_packed))
         return set_err(ctx, FADEHIP_E_INVALID, "batch has NULL arrays");
@@ -1280,27 +1319,29 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         if (c >= 0) hist[c]++;
         max_lq = std::max(max_lq, std::min(lq, MAX_LONG_QUERY));
     }
-    memcpy(s.hist, hist, sizeof hist);
-    s.max_lq = max_lq;
-    s.span_bound = span;
+    memcpy(nx.hist, hist, sizeof hist);
+    nx.max_lq = max_lq;
+    nx.span_bound = span;
     const Layout L = batch_layout(n, (int64_t)n_cig, (int64_t)n_seq);
     const void *src[N_ARR] = {b->tid, b->pos, b->l_seq, b->cigar_off, b->seq_off, b->flag, b->has_sa, b->cigar_ops, b->seq_packed};
     const uint8_t *base = (const uint8_t *)b->tid;
     bool direct = ((uintptr_t)base & 255u) == 0;
     for (int k = 0; k < N_ARR && direct; k++)
         if (L.bytes[k] && (const uint8_t *)src[k] != base + L.off[k]) direct = false;
-    if ((rc = reserve(ctx, s.in, L.total))) return rc;
+    if ((rc = reserve(ctx, s.in[nx.buf], L.total))) return rc;
     if (!direct) {
-        // arrays from anywhere: gather them into the slot's pinned staging block (one host copy) for the one DMA
-        if ((rc = reserve_pinned(ctx, s.stage, L.total))) return rc;
+        // arrays from anywhere: gather them into the pinned staging block of this input buffer (one host copy) for the one DMA
+        PinBuf &stage = s.stage[nx.buf];
+        if ((rc = reserve_pinned(ctx, stage, L.total))) return rc;
         for (int k = 0; k < N_ARR; k++)
-            if (L.bytes[k]) memcpy(s.stage.p + L.off[k], src[k], L.bytes[k]);
-        base = s.stage.p;
+            if (L.bytes[k]) memcpy(stage.p + L.off[k], src[k], L.bytes[k]);
+        base = stage.p;
     }
-    s.L = L;
-    s.h_base = base;
-    HIPCHK(ctx, hipMemcpyAsync(s.in.p, base, L.off[N_ARR - 1] + L.bytes[N_ARR - 1], hipMemcpyHostToDevice, s.stream));
-    s.state = 1;
+    nx.L = L;
+    nx.h_base = base;
+    HIPCHK(ctx, hipMemcpyAsync(s.in[nx.buf].p, base, L.off[N_ARR - 1] + L.bytes[N_ARR - 1], hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(ctx, hipEventRecord(s.ev_copied, ctx->copy_stream));
+    nx.valid = true;
     return 0;
 }
 
@@ -1308,10 +1349,26 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot &s = ctx->slots[slot];
-    if (s.state < 1) return set_err(ctx, FADEHIP_E_STATE, "slot %d has no uploaded batch", slot);
+    if (!s.next.valid && !s.have_batch) return set_err(ctx, FADEHIP_E_STATE, "slot %d has no uploaded batch", slot);
     if (window < 0) return set_err(ctx, FADEHIP_E_INVALID, "window must be >= 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));  // results never fetched: the slot's buffers are still in use
+    s.state = 0;
+    if (s.next.valid) {
+        // the batch uploaded last becomes the batch of this (and any repeated) run; its H2D is awaited on the device
+        const Slot::Pending &nx = s.next;
+        s.cur = nx.buf;
+        s.L = nx.L;
+        s.h_base = nx.h_base;
+        memcpy(s.hist, nx.hist, sizeof s.hist);
+        s.max_lq = nx.max_lq;
+        s.span_bound = nx.span_bound;
+        s.n_reads = nx.n_reads;
+        s.n_skipped = nx.n_skipped;
+        s.have_batch = true;
+        s.next.valid = false;
+        if (s.n_reads) HIPCHK(ctx, hipStreamWaitEvent(s.stream, s.ev_copied, 0));
+    }
     s.floor_len = floor_len;
     s.window = window;
     if (s.n_reads == 0) {
@@ -1323,7 +1380,7 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
     if ((rc = plan_run(ctx, s))) return rc;
     if ((rc = enqueue_run(ctx, s))) {
         (void)hipStreamSynchronize(s.stream);
-        s.state = 1;
+        s.state = 0;
         return rc;
     }
     s.state = 2;
@@ -1379,7 +1436,9 @@ int fadehip_annotate_collect(fadehip_ctx *ctx, int slot, fadehip_anno_out *out) 
 int fadehip_sync(fadehip_ctx *ctx) {
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) HIPCHK(ctx, hipStreamSynchronize(ctx->slots[k].stream));
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (int k = 0; k < FADEHIP_NUM_SLOTS; k++)
+        if (ctx->slots[k].stream) HIPCHK(ctx, hipStreamSynchronize(ctx->slots[k].stream));
     return 0;
 }
 

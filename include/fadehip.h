@@ -189,7 +189,7 @@ typedef struct {
     int32_t reserved;
 } fadehip_anno_out;
 
-/* Zero-copy form of the results: pointers into the slot's pinned result block, valid until the slot is uploaded again. */
+/* Zero-copy form of the results: pointers into the slot's pinned result block, valid until the slot is RUN again. */
 typedef struct {
     const uint8_t *rs;        /* [n_reads] */
     const fadehip_aln *aln;   /* [n_aln] */
@@ -200,7 +200,9 @@ typedef struct {
 } fadehip_anno_view;
 
 /* Asynchronous pipeline, slot in [0, FADEHIP_NUM_SLOTS); one host thread can keep every slot busy:
- *   upload  : ONE hipMemcpyAsync of the batch block on the slot's stream (see fadehip_batch_bind); returns at once
+ *   upload  : ONE hipMemcpyAsync of the batch block (see fadehip_batch_bind) on the slot's copy stream, into the input
+ *             buffer the slot's run in flight does not use; returns at once.  Uploading batch k + 1 right after run(k)
+ *             takes the H2D off the slot's critical path; the results of run(k) stay valid until run(k + 1)
  *   run     : enqueues gate -> score pass (SW score, end cell, wave snapshots) -> selection of the alignments that can
  *             still be artifact calls -> device-side plan of the traced re-computation -> traced re-computation of
  *             their last steps -> traceback + artifact gates -> D2H of rs / aln / counters into the slot's pinned
@@ -212,8 +214,8 @@ typedef struct {
  *             device found in the batch (bad tid, window beyond max_ref_len, ...) are reported HERE, not by run.  If
  *             the traced re-computation needed more scratch than the slot held, the scratch grows and the batch runs
  *             again inside this call (a warm-up effect; FADEHIP_DEBUG=1 reports it).
- * submit = upload + run.  The batch arrays handed to upload / submit must stay valid and unchanged until the slot's
- * results / collect has returned.  floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
+ * submit = upload + run.  The batch arrays handed to upload / submit must stay valid and unchanged until the results /
+ * collect of the run that consumes them has returned.  floor_len = --min-length (app.d:17), window = --window-size (app.d:18). */
 int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch);
 int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t window);
 int fadehip_annotate_submit(fadehip_ctx *ctx, int slot, const fadehip_read_batch *batch,

@@ -113,7 +113,7 @@ def test_all_slots_in_flight_from_one_thread(ctx):
         assert _key(got[k][1]) == _key(ref[k][1]), k
 
 
-def test_results_are_views_until_the_next_upload(ctx):
+def test_results_are_views_until_the_next_run(ctx):
     cfg, g, b = synth.make_config("C2", 4000, contig_len=200_000)
     ctx.genome_upload(g.names, g.ascii_contigs())
     ctx.annotate_upload(3, b)
@@ -124,14 +124,23 @@ def test_results_are_views_until_the_next_upload(ctx):
     assert len(rs) == 4000 and int(st[0]) == 4000 and len(aln) == int((np.asarray(aln["read_idx"]) >= 0).sum())
     p = ctx.last_profile(3)
     assert p["alignments"] == len(aln) and p["forward_ms"] > 0
-    ctx.annotate_upload(3, b)  # a new batch in the slot: the old results and their profile are gone
-    with pytest.raises(fade_amd.FadeHipError) as e:
-        ctx.last_profile(3)
-    assert e.value.code == -6
-    with pytest.raises(fade_amd.FadeHipError):
-        ctx.annotate_results(3)  # uploaded, not run
-    ctx.annotate_run(3, cfg["floor_len"], cfg["window"])
-    assert np.array_equal(ctx.annotate_results(3)[0], rs)
+    half = synth.take(b, np.arange(2000))
+    ctx.annotate_upload(3, half)  # the batch of the slot's NEXT run goes up; the results of the last run stay
+    rs3, aln3, st3 = ctx.annotate_results(3)
+    assert rs3.ctypes.data == rs.ctypes.data and len(rs3) == 4000 and ctx.last_profile(3)["alignments"] == len(aln)
+    ctx.annotate_run(3, cfg["floor_len"], cfg["window"])  # ... until the slot is run again
+    rs4, aln4, st4 = ctx.annotate_results(3)
+    assert len(rs4) == 2000 and int(st4[0]) == 2000
+    fresh = fade_amd.Context(device=0)
+    try:
+        with pytest.raises(fade_amd.FadeHipError) as e:
+            fresh.annotate_results(0)  # nothing was ever run
+        assert e.value.code == -6
+        with pytest.raises(fade_amd.FadeHipError) as e:
+            fresh.genome_upload(g.names, g.ascii_contigs()) or fresh.annotate_run(0, 5, 100)  # nothing uploaded
+        assert e.value.code == -6
+    finally:
+        fresh.close()
 
 
 def test_two_contexts_on_one_device_interleaved(oracle):
@@ -185,3 +194,27 @@ def test_slot_reuse_without_fetching_results(ctx):
     assert np.array_equal(got[0], want[0]) and list(got[2]) == list(want[2]) and _key(got[1]) == _key(want[1])
     out = ctx.sw_batch([b"ACGTACGTAC"], [b"TTACGTACGTACTT"])  # level 1 borrows slot 0
     assert int(out[0]["score"]) == 20
+
+
+def test_prefetching_uploads_pipeline(ctx):
+    """The streamed pattern of bench.py and of a reader-fed driver: right after run(k) on a slot, the batch of that slot's
+    next run is uploaded (into the slot's other input buffer, on its copy stream) while run(k) is still in flight."""
+    cfg, g, b = synth.make_config("C5", 10 * 3000, contig_len=400_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    parts = [synth.take(b, np.arange(k * 3000, (k + 1) * 3000)) for k in range(10)]
+    ref = [ctx.annotate(p, cfg["floor_len"], cfg["window"], slot=3) for p in parts]
+    pinned = [ctx.pinned_batch(p) for p in parts]
+    n_slots, got = 2, [None] * 10
+    for seq in range(10):
+        slot = seq % n_slots
+        if seq >= n_slots:
+            got[seq - n_slots] = ctx.annotate_collect(slot)
+        else:
+            ctx.annotate_upload(slot, pinned[seq])
+        ctx.annotate_run(slot, cfg["floor_len"], cfg["window"])
+        if seq + n_slots < 10:
+            ctx.annotate_upload(slot, pinned[seq + n_slots])  # beside the run just enqueued
+    for seq in (8, 9):
+        got[seq] = ctx.annotate_collect(seq % n_slots)
+    for k in range(10):
+        assert np.array_equal(got[k][0], ref[k][0]) and list(got[k][2]) == list(ref[k][2]) and _key(got[k][1]) == _key(ref[k][1]), k

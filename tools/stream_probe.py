@@ -37,14 +37,17 @@ for n_slots in SLOTS:
         for phase in range(2):  # warm-up, then timed
             t_up = t_run = t_res = 0.0
             t0 = time.perf_counter()
+            prefetch = os.environ.get("PROBE_PREFETCH", "1") == "1"
             for seq in range(reps):
                 slot = seq % n_slots
                 if busy[slot]:
                     a = time.perf_counter(); ctx.annotate_results(slot); t_res += time.perf_counter() - a
-                if not resident:
+                if not resident and (not prefetch or seq < n_slots):
                     a = time.perf_counter(); ctx.annotate_upload(slot, pinned[seq % nb]); t_up += time.perf_counter() - a
                 a = time.perf_counter(); ctx.annotate_run(slot, cfg["floor_len"], cfg["window"]); t_run += time.perf_counter() - a
                 busy[slot] = True
+                if not resident and prefetch and seq + n_slots < reps:  # the slot's next batch goes up beside this run
+                    a = time.perf_counter(); ctx.annotate_upload(slot, pinned[(seq + n_slots) % nb]); t_up += time.perf_counter() - a
             for slot in range(n_slots):
                 if busy[slot]:
                     a = time.perf_counter(); ctx.annotate_results(slot); t_res += time.perf_counter() - a
