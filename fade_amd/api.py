@@ -51,7 +51,7 @@ class Context:
             raise FadeHipError(rc, self._L.fadehip_last_error(None).decode())
         self._h = h
         self._keep = {}
-        self._out = {}
+        self._views = {}
         self.contig_names = None
 
     def close(self):
@@ -197,15 +197,27 @@ class Context:
         """Enqueues the whole device path of the slot's batch and returns (errors of the batch surface at results)."""
         self._chk(self._L.fadehip_annotate_run(self._h, slot, floor_len, window))
 
+    def _view(self, addr, count, dtype):
+        """numpy view of `count` items at a device-library address; the (address, size) pairs of a streaming run repeat,
+        and building a ctypes array type per call costs tens of microseconds."""
+        key = (addr, count, np.dtype(dtype).itemsize)
+        arr = self._views.get(key)
+        if arr is None:
+            nbytes = count * np.dtype(dtype).itemsize
+            arr = np.frombuffer((C.c_uint8 * nbytes).from_address(addr), dtype=dtype)
+            if len(self._views) > 256:
+                self._views.clear()
+            self._views[key] = arr
+        return arr
+
     def annotate_results(self, slot):
         """Waits for the slot; rs [n], alignments [n_aln], stats [8] as views into the slot's pinned result block
         (valid until the slot is run again), plus n_oversize."""
         v = _lib.AnnoView()
         self._chk(self._L.fadehip_annotate_results(self._h, slot, C.byref(v)))
         n, n_aln = v.n_reads, v.n_aln
-        rs = np.frombuffer((C.c_uint8 * n).from_address(v.rs), dtype=np.uint8) if n else np.zeros(0, np.uint8)
-        aln = (np.frombuffer((C.c_uint8 * (n_aln * ALN_DTYPE.itemsize)).from_address(v.aln), dtype=ALN_DTYPE)
-               if n_aln else np.zeros(0, ALN_DTYPE))
+        rs = self._view(v.rs, n, np.uint8) if n else np.zeros(0, np.uint8)
+        aln = self._view(v.aln, n_aln, ALN_DTYPE) if n_aln else np.zeros(0, ALN_DTYPE)
         self.last_oversize = int(v.n_oversize)
         return rs, aln, np.array(list(v.stats), dtype=np.int64)
 
