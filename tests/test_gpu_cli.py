@@ -179,3 +179,27 @@ def test_cli_bam_input_in_place_records(tmp_path, tag):
     assert second.returncode == 0, second.stderr.decode()
     _, _, rb2 = samutil.bam_to_sam_records(second.stdout)
     assert rb2 == rb
+
+
+def test_cli_input_without_soft_clips(tmp_path):
+    """Nothing to send to the device (anno.d:61-65 settles every record): every record gets rs = 0, the stats still count
+    the reads, and an input with no records at all gives a header-only output."""
+    from fade_amd import synth
+    cfg = synth.config("C2")
+    cfg.update(contig_len=100_000, p_sc=0.0)
+    g = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    b = synth.make_reads(g, 700, 3, **cfg)
+    sam, fa, empty = tmp_path / "in.sam", tmp_path / "ref.fa", tmp_path / "empty.sam"
+    text = samutil.batch_to_sam(b, g.names, [int(x) for x in g.lengths])
+    sam.write_text(text)
+    empty.write_text("".join(l + "\n" for l in text.splitlines() if l.startswith("@")))
+    fa.write_bytes(g.fasta_bytes())
+    p = _run(["annotate", "--stats", "--batch", "300", str(sam), str(fa)])
+    assert p.returncode == 0, p.stderr.decode()
+    header, recs = samutil.parse_sam(p.stdout.decode())
+    assert len(recs) == 700 and all(r["tags"]["rs"][1] == "0" and "am" not in r["tags"] for r in recs)
+    assert b"read count:\t700\nClipped %:\t0\n" in p.stderr
+    for args in ([], ["-b"]):
+        q = _run(["annotate"] + args + [str(empty), str(fa)])
+        assert q.returncode == 0, q.stderr.decode()
+    assert not [l for l in _run(["annotate", str(empty), str(fa)]).stdout.decode().splitlines() if not l.startswith("@")]
