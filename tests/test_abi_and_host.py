@@ -180,3 +180,21 @@ def test_ref_consuming_op_set_has_one_definition():
     assert tuple(k for k in range(16) if (mask >> k) & 1) == _lib.REF_CONSUMING_OPS == (0, 2, 3, 7, 8)
     for path in ("fade_amd/csrc/fadehip_kernels.hpp", "fade_amd/csrc/fadehip.hip"):
         assert "op == 0 || op == 2 || op == 3" not in open(os.path.join(ROOT, path)).read(), path
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/fadehip.h is a C header (C99, -pedantic): a C translation unit that takes the address of every declared
+    entry point compiles and links against libfadehip.so — the boundary a D / cgo / ctypes binding sees."""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    names = _declared_symbols()
+    src.write_text('#include "fadehip.h"\n#include <stdio.h>\nint main(void) {\n    void *p[] = {' +
+                   ", ".join("(void *)%s" % n for n in names) +
+                   '};\n    fadehip_params prm;\n    fadehip_params_default(&prm);\n'
+                   '    printf("%d %d %u %d\\n", fadehip_abi_version(), (int)(sizeof p / sizeof p[0]), prm.rules, (int)sizeof(fadehip_aln));\n    return 0;\n}\n')
+    exe = tmp_path / "abi_c"
+    lib_dir = os.path.join(ROOT, "fade_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", lib_dir, "-lfadehip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=60).stdout.decode().split()
+    assert out == ["2", str(len(names)), "127", "120"]
