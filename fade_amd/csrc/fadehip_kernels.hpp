@@ -1102,8 +1102,11 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 //         resumed from the snapshot taken after step T0-1; no end-cell tracking
 // MODE 3: MODE 2 with the A.4 rule switches read at run time (FADEHIP_RULE_HDIR_DIAG_F_E, _GAP_TIE_EXTENDS off):
 //         a few more instructions per cell, used only when a rule differs from the default
-// waves per SIMD asked of the register allocator for the score pass (the other modes are left alone)
-__host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return (MODE == 1 && R <= 10) ? 4 : 1; }
+// waves per SIMD asked of the register allocator for the score pass: 4 up to R = 10 (128 VGPRs, no spills), 3 up to R = 16
+// (168; R = 16 spills ~100 registers outside its sweep and is still 6 % faster than at 2 waves), 2 beyond (R = 20 / 24:
+// +27 % / +30 % over the unconstrained allocation, which took 256 VGPRs and one wave).  The traced pass is latency-bound
+// and left alone.
+__host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return MODE != 1 ? 1 : (R <= 10 ? 4 : (R <= 16 ? 3 : 2)); }
 
 template <int R, int MODE>
 __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs a) {

@@ -1,6 +1,7 @@
 """Where a streamed step's time goes: host time inside upload / run / results per batch, and the streamed rate for 1..4
 slots in flight (C2, 1 M reads per batch, records without an S op left out).  Run on the GPU box."""
 import json
+import os
 import sys
 import time
 
@@ -14,6 +15,9 @@ cfgname = sys.argv[1] if len(sys.argv) > 1 else "C2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 cfg = synth.config(cfgname)
+if os.environ.get("PROBE_READ_LEN"):  # other row classes: e.g. 210 -> R = 14, 300 -> R = 20
+    cfg["read_len"] = int(os.environ["PROBE_READ_LEN"])
+    cfg["insert_mu"] = max(cfg["insert_mu"], cfg["read_len"] + 200)
 g = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
 ctx = fade_amd.Context(device=0)
 ctx.genome_upload(g.names, g.ascii_contigs())
