@@ -1104,8 +1104,8 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 //         a few more instructions per cell, used only when a rule differs from the default
 // waves per SIMD asked of the register allocator for the score pass: 4 up to R = 10 (128 VGPRs, no spills), 3 up to R = 16
 // (168; R = 16 spills ~100 registers outside its sweep and is still 6 % faster than at 2 waves), 2 beyond (R = 20 / 24:
-// +27 % / +30 % over the unconstrained allocation, which took 256 VGPRs and one wave).  The traced pass is latency-bound
-// and left alone.
+// +27 % / +30 % over the unconstrained allocation, which took 256 VGPRs and one wave).  The traced pass is latency-bound:
+// 3 or 4 waves per SIMD (40 / 85 spilled registers) changed nothing measurable, it is left alone.
 __host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return MODE != 1 ? 1 : (R <= 10 ? 4 : (R <= 16 ? 3 : 2)); }
 
 template <int R, int MODE>
