@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         uint32_t total = 0;
 #pragma unroll
         for (int k = 0; k < NUM_BUCKETS; k++) {
-            const uint32_t cnt = a.bucket_n[NUM_BUCKETS - 1 - k];  // longest bucket first
+            const uint32_t cnt = min(a.bucket_n[NUM_BUCKETS - 1 - k], a.cand_cap);  // longest bucket first (a bucket never holds more than its capacity)
             const int octs_k = (int)((cnt + 7) / 8);
             if (b < 0 && oct < first + octs_k) { b = NUM_BUCKETS - 1 - k; local = oct - first; n_b = (int)cnt; }
             first += octs_k;

@@ -365,7 +365,11 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
     std::vector<uint8_t> rs(n, 0);
     for (size_t k = 0; k < c.sent.size(); k++) rs[c.sent[k]] = c.rs_sent[k];
     std::vector<int> art_of(n, -1);
-    for (size_t k = 0; k < c.art.size(); k++) art_of[c.sent[(size_t)c.art[k].read_idx]] = (int)k;
+    for (size_t k = 0; k < c.art.size(); k++) {
+        const int32_t si = c.art[k].read_idx;  // an index into the records that were sent
+        if (si < 0 || (size_t)si >= c.sent.size()) throw std::runtime_error("device returned an alignment for a record that was not sent");
+        art_of[c.sent[(size_t)si]] = (int)k;
+    }
     const size_t nt = (size_t)pool.size();
     if (!c.is_block) {
         pool.parallel_for(nt, [&](size_t t) {
