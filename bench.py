@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--slots", type=int, default=2, help="batches in flight per GPU")
     ap.add_argument("--full-batches", action="store_true", help="send every record (no anno.d:61-65 filter in the packing step)")
+    ap.add_argument("--no-all-sent", action="store_true", help="skip the secondary figure with every record sent")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -134,7 +135,7 @@ def main():
     ctx = fade_amd.Context(device=local, max_batch_reads=max(args.batch_reads, 1 << 20))
     ctx.genome_upload(genome.names, genome.ascii_contigs())
     # per-GPU record range: each rank owns its own shard of the reads (seed 100 (k + 1) + rank)
-    full, pinned = [], []
+    full, pinned, pinned_all = [], [], []
     t_gen = time.perf_counter()
     for k in range(BATCHES_PER_STEP):
         b = synth.make_reads(genome, args.batch_reads, 100 * (k + 1) + rank, **cfg)
@@ -144,6 +145,10 @@ def main():
         else:
             sub, _ = ctx.clipped_only(b)  # what the driver's reader threads do while they pack a batch
         pinned.append(ctx.pinned_batch(sub))
+        if not args.full_batches and not args.no_all_sent and k < 4:
+            allrec = dict(b)  # every record, for the secondary figure: nothing left to the packing step
+            allrec["ref_span_bound"] = sub["ref_span_bound"]
+            pinned_all.append(ctx.pinned_batch(allrec))
         full.append(b if (rank == 0 and not args.no_cpu and world == 1) else None)
     t_gen = time.perf_counter() - t_gen
     floor_len, window = cfg["floor_len"], cfg["window"]
@@ -153,7 +158,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n_steps, resident, profs=None):
+    def run_steps(n_steps, resident, profs=None, pinned=pinned):
         """n_steps x BATCHES_PER_STEP batches through the slots; returns the summed stats.d counters."""
         stats = np.zeros(8, np.int64)
         busy = [False] * n_slots
@@ -176,12 +181,12 @@ def main():
                 if busy[slot]:
                     finish(slot)
                 if not resident and seq < n_slots:
-                    ctx.annotate_upload(slot, pinned[k])  # the first batch of each slot; the later ones were prefetched
+                    ctx.annotate_upload(slot, pinned[k % len(pinned)])  # the first batch of each slot; the later ones were prefetched
                 ctx.annotate_run(slot, floor_len, window)
                 busy[slot] = True
                 # the batch of this slot's NEXT run goes up now, beside the run just enqueued (upload never waits for it)
                 if not resident and seq + n_slots < total:
-                    ctx.annotate_upload(slot, pinned[(seq + n_slots) % BATCHES_PER_STEP])
+                    ctx.annotate_upload(slot, pinned[(seq + n_slots) % BATCHES_PER_STEP % len(pinned)])
                 seq += 1
         for slot in range(n_slots):
             if busy[(seq + slot) % n_slots]:
@@ -204,6 +209,16 @@ def main():
     run_steps(res_steps, True)
     barrier()
     dt_res = time.perf_counter() - t0
+    # ---- secondary: every record sent (the packing step leaves nothing out): 10x the bytes over PCIe, 10x the records
+    # through upload's validation pass and the gate
+    dt_all = None
+    if pinned_all:
+        run_steps(1, False, pinned=pinned_all)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(2, False, pinned=pinned_all)
+        barrier()
+        dt_all = time.perf_counter() - t0
     # ---- the dominant kernel alone on the device (one slot, serial): its HIP-event time without a neighbour
     solo = []
     for k in range(3):
@@ -255,6 +270,7 @@ def main():
             "parity": "bit-exact vs the restated reference semantics (oracle/; unpinned: the reference has no tests or fixtures and cannot be built here)",
             "value_is": "streamed: pinned host batch -> upload (1 hipMemcpyAsync) -> run -> results on the host, %d slots in flight, one host thread" % n_slots,
             "value_resident": reads_per_step * world * res_steps / dt_res_max,
+            "value_all_records_sent": None if dt_all is None else reads_per_step * 2 / dt_all,  # this rank's rate, per GPU
             "config": {"workload": workload, "batches_per_step": BATCHES_PER_STEP,
                        "records_sent_per_step": int(sum(p.n for p in pinned)),
                        "upload_bytes_per_step": int(sum(p.nbytes for p in pinned)),
