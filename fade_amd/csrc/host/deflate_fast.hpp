@@ -22,18 +22,39 @@ public:
     // worst case: a stored block (5 bytes of framing); the caller's buffer must hold n + 16 bytes
     static constexpr size_t bound(size_t n) { return n + 16; }
 
-    // effort: 1 = greedy parse, 2 = lazy parse (default), 3 = lazy parse over 4 candidates per hash
-    explicit FastDeflate(int effort = 2) : effort_(std::max(1, std::min(3, effort))) {
+    // effort: 1 = greedy parse that stops probing early in match-free stretches, 2 = lazy parse with a milder skip
+    // (default: output no larger than zlib level 6's on BAM payloads), 3 = lazy parse probing every position,
+    // 4 = lazy parse over 4 candidates per hash.  skip_after / skip_cap >= 0 override the effort's skip rule (parse()).
+    static constexpr int MAX_EFFORT = 4;
+    explicit FastDeflate(int effort = 2, int skip_after = -1, int skip_cap = -1) : effort_(std::max(1, std::min(MAX_EFFORT, effort))) {
         lazy_ = effort_ >= 2;
+        skip_after_ = effort_ == 1 ? 4 : effort_ == 2 ? 16 : 0;
+        skip_cap_ = effort_ == 1 ? 15 : effort_ == 2 ? 7 : 0;
+        if (skip_after >= 0) skip_after_ = (size_t)skip_after;
+        if (skip_cap >= 0) skip_cap_ = (size_t)skip_cap;
         init_static();
     }
 
     // Compresses in[0, n), n <= MAX_IN, into one final DEFLATE block at out; returns the byte count (<= bound(n)).
     size_t compress(const uint8_t *in, size_t n, uint8_t *out) {
-        if (effort_ >= 3) parse<4, 15>(in, n);
+#ifdef FADE_DEFLATE_TIMING  // selftest only: where a block's time goes
+        const auto t0 = std::chrono::steady_clock::now();
+#endif
+        if (effort_ >= 4) parse<4, 15>(in, n);
         else parse<1, 14>(in, n);
+#ifdef FADE_DEFLATE_TIMING
+        const auto t1 = std::chrono::steady_clock::now();
+        const size_t r = encode(in, n, out);
+        t_parse += std::chrono::duration<double>(t1 - t0).count();
+        t_encode += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        return r;
+#else
         return encode(in, n, out);
+#endif
     }
+#ifdef FADE_DEFLATE_TIMING
+    double t_parse = 0, t_encode = 0;
+#endif
 
 private:
     // ------------------------------------------------------------------ LZ77 parse
@@ -43,9 +64,13 @@ private:
     // cache-miss chain per position (measured: 45 cycles/position against 20).  Only a 5-byte hit branches into the
     // extension code.  Minimum match 5: shorter ones rarely pay for their distance bits.
     // Measured on BAM payloads (selftest/deflate_selftest <file>; uniform qualities / binned qualities with runs):
-    //   1 way,  14 bits: 0.5701 / 0.4082 of the input at 70 MB/s       (efforts 1 and 2)
-    //   4 ways, 15 bits: 0.5684 / 0.40   at 29 MB/s                    (effort 3)
+    //   1 way,  14 bits: 0.5701 / 0.4082 of the input at 70 MB/s       (effort 3)
+    //   4 ways, 15 bits: 0.5684 / 0.40   at 29 MB/s                    (effort 4)
     //   zlib level 6   : 0.5908 / 0.3957 at 8-14 MB/s on the same core
+    // The parse is 78 % of a block's time and nearly all of it is probes that find nothing, so efforts 1 and 2 skip
+    // (see the literal branch of parse()).  On an idle core of the GPU box's host, uniform qualities
+    // (tools/deflate_where.sh): effort 1 364 MB/s 0.6020, effort 2 264 MB/s 0.5907, effort 3 201 MB/s 0.5709,
+    // effort 4 86 MB/s 0.5691; zlib level 1 88 MB/s 0.6123, zlib level 6 40 MB/s 0.5915.
     static constexpr int MIN_MATCH = 5, MAX_MATCH = 258;
     static constexpr uint64_t MASK5 = 0xffffffffffull;
     static inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -111,10 +136,12 @@ private:
         extra_bits_ = 0;
         const size_t hash_end = n >= 8 ? n - 7 : 0;  // positions < hash_end can be hashed
         size_t p = 0;
+        size_t miss = 0;  // positions probed in vain since the last match
         while (p < n) {
             int len = 0, dist = 0;
             if (p < hash_end) len = find<WAYS, HB>(in, n, p, dist);
             if (len >= MIN_MATCH) {
+                miss = 0;
                 bool probed = false;  // whether p + 1 is already in the table
                 if (lazy_) {
                     // defer while the next position starts a strictly longer match
@@ -135,6 +162,14 @@ private:
             } else {
                 put_literal(in[p]);
                 p++;
+                if (skip_after_) {
+                    // Qualities and packed bases: nothing to find for hundreds of bytes, and every probe costs ~10 cycles.
+                    // After skip_after_ probes in vain, each further one is followed by (misses / skip_after_, at most
+                    // skip_cap_) literals that are neither probed nor entered into the table.
+                    miss++;
+                    size_t k = std::min<size_t>(miss / skip_after_, skip_cap_);
+                    for (; k && p < n; k--) put_literal(in[p++]);
+                }
             }
         }
         count_literals();
@@ -431,6 +466,7 @@ private:
         return (size_t)(bw.finish() - out);
     }
 
+    size_t skip_after_ = 0, skip_cap_ = 0;  // 0: every position is probed
     int effort_;
     bool lazy_;
     uint64_t tab_[1 << 15];

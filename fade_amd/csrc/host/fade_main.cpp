@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <deque>
 #include <functional>
+#include <unistd.h>
 
 #ifndef FADE_VERSION
 #define FADE_VERSION "v0.5.0-mi355x"
@@ -455,9 +456,32 @@ struct StageThreads {
     }
 };
 
+// seconds since the kernel started this process (/proc/self/stat field 22 against /proc/uptime), for -T only
+static double since_process_start() {
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return 0;
+    char buf[2048];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')');  // comm may contain spaces
+    unsigned long long start = 0;
+    if (!p) return 0;
+    p += 2;
+    for (int field = 3; field < 22 && p; field++) { p = strchr(p, ' '); if (p) p++; }
+    if (!p || sscanf(p, "%llu", &start) != 1) return 0;
+    double up = 0;
+    f = fopen("/proc/uptime", "r");
+    if (!f) return 0;
+    if (fscanf(f, "%lf", &up) != 1) up = 0;
+    fclose(f);
+    return up - (double)start / (double)sysconf(_SC_CLK_TCK);
+}
+
 static int annotate_main(const std::string &cl, const Opts &o) {
     StageClock ck_total, ck_fasta, ck_upload, ck_read, ck_pack, ck_submit, ck_collect, ck_tags, ck_write;
     ck_total.start();
+    if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (annotate begins)\n", since_process_start());
     // anno.d:18-19 (htslib log format)
     fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
     const int nthreads = o.threads > 0 ? o.threads : std::max(1u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u);
@@ -1126,7 +1150,29 @@ int main(int argc, char **argv) {
             fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");
             return 1;
         }
-        return annotate_main(cl, o);
+        const int rc = annotate_main(cl, o);
+        if (o.timing) {
+            long rss_kb = 0, hwm_kb = 0;
+            if (FILE *f = fopen("/proc/self/status", "r")) {
+                char line[256];
+                while (fgets(line, sizeof line, f)) {
+                    sscanf(line, "VmRSS: %ld", &rss_kb);
+                    sscanf(line, "VmHWM: %ld", &hwm_kb);
+                }
+                fclose(f);
+            }
+            if (const char *dump = getenv("FADE_SMAPS_DUMP")) {  // tools/smaps_top.py
+                FILE *fi = fopen("/proc/self/smaps", "r"), *fo = fopen(dump, "w");
+                char buf[4096];
+                size_t n;
+                while (fi && fo && (n = fread(buf, 1, sizeof buf, fi)) > 0) fwrite(buf, 1, n, fo);
+                if (fi) fclose(fi);
+                if (fo) fclose(fo);
+            }
+            fprintf(stderr, "[timing] since process start %.3f s (annotate returned); resident %ld MB, peak %ld MB\n", since_process_start(),
+                    rss_kb >> 10, hwm_kb >> 10);
+        }
+        return rc;
     }
     if (sub == "extract") {  // app.d:130-153
         Opts o;

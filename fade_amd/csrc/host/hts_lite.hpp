@@ -27,6 +27,7 @@
 #include <memory>
 #include <vector>
 
+#include "crc32_fast.hpp"
 #include "deflate_fast.hpp"
 #include "inflate_fast.hpp"
 
@@ -598,7 +599,7 @@ static const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff
 
 // FADE_BGZF_CODEC=zlib selects zlib (level 6 deflate, what htslib does by default, and zlib's inflate) instead of
 // deflate_fast.hpp / inflate_fast.hpp;
-// FADE_BGZF_EFFORT=1|2|3 picks FastDeflate's effort (default 2)
+// FADE_BGZF_EFFORT=1..4 picks FastDeflate's effort (default 2)
 inline bool bgzf_use_zlib() {
     static const bool z = [] {
         const char *e = getenv("FADE_BGZF_CODEC");
@@ -614,7 +615,7 @@ inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::ve
     if (level > 0 && !bgzf_use_zlib()) {
         static thread_local std::unique_ptr<FastDeflate> fd;
         if (!fd) {
-            const char *e = getenv("FADE_BGZF_EFFORT");  // 1 fastest, 2 default, 3 closest to zlib level 6 in size
+            const char *e = getenv("FADE_BGZF_EFFORT");  // 1 fastest ... 4 smallest (deflate_fast.hpp)
             fd.reset(new FastDeflate(e ? atoi(e) : 2));
         }
         clen = fd->compress(src, n, buf + 18);
@@ -636,7 +637,7 @@ inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::ve
     memcpy(buf, hdr, 16);
     const uint16_t bs = (uint16_t)(bsize - 1);
     memcpy(buf + 16, &bs, 2);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n), isz = (uint32_t)n;
+    const uint32_t crc = crc32_fast(0, src, n), isz = (uint32_t)n;
     memcpy(buf + 18 + clen, &crc, 4);
     memcpy(buf + 18 + clen + 4, &isz, 4);
     out.insert(out.end(), buf, buf + bsize);
@@ -855,7 +856,7 @@ public:
             // the block's CRC32 (RFC 1952 trailer), as htslib checks it
             uint32_t want;
             memcpy(&want, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
-            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst.data() + base + ooff[k], (uInt)isz[k]) != want) bad_ = true;
+            if (crc32_fast(0, dst.data() + base + ooff[k], isz[k]) != want) bad_ = true;
         });
         if (bad_) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
         return true;

@@ -8,6 +8,7 @@
 #include <random>
 #include <string>
 #include <vector>
+#include "../crc32_fast.hpp"
 #include "../deflate_fast.hpp"
 #include "../inflate_fast.hpp"
 
@@ -92,8 +93,9 @@ static size_t zlib_block(const uint8_t *in, size_t n, int level, uint8_t *out, s
 int main(int argc, char **argv) {
     std::mt19937_64 rng(12345);
     int fails = 0, cases = 0;
-    for (int effort = 1; effort <= 3; effort++) {
-        FastDeflate fd(effort);
+    for (int effort = 1; effort <= FastDeflate::MAX_EFFORT + 1; effort++) {
+        // (the last round: a skip rule far beyond the shipped ones)
+        FastDeflate fd = effort <= FastDeflate::MAX_EFFORT ? FastDeflate(effort) : FastDeflate(2, 1, 300);
         auto check = [&](const std::vector<uint8_t> &v, const char *what) {
             cases++;
             if (!roundtrip(fd, v.data(), v.size(), nullptr)) { fprintf(stderr, "  case: %s, n=%zu, effort=%d\n", what, v.size(), effort); fails++; }
@@ -163,6 +165,24 @@ int main(int argc, char **argv) {
             check(v, "mixture");
         }
     }
+    // crc32_fast against zlib's crc32: every length up to 5000, random lengths and offsets beyond, and continuation
+    {
+        std::vector<uint8_t> v(1 << 17);
+        for (auto &c : v) c = (uint8_t)rng();
+        for (int it = 0; it < 30000; it++) {
+            size_t n = it < 5000 ? (size_t)it : (size_t)(rng() % 70000);
+            const size_t off = (size_t)(rng() % 64);
+            n = std::min(n, v.size() - off);
+            const size_t cut = n ? (size_t)(rng() % n) : 0;
+            const uint32_t want = (uint32_t)crc32(0L, v.data() + off, (uInt)n);
+            cases++;
+            if (crc32_fast(0, v.data() + off, n) != want ||
+                crc32_fast(crc32_fast(0, v.data() + off, cut), v.data() + off + cut, n - cut) != want) {
+                fprintf(stderr, "crc32_fast differs from zlib: n=%zu off=%zu cut=%zu\n", n, off, cut);
+                fails++;
+            }
+        }
+    }
     printf("deflate_selftest: %d cases, %d failures\n", cases, fails);
     if (fails) return 1;
 
@@ -176,26 +196,30 @@ int main(int argc, char **argv) {
         fclose(f);
         const size_t B = 0xff00;
         std::vector<uint8_t> out(B + 1024);
-        for (int mode = 0; mode < 5; mode++) {  // 0..2 FastDeflate effort 1..3, 3 = zlib 1, 4 = zlib 6
-            FastDeflate fd(std::min(mode + 1, 3));
+        const int NE = FastDeflate::MAX_EFFORT;
+        for (int mode = 0; mode < NE + 2; mode++) {  // FastDeflate effort 1..NE, then zlib 1 and zlib 6
+            FastDeflate fd(std::min(mode + 1, NE));
             size_t total = 0;
             const auto t0 = std::chrono::steady_clock::now();
             for (size_t o = 0; o < data.size(); o += B) {
                 const size_t n = std::min(B, data.size() - o);
-                if (mode < 3) {
+                if (mode < NE) {
                     size_t c = 0;
                     if (!roundtrip(fd, data.data() + o, n, &c)) return 1;
                     total += c;
-                } else total += zlib_block(data.data() + o, n, mode == 3 ? 1 : 6, out.data(), out.size());
+                } else total += zlib_block(data.data() + o, n, mode == NE ? 1 : 6, out.data(), out.size());
             }
             double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (mode < 3) {  // time compression alone (the loop above also inflates)
+            if (mode < NE) {  // time compression alone (the loop above also inflates)
                 const auto t1 = std::chrono::steady_clock::now();
                 for (size_t o = 0; o < data.size(); o += B) fd.compress(data.data() + o, std::min(B, data.size() - o), out.data());
                 dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
             }
+#ifdef FADE_DEFLATE_TIMING
+            if (mode < NE) printf("    parse %.3f s, encode %.3f s (both loops)\n", fd.t_parse, fd.t_encode);
+#endif
             printf("%-22s %10zu -> %10zu bytes (%.4f)  %7.1f MB/s\n",
-                   mode < 3 ? (std::string("FastDeflate effort ") + std::to_string(mode + 1)).c_str() : (mode == 3 ? "zlib level 1" : "zlib level 6"),
+                   mode < NE ? (std::string("FastDeflate effort ") + std::to_string(mode + 1)).c_str() : (mode == NE ? "zlib level 1" : "zlib level 6"),
                    data.size(), total, (double)total / (double)data.size(), (double)data.size() / dt / 1e6);
         }
     }

@@ -76,6 +76,8 @@ def main():
 
     def run(tag, exe, args, out, t, env=None):
         base = [exe, "annotate", "--timing", "-t", str(t), "-w", str(cfg["window"]), "--batch", "262144"]
+        if os.path.exists(out):  # (truncating the previous leg's 1.6 GB output costs 0.3 s: not part of this leg)
+            os.remove(out)
         t1 = time.time()
         with open(out, "wb") as fo:
             p = subprocess.run(base + args, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
@@ -93,6 +95,8 @@ def main():
         return
     run("gpu_bam_to_bam", fade, ["-b", bam, fa], out_gpu, threads)
     run("gpu_bam_to_bam_effort1", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), threads, env={"FADE_BGZF_EFFORT": "1"})
+    run("gpu_bam_to_bam_effort3", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), threads, env={"FADE_BGZF_EFFORT": "3"})
+    run("gpu_bam_to_bam_again", fade, ["-b", bam, fa], out_gpu, threads)
     run("gpu_bam_to_bam_32_threads", fade, ["-b", bam, fa], os.path.join(tmp, "e2e.out3.bam"), 32)
     run("gpu_bam_to_ubam", fade, ["-u", bam, fa], os.path.join(tmp, "e2e.out.ubam"), threads)
     run("gpu_sam_to_bam", fade, ["-b", sam, fa], os.path.join(tmp, "e2e.out2.bam"), threads)
