@@ -138,7 +138,7 @@ struct Cand {           // pass-2 work item: which alignment, and the sweep step
 #ifndef FADEHIP_CK_SHIFT
 #define FADEHIP_CK_SHIFT 7
 #endif
-constexpr int CK_SHIFT = FADEHIP_CK_SHIFT, CK_COLS = 1 << CK_SHIFT;  // snapshot stride (a multiple of the 32-step key window)
+constexpr int CK_SHIFT = FADEHIP_CK_SHIFT, CK_COLS = 1 << CK_SHIFT;  // snapshot stride (a multiple of the 16- or 32-step key window)
 static_assert(CK_SHIFT >= 5 && CK_SHIFT <= 9, "snapshots fall on key-window ends");
 __host__ __device__ constexpr int ck_dwords(int R) { return 2 * R + 4; }  // per lane per snapshot
 constexpr int NUM_BUCKETS = 10;                       // pass-2 lists by number of sweep steps to re-compute
@@ -1243,10 +1243,15 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // End-cell tracking.  MODE 0: a 32-bit key (H, 0xffff - t) per row and alignment.  MODE 1: one packed 16-bit
     // key per row PAIR, 4*H8 + (31 - t % 32) = (32*H, position inside the current 32-step window), folded into
     // (GH, GT) = (best 32*H so far, its step) at every window end: 2 + 0.3 instructions per cell pair instead of 3.
-    // MODE 1, row classes up to 14 (scores <= 448): ONE key per pair of rows, 8*H8 + 2*(31 - t % 32) + (row even), kept
-    // with v_pk_maximum3_f16 (1.5 instead of 2 instructions per cell pair and half the fold work; the key stays below
-    // the f16 infinity pattern 0x7c00 only while 64 * score + 63 < 31744).
-    constexpr bool PAIRKEY = (MODE == 1) && (R <= 14);
+    // MODE 1, row classes up to 24: ONE key per pair of rows, kept with v_pk_maximum3_f16 (1.5 instead of 2 instructions
+    // per cell pair), which orders the 16-bit patterns only below the f16 infinity 0x7c00.  Row classes up to 14 (scores
+    // <= 448): 8*H8 + 2*(31 - t % 32) + (row even) = 64 * score + 6 low bits, 32-step windows and half the fold work.
+    // Row classes 16 .. 24 (scores <= 768): 4*H8 + 2*(15 - t % 16) + (row even) = 32 * score + 5 low bits, 16-step
+    // windows (the fold work of the unpaired key).  R = 32 (scores up to 1024) keeps one key per row.
+    constexpr bool PAIRKEY = (MODE == 1) && (R <= 24);
+    constexpr int KW = (PAIRKEY && R > 14) ? 16 : 32;              // steps per key window
+    constexpr int KLOW = PAIRKEY ? (KW == 32 ? 6 : 5) : 5;          // key bits below the score
+    constexpr uint32_t KLOWM = ((1u << KLOW) - 1u) * 0x10001u;      // ... as a mask over both halves
     uint32_t Hl[R], Eh[R], bestA[R], bestB[R];  // MODE 1 reuses bestA as the window key and bestB as GH
     uint32_t GT[R];
 #pragma unroll
@@ -1323,9 +1328,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         }
     }
     const uint8_t *wt = reinterpret_cast<const uint8_t *>(wtab);
-    constexpr int GROUP = (MODE == 1) ? 8 : (1 << 30);
+    constexpr int GROUP = (MODE == 1) ? KW / 4 : (1 << 30);  // blocks (of 4 steps) per key window
     for (int blk0 = 0; blk0 < n_blocks; blk0 += GROUP) {
-    const int blk_end = (MODE == 1) ? min(n_blocks, blk0 + 8) : n_blocks;
+    const int blk_end = (MODE == 1) ? min(n_blocks, blk0 + GROUP) : n_blocks;
     for (int blk = blk0; blk < blk_end; blk++) {
         const uint64_t rw = *reinterpret_cast<const uint64_t *>(lref + blk * 4);
         uint32_t acc[R];
@@ -1352,9 +1357,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                 tB = make_uint2(e.y, e.w);
             }
             const uint32_t ct = (uint32_t)(0xffff - t);
-            const uint32_t tk = (uint32_t)(31 - (t & 31)) * 0x10001u;  // MODE 1: position inside the 32-step window
-            // PAIRKEY: ... and which row of the pair: 2 * position + (row even), or 32 * (row even) + position
-            const uint32_t tk_even = end_min_ref ? tk * 2u + 0x10001u : tk + 0x00200020u, tk_odd = end_min_ref ? tk * 2u : tk;
+            const uint32_t tk = (uint32_t)(KW - 1 - (t & (KW - 1))) * 0x10001u;  // MODE 1: position inside the key window
+            // PAIRKEY: ... and which row of the pair: 2 * position + (row even), or KW * (row even) + position
+            const uint32_t tk_even = end_min_ref ? tk * 2u + 0x10001u : tk + (uint32_t)KW * 0x10001u, tk_odd = end_min_ref ? tk * 2u : tk;
             uint32_t kprev = 0;
             uint32_t hd = hu_prev;
             hu_prev = hu;
@@ -1402,7 +1407,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                     bestA[r] = as_u32(__builtin_elementwise_max(as_u2(bestA[r]), as_u2(pk_mad4(H, tk))));
                 }
                 if constexpr (PAIRKEY) {
-                    const uint32_t k = pk_mad8(H, (r & 1) ? tk_odd : tk_even);
+                    const uint32_t k = KW == 32 ? pk_mad8(H, (r & 1) ? tk_odd : tk_even) : pk_mad4(H, (r & 1) ? tk_odd : tk_even);
                     if (r & 1) bestA[r >> 1] = pk_max3_nonneg(bestA[r >> 1], kprev, k);
                     else kprev = k;
                 }
@@ -1423,12 +1428,11 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     }
     if constexpr (MODE == 1) {
         // fold the window's keys into (GH, GT); a later window wins only with a strictly larger H (Appendix A.3)
-        // PAIRKEY: GT holds 2 * t + (row odd) = (2 * (32 * window + 31) + 1) - (2 * (31 - t % 32) + (row even))
-        // (a pair key under the other A.3 rule: the row bit ranks with H, GT = 64 * window + 32 * (row odd) + t % 32)
-        const uint32_t wbase = PAIRKEY ? (end_min_ref ? (uint32_t)(((blk0 >> 3) * 32 + 31) * 2 + 1) * 0x10001u
-                                                      : (uint32_t)((blk0 >> 3) * 64 + 63) * 0x10001u)
-                                       : (uint32_t)((blk0 >> 3) * 32 + 31) * 0x10001u;
-        const uint32_t HMASK = PAIRKEY ? (end_min_ref ? 0xffc0ffc0u : 0xffe0ffe0u) : 0xffe0ffe0u, PMASK = PAIRKEY ? 0x003f003fu : 0x001f001fu;
+        // PAIRKEY: GT holds 2 * t + (row odd) = (2 * (KW * window + KW - 1) + 1) - (2 * (KW - 1 - t % KW) + (row even))
+        // (a pair key under the other A.3 rule: the row bit ranks with H, GT = 2 KW * window + KW * (row odd) + t % KW)
+        const uint32_t win = (uint32_t)(blk0 / GROUP);
+        const uint32_t wbase = PAIRKEY ? (win * (2 * KW) + (2 * KW - 1)) * 0x10001u : (win * 32 + 31) * 0x10001u;
+        const uint32_t HMASK = (PAIRKEY && !end_min_ref) ? ~(((1u << (KLOW - 1)) - 1u) * 0x10001u) : ~KLOWM, PMASK = KLOWM;
 #pragma unroll
         for (int r = 0; r < (PAIRKEY ? R / 2 : R); r++) {
             const uint32_t wk = bestA[r];
@@ -1441,9 +1445,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             bestA[r] = 0;
         }
         // snapshot of the wave state after step 32(k+1)-1
-        constexpr int WIN_PER_CK = CK_COLS / 32;
-        const int sn = ((blk0 >> 3) + 1) / WIN_PER_CK - 1;
-        if (blk_end == blk0 + 8 && ((blk0 >> 3) + 1) % WIN_PER_CK == 0 && sn < a.n_ck) {
+        constexpr int WIN_PER_CK = CK_COLS / KW;
+        const int sn = ((int)win + 1) / WIN_PER_CK - 1;
+        if (blk_end == blk0 + GROUP && ((int)win + 1) % WIN_PER_CK == 0 && sn < a.n_ck) {
             constexpr int CKD = ck_dwords(R);
             uint32_t *cp = ckw + (uint64_t)sn * (CKD * 64);
 #pragma unroll
@@ -1481,13 +1485,16 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
 #pragma unroll
         for (int p2 = 0; p2 < NK; p2++) {
             const uint32_t gh = bestB[p2], gt = GT[p2];
-            const uint32_t ha = (gh & 0xffc0u) >> 3, hb = (gh >> 19) & 0x1ff8u;  // 64*H = 8*H8
+            // the key's score field is 64 * score = 8 * H8 (6 low bits) or 32 * score = 4 * H8 (5 low bits)
+            constexpr int KS = KLOW - 3, KB = KLOW - 1;  // shift back to H8; bits of the position inside a window
+            const uint32_t ha = ((gh & 0xffffu) >> KLOW) << 3, hb = (gh >> (16 + KLOW)) << 3;
+            static_assert(KS == 2 || KS == 3, "key scale");
             const uint32_t gta = gt & 0xffffu, gtb = gt >> 16;
-            // GT = 2 t + (row odd), or 64 * (t / 32) + 32 * (row odd) + t % 32 under the other A.3 rule
-            const uint32_t ta = end_min_ref ? gta >> 1 : ((gta >> 6) << 5) | (gta & 31u);
-            const uint32_t tb = end_min_ref ? gtb >> 1 : ((gtb >> 6) << 5) | (gtb & 31u);
-            rowA[p2] = 2u * (uint32_t)p2 + (end_min_ref ? (gta & 1u) : ((gta >> 5) & 1u));
-            rowB[p2] = 2u * (uint32_t)p2 + (end_min_ref ? (gtb & 1u) : ((gtb >> 5) & 1u));
+            // GT = 2 t + (row odd), or 2 KW * (t / KW) + KW * (row odd) + t % KW under the other A.3 rule
+            const uint32_t ta = end_min_ref ? gta >> 1 : ((gta >> KLOW) << KB) | (gta & (uint32_t)(KW - 1));
+            const uint32_t tb = end_min_ref ? gtb >> 1 : ((gtb >> KLOW) << KB) | (gtb & (uint32_t)(KW - 1));
+            rowA[p2] = 2u * (uint32_t)p2 + (end_min_ref ? (gta & 1u) : ((gta >> KB) & 1u));
+            rowB[p2] = 2u * (uint32_t)p2 + (end_min_ref ? (gtb & 1u) : ((gtb >> KB) & 1u));
             bestA[p2] = ha ? ((ha << 16) | (0xffffu - ta)) : 0u;
             bestB[p2] = hb ? ((hb << 16) | (0xffffu - tb)) : 0u;
         }

@@ -18,8 +18,13 @@ base = os.path.join(root, "gpurun_out", "prof_" + tag)
 calib = os.path.join(root, "gpurun_out", "prof_calib")
 
 
+def newest(pattern):
+    # gpurun merges every call's outputs into the same directories: take the latest run's file, not an earlier one's
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def load(d):
-    f = glob.glob(os.path.join(calib if d.startswith("calib") else base, d, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(calib if d.startswith("calib") else base, d, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -50,8 +55,8 @@ for k in fetch:
         e["valu_busy_frac"] = s["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)  # quad-cycles; 1024 SIMDs
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(root, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
-shutil.copy(glob.glob(os.path.join(base, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(root, "profiles", tag + "_kernel_stats_1slot.csv"))
-shutil.copy(glob.glob(os.path.join(base, "stats2", "*", "*_kernel_stats.csv"))[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(base, "stats", "*", "*_kernel_stats.csv")), os.path.join(root, "profiles", tag + "_kernel_stats_1slot.csv"))
+shutil.copy(newest(os.path.join(base, "stats2", "*", "*_kernel_stats.csv")), os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(base, "bench_under_rocprof.json"), os.path.join(root, "profiles", tag + "_bench_under_rocprof.json"))
 for d, f in (("fetch", f1), ("write", f2), ("calib_fetch", f3), ("calib_write", f4), ("sq", f5)):
     shutil.copy(f, os.path.join(root, "profiles", "%s_pmc_%s.csv" % (tag, d)))
