@@ -23,13 +23,14 @@ public:
     static constexpr size_t bound(size_t n) { return n + 16; }
 
     // effort: 1 = greedy parse that stops probing early in match-free stretches, 2 = lazy parse with a milder skip
-    // (default: output no larger than zlib level 6's on BAM payloads), 3 = lazy parse probing every position,
-    // 4 = lazy parse over 4 candidates per hash.  skip_after / skip_cap >= 0 override the effort's skip rule (parse()).
+    // (default: output smaller than zlib level 6's on BAM payloads), both over the 16-bit one-candidate table
+    // (parse_fast); 3 = lazy parse probing every position, 4 = lazy parse over 4 candidates per hash (parse).
+    // skip_after / skip_cap >= 0 override the effort's skip rule.
     static constexpr int MAX_EFFORT = 4;
     explicit FastDeflate(int effort = 2, int skip_after = -1, int skip_cap = -1) : effort_(std::max(1, std::min(MAX_EFFORT, effort))) {
         lazy_ = effort_ >= 2;
-        skip_after_ = effort_ == 1 ? 4 : effort_ == 2 ? 16 : 0;
-        skip_cap_ = effort_ == 1 ? 15 : effort_ == 2 ? 7 : 0;
+        skip_after_ = effort_ == 1 ? 16 : effort_ == 2 ? 48 : 0;
+        skip_cap_ = effort_ <= 2 ? 7 : 0;
         if (skip_after >= 0) skip_after_ = (size_t)skip_after;
         if (skip_cap >= 0) skip_cap_ = (size_t)skip_cap;
         init_static();
@@ -41,7 +42,8 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
 #endif
         if (effort_ >= 4) parse<4, 15>(in, n);
-        else parse<1, 14>(in, n);
+        else if (effort_ == 3) parse<1, 14>(in, n);
+        else parse_fast<14>(in, n);
 #ifdef FADE_DEFLATE_TIMING
         const auto t1 = std::chrono::steady_clock::now();
         const size_t r = encode(in, n, out);
@@ -67,10 +69,10 @@ private:
     //   1 way,  14 bits: 0.5701 / 0.4082 of the input at 70 MB/s       (effort 3)
     //   4 ways, 15 bits: 0.5684 / 0.40   at 29 MB/s                    (effort 4)
     //   zlib level 6   : 0.5908 / 0.3957 at 8-14 MB/s on the same core
-    // The parse is 78 % of a block's time and nearly all of it is probes that find nothing, so efforts 1 and 2 skip
-    // (see the literal branch of parse()).  On an idle core of the GPU box's host, uniform qualities
-    // (tools/deflate_where.sh): effort 1 364 MB/s 0.6020, effort 2 264 MB/s 0.5907, effort 3 201 MB/s 0.5709,
-    // effort 4 86 MB/s 0.5691; zlib level 1 88 MB/s 0.6123, zlib level 6 40 MB/s 0.5915.
+    // The parse is 78 % of a block's time and nearly all of it is probes that find nothing, so efforts 1 and 2 probe
+    // four positions per round and skip ahead in match-free stretches (parse_fast).  On an idle core of the GPU box's
+    // host, uniform qualities (tools/deflate_where.sh): effort 1 564 MB/s 0.5954, effort 2 462 MB/s 0.5729, effort 3
+    // 201 MB/s 0.5709, effort 4 86 MB/s 0.5691; zlib level 1 88 MB/s 0.6123, zlib level 6 40 MB/s 0.5915.
     static constexpr int MIN_MATCH = 5, MAX_MATCH = 258;
     static constexpr uint64_t MASK5 = 0xffffffffffull;
     static inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -174,6 +176,122 @@ private:
         }
         count_literals();
         lfreq_[256] = 1;  // end of block
+    }
+
+    // ---- efforts 1 and 2: one candidate per hash in a 16-bit table (32 KB: stays in L1), four positions probed per
+    // round from ONE 8-byte load (its four 5-byte windows), one branch per round while nothing is found.  An empty
+    // table entry is position 0, a candidate like any other: the 5-byte compare and the distance test (0 < dist <=
+    // 32768 as one unsigned compare) decide.  The positions of a round do not see each other's insertions, so a match
+    // at distance < 4 is found one round late (a run loses at most 3 bytes of its first match).
+    template <int HB> inline int find16(const uint8_t *in, size_t n, size_t p, int &dist_out) {
+        const uint64_t v = load64(in + p) & MASK5;
+        const uint32_t h = hash5<HB>(v);
+        const size_t c = tab16_[h];
+        tab16_[h] = (uint16_t)p;
+        dist_out = 0;
+        if (__builtin_expect(((load64(in + c) & MASK5) != v) | (p - c - 1 >= 32768), 1)) return 0;
+        const int l = match_len(in + c, in + p, (int)std::min<size_t>(MAX_MATCH, n - p));
+        if (!worth(l, (int)(p - c))) return 0;
+        dist_out = (int)(p - c);
+        return l;
+    }
+    template <int HB> void parse_fast(const uint8_t *in, size_t n) {
+        memset(tab16_, 0, sizeof(uint16_t) << HB);
+        memset(lfreq_, 0, sizeof lfreq_);
+        memset(dfreq_, 0, sizeof dfreq_);
+        memset(lhist_, 0, sizeof lhist_);
+        nsym_ = 0;
+        extra_bits_ = 0;
+        const size_t hash_end = n >= 8 ? n - 7 : 0;  // positions < hash_end can be hashed
+        size_t p = 0, miss = 0, lit_start = 0;  // lit_start: first position after the last match
+        while (p < n) {
+            // rounds of four probes while nothing is found
+            while (p + 4 <= hash_end) {
+                const uint64_t w = load64(in + p);
+                const uint64_t v0 = w & MASK5, v1 = (w >> 8) & MASK5, v2 = (w >> 16) & MASK5, v3 = w >> 24;
+                const uint32_t h0 = hash5<HB>(v0), h1 = hash5<HB>(v1), h2 = hash5<HB>(v2), h3 = hash5<HB>(v3);
+                const size_t c0 = tab16_[h0], c1 = tab16_[h1], c2 = tab16_[h2], c3 = tab16_[h3];
+                const uint32_t hit = (uint32_t)(((load64(in + c0) & MASK5) == v0) & (p - c0 - 1 < 32768)) |
+                                     (uint32_t)(((load64(in + c1) & MASK5) == v1) & (p - c1 < 32768)) << 1 |
+                                     (uint32_t)(((load64(in + c2) & MASK5) == v2) & (p + 1 - c2 < 32768)) << 2 |
+                                     (uint32_t)(((load64(in + c3) & MASK5) == v3) & (p + 2 - c3 < 32768)) << 3;
+                if (__builtin_expect(hit != 0, 0)) {
+                    // the positions before the first hit are literals; the hit itself goes through find16 below
+                    const int first = __builtin_ctz(hit);
+                    const uint32_t hs[3] = {h0, h1, h2};
+                    for (int j = 0; j < first; j++) {
+                        tab16_[hs[j]] = (uint16_t)(p + (size_t)j);
+                        put_literal_counted(in[p + (size_t)j], p + (size_t)j);
+                    }
+                    p += (size_t)first;
+                    break;
+                }
+                tab16_[h0] = (uint16_t)p;
+                tab16_[h1] = (uint16_t)(p + 1);
+                tab16_[h2] = (uint16_t)(p + 2);
+                tab16_[h3] = (uint16_t)(p + 3);
+                // four literals: symbols as one 64-bit store, one histogram per position of the round
+                const uint64_t s4 = (w & 0xff) | ((w & 0xff00) << 8) | ((w & 0xff0000) << 16) | ((w & 0xff000000ull) << 24);
+                memcpy(sym_ + nsym_, &s4, 8);
+                nsym_ += 4;
+                lhist_[p & 3][w & 0xff]++;
+                lhist_[(p + 1) & 3][(w >> 8) & 0xff]++;
+                lhist_[(p + 2) & 3][(w >> 16) & 0xff]++;
+                lhist_[(p + 3) & 3][(w >> 24) & 0xff]++;
+                p += 4;
+                if (skip_after_) {
+                    // Qualities and packed bases: nothing to find for hundreds of bytes.  After skip_after_ probes in
+                    // vain every probe is followed by (misses / skip_after_, at most skip_cap_) literals that are
+                    // neither probed nor entered into the table.
+                    miss += 4;
+                    size_t k = 4 * std::min<size_t>(miss / skip_after_, skip_cap_);
+                    k = std::min(k, n - p);
+                    for (size_t j = 0; j < k; j++) put_literal_counted(in[p + j], p + j);
+                    p += k;
+                }
+            }
+            if (p >= n) break;
+            int len = 0, dist = 0;
+            if (p < hash_end) len = find16<HB>(in, n, p, dist);
+            if (len >= MIN_MATCH) {
+                miss = 0;
+                bool probed = false;  // whether p + 1 is already in the table
+                if (lazy_) {
+                    // defer while the next position starts a strictly longer match
+                    while (len < 40 && p + 1 < hash_end) {
+                        int d2 = 0;
+                        const int l2 = find16<HB>(in, n, p + 1, d2);
+                        if (l2 <= len) { probed = true; break; }
+                        put_literal_counted(in[p], p);
+                        p++;
+                        len = l2;
+                        dist = d2;
+                    }
+                }
+                // catch up: a probe that landed inside a repeat (after skipped positions) extends the match backwards
+                // over the literals already emitted since the last match
+                size_t back = 0;
+                while (p - back > lit_start && p - back > (size_t)dist && len + (int)back < MAX_MATCH &&
+                       in[p - back - 1] == in[p - back - 1 - (size_t)dist]) back++;
+                for (size_t j = 1; j <= back; j++) lhist_[(p - j) & 3][in[p - j]]--;
+                nsym_ -= back;
+                put_match(len + (int)back, dist);
+                const size_t stop = std::min(p + (size_t)len, hash_end);
+                for (size_t q = p + 1 + (probed ? 1 : 0); q < stop; q++) tab16_[hash5<HB>(load64(in + q) & MASK5)] = (uint16_t)q;
+                p += (size_t)len;
+                lit_start = p;
+            } else {
+                put_literal_counted(in[p], p);
+                p++;
+                miss++;
+            }
+        }
+        for (int c = 0; c < 256; c++) lfreq_[c] = lhist_[0][c] + lhist_[1][c] + lhist_[2][c] + lhist_[3][c];
+        lfreq_[256] = 1;  // end of block
+    }
+    inline void put_literal_counted(uint8_t c, size_t pos) {  // the histogram is chosen by position, so that catch-up can undo it
+        sym_[nsym_++] = c;
+        lhist_[pos & 3][c]++;
     }
 
     // symbol stream: a literal is its byte value; a match is 0x8000 | length followed by distance - 1.
@@ -334,14 +452,19 @@ private:
                 cnt -= 32;
             }
         }
-        inline uint8_t *finish() {
-            while (cnt > 0) {
+        // whole bytes out; the partial byte (tail_bits < 8 bits) stays in `tail` for the caller to continue from
+        uint64_t tail = 0;
+        int tail_bits = 0;
+        inline void finish() {
+            while (cnt >= 8) {
                 *p++ = (uint8_t)buf;
                 buf >>= 8;
                 cnt -= 8;
             }
+            tail = buf;
+            tail_bits = cnt;
+            buf = 0;
             cnt = 0;
-            return p;
         }
     };
 
@@ -448,28 +571,67 @@ private:
             assign_codes(dlen, 32, dcode);
             ll = llen; lc = lcode; dl = dlen; dc = dcode;
         }
-        for (size_t i = 0; i < nsym_; i++) {
+        bw.finish();  // the header, to a byte boundary at most 7 bits short: the symbol loop has its own 64-bit writer
+        // Symbols: code and length of a literal / length symbol come from one 32-bit table entry; the bit buffer is
+        // flushed without a branch (8 bytes stored, the pointer advanced by the whole bytes), after every two literals
+        // (<= 30 bits) or one match (<= 48 bits) on top of the <= 7 bits left over.
+        uint32_t lt[288];
+        for (int i = 0; i < 288; i++) lt[i] = (uint32_t)lc[i] | ((uint32_t)ll[i] << 16);
+        uint8_t *op = bw.p;
+        uint64_t buf = bw.tail;
+        int cnt = bw.tail_bits;
+        auto flush = [&]() {
+            memcpy(op, &buf, 8);
+            op += cnt >> 3;
+            buf >>= (cnt & ~7);
+            cnt &= 7;
+        };
+        sym_[nsym_] = 0x8000u | 0x7fffu;  // sentinel: stops the literal pairing at the end
+        for (size_t i = 0; i < nsym_;) {
             const uint32_t v = sym_[i];
             if (!(v & 0x8000u)) {
-                bw.add(lc[v], ll[v]);
+                const uint32_t e0 = lt[v];
+                buf |= (uint64_t)(e0 & 0xffffu) << cnt;
+                cnt += (int)(e0 >> 16);
+                i++;
+                const uint32_t v1 = sym_[i];
+                if (!(v1 & 0x8000u)) {
+                    const uint32_t e1 = lt[v1];
+                    buf |= (uint64_t)(e1 & 0xffffu) << cnt;
+                    cnt += (int)(e1 >> 16);
+                    i++;
+                }
+                flush();
             } else {
-                const int len = (int)(v & 0x7fffu), dist = (int)sym_[++i] + 1;
+                const int len = (int)(v & 0x7fffu), dist = (int)sym_[i + 1] + 1;
+                i += 2;
                 const int ls = len_sym_[len];
-                bw.add(lc[257 + ls], ll[257 + ls]);
-                if (len_xbits_[ls]) bw.add((uint32_t)(len - len_base_[ls]), len_xbits_[ls]);
+                const uint32_t e = lt[257 + ls];
+                buf |= (uint64_t)(e & 0xffffu) << cnt;
+                cnt += (int)(e >> 16);
+                buf |= (uint64_t)(uint32_t)(len - len_base_[ls]) << cnt;
+                cnt += len_xbits_[ls];
                 const int ds = dist_sym(dist);
-                bw.add(dc[ds], dl[ds]);
-                if (dist_xbits_[ds]) bw.add((uint32_t)(dist - dist_base_[ds]), dist_xbits_[ds]);
+                buf |= (uint64_t)dc[ds] << cnt;
+                cnt += dl[ds];
+                buf |= (uint64_t)(uint32_t)(dist - dist_base_[ds]) << cnt;
+                cnt += dist_xbits_[ds];
+                flush();
             }
         }
-        bw.add(lc[256], ll[256]);
-        return (size_t)(bw.finish() - out);
+        buf |= (uint64_t)lc[256] << cnt;
+        cnt += ll[256];
+        flush();
+        if (cnt) *op++ = (uint8_t)buf;
+        return (size_t)(op - out);
     }
 
     size_t skip_after_ = 0, skip_cap_ = 0;  // 0: every position is probed
     int effort_;
     bool lazy_;
     uint64_t tab_[1 << 15];
+    uint16_t tab16_[1 << 14];
+    uint32_t lhist_[4][256];
     uint16_t sym_[65536 + 8];
     size_t nsym_ = 0;
     uint64_t extra_bits_ = 0;

@@ -245,7 +245,7 @@ static void pack_chunk_t(Chunk &c, Pool &pool, BlockPool &blocks, const Get &get
             r.span = std::max(r.span, cigar_ref_len(rec));
         }
         rg[t + 1] = r;
-    });
+    }, CPU_PACK);
     int64_t span = 1;
     for (size_t t = 1; t <= nt; t++) {
         span = std::max(span, rg[t].span);
@@ -282,7 +282,7 @@ static void pack_chunk_t(Chunk &c, Pool &pool, BlockPool &blocks, const Get &get
             nq += sb;
             k++;
         }
-    });
+    }, CPU_PACK);
     coff[ns] = (uint32_t)ncig;
     soff[ns] = (uint32_t)nseq;
     c.b.n_skipped = (int32_t)(n - ns);
@@ -376,7 +376,7 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
         pool.parallel_for(nt, [&](size_t t) {
             for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++)
                 tag_owned_record(c.recs[i], rs[i], art_of[i] >= 0 ? &c.art[(size_t)art_of[i]] : nullptr, h);
-        });
+        }, CPU_TAGS);
         return;
     }
     // Records framed in place: the new tags become a suffix behind the record's bytes (htslib appends an absent tag).
@@ -414,7 +414,7 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
             }
             o.sfx_off[i + 1] = (uint32_t)len;
         }
-    });
+    }, CPU_TAGS);
     for (auto &v : owned_t)
         for (auto &e : v) o.owned.push_back(std::move(e));
     for (size_t i = 0; i < n; i++) o.sfx_off[i + 1] += o.sfx_off[i];
@@ -435,7 +435,7 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
                 }
             }
         }
-    });
+    }, CPU_TAGS);
 }
 
 struct StageClock {
@@ -724,6 +724,23 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             fprintf(stderr, "[timing] total %.3f s: fasta %.3f, create+genome upload %.3f | reader stage %.3f | pack %.3f, "
                             "submit %.3f, results %.3f | writer stage: tags %.3f, write %.3f (stages overlap)\n",
                     ck_total.t, ck_fasta.t, ck_upload.t, ck_read.t, ck_pack.t, ck_submit.t, ck_collect.t, ck_tags.t, ck_write.t);
+        if (o.timing) {  // core-seconds of the pools' work by kind (thread CPU time)
+            std::string line = "[timing] pool core-seconds:";
+            double sum = 0;
+            for (int k = 0; k < CPU_KINDS; k++) {
+                const double sec = (double)cpu_meter()[k].load() * 1e-9;
+                if (sec < 0.0005) continue;
+                char buf[64];
+                snprintf(buf, sizeof buf, " %s %.3f,", cpu_kind_name(k), sec);
+                line += buf;
+                sum += sec;
+            }
+            fprintf(stderr, "%s total %.3f\n", line.c_str(), sum);
+            const ReadProf &rp = read_prof();
+            if (reader.is_bam())
+                fprintf(stderr, "[timing] BAM reader thread: wait for file bytes %.3f, scan %.3f, inflate (parallel) %.3f, frame %.3f, carry %.3f, "
+                                "layout check (parallel) %.3f\n", rp.wait_io, rp.scan, rp.inflate, rp.frame, rp.carry, rp.layout);
+        }
     } catch (const std::exception &e) {
         fprintf(stderr, "[E::fade annotate] %s\n", e.what());
         return 1;

@@ -10,7 +10,9 @@
 #pragma once
 #include <zlib.h>
 #include <algorithm>
+#include <sys/mman.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -34,6 +36,22 @@
 namespace htsl {
 
 // ------------------------------------------------------------------ small thread pool
+// Thread CPU time of the pools' work by kind (annotate --timing): where the host's core-seconds go.
+enum CpuKind { CPU_INFLATE, CPU_FRAME, CPU_SAM_PARSE, CPU_PACK, CPU_TAGS, CPU_COPY, CPU_DEFLATE, CPU_SAM_FORMAT, CPU_KINDS };
+inline std::atomic<int64_t> *cpu_meter() {
+    static std::atomic<int64_t> ns[CPU_KINDS];
+    return ns;
+}
+inline const char *cpu_kind_name(int k) {
+    static const char *const names[CPU_KINDS] = {"inflate+crc", "frame", "sam parse", "pack", "tags", "copy", "deflate+crc", "sam format"};
+    return names[k];
+}
+inline int64_t thread_cpu_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
+}
+
 class Pool {
 public:
     explicit Pool(int n) : n_(std::max(1, n)) {
@@ -49,14 +67,18 @@ public:
     }
     int size() const { return n_; }
     // fn(i) for i in [0, count), dynamic distribution; returns when all are done
-    void parallel_for(size_t count, const std::function<void(size_t)> &fn) {
+    // kind >= 0: the threads' CPU time inside fn is added to cpu_meter()[kind]
+    void parallel_for(size_t count, const std::function<void(size_t)> &fn, int kind = -1) {
         if (count == 0) return;
         if (n_ == 1 || count == 1) {
+            const int64_t t0 = kind >= 0 ? thread_cpu_ns() : 0;
             for (size_t i = 0; i < count; i++) fn(i);
+            if (kind >= 0) cpu_meter()[kind] += thread_cpu_ns() - t0;
             return;
         }
         {
             std::lock_guard<std::mutex> l(m_);
+            kind_ = kind;
             fn_ = &fn;
             count_ = count;
             next_.store(0);
@@ -72,11 +94,14 @@ public:
 
 private:
     void run() {
+        const int kind = kind_;
+        const int64_t t0 = kind >= 0 ? thread_cpu_ns() : 0;
         for (;;) {
             size_t i = next_.fetch_add(1);
             if (i >= count_) break;
             (*fn_)(i);
         }
+        if (kind >= 0) cpu_meter()[kind] += thread_cpu_ns() - t0;
     }
     void worker(int) {
         uint64_t seen = 0;
@@ -100,6 +125,7 @@ private:
     std::condition_variable cv_, done_;
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t count_ = 0;
+    int kind_ = -1;
     std::atomic<size_t> next_{0};
     int pending_ = 0;
     uint64_t gen_ = 0;
@@ -713,24 +739,68 @@ private:
 
 // Growable byte buffer that does not value-initialise what it grows by (std::vector::resize zero-fills: 0.9 GB per
 // million reads between the compressed and the inflated side of the BGZF reader, on its serial thread).
+// Large buffers are recycled through a small free list: a batch's 75-300 MB of inflated records would otherwise be
+// mapped, page-faulted (by the inflating threads), grown by copying and unmapped once per batch.
 class RawBuf {
 public:
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p_); }
+    ~RawBuf() {
+        if (p_ && cap_ >= kPoolMin) {
+            std::lock_guard<std::mutex> l(pool_mutex());
+            auto &fl = pool_list();
+            if (fl.size() < kPoolMax) {
+                fl.push_back({p_, cap_});
+                return;
+            }
+        }
+        free(p_);
+    }
+    // capacity for n bytes without changing the size (a recycled buffer if one is large enough)
+    void reserve(size_t n) {
+        if (n <= cap_) return;
+        if (!p_ && n >= kPoolMin) {
+            std::lock_guard<std::mutex> l(pool_mutex());
+            auto &fl = pool_list();
+            size_t best = fl.size();
+            for (size_t k = 0; k < fl.size(); k++)
+                if (fl[k].second >= n && (best == fl.size() || fl[k].second < fl[best].second)) best = k;
+            if (best < fl.size()) {
+                p_ = fl[best].first;
+                cap_ = fl[best].second;
+                fl.erase(fl.begin() + (long)best);
+                return;
+            }
+            // none large enough: map afresh (growing a recycled one means moving 100 MB of page tables: 10-25 ms) and
+            // let the smallest go if the list is full
+            if (fl.size() >= kPoolMax) {
+                size_t small = 0;
+                for (size_t k = 1; k < fl.size(); k++)
+                    if (fl[k].second < fl[small].second) small = k;
+                free(fl[small].first);
+                fl.erase(fl.begin() + (long)small);
+            }
+        }
+        const size_t c = std::max(n, cap_ + cap_ / 2);
+        uint8_t *q = (uint8_t *)realloc(p_, c);
+        if (!q) throw std::bad_alloc();
+        p_ = q;
+        cap_ = c;
+        if (c >= kPoolMin) {
+            // 2 MB pages where the kernel offers them on request: 512x fewer faults for the threads that fill the buffer
+            // and as many fewer pages to give back
+            const uintptr_t lo = ((uintptr_t)q + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)q + c) & ~(uintptr_t)4095;
+            if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+        }
+    }
+    size_t capacity() const { return cap_; }
     uint8_t *data() { return p_; }
     const uint8_t *data() const { return p_; }
     size_t size() const { return n_; }
     void clear() { n_ = 0; }
     void resize(size_t n) {
-        if (n > cap_) {
-            const size_t c = std::max(n, cap_ + cap_ / 2);
-            uint8_t *q = (uint8_t *)realloc(p_, c);
-            if (!q) throw std::bad_alloc();
-            p_ = q;
-            cap_ = c;
-        }
+        if (n > cap_) reserve(n_ ? std::max(n, cap_ + cap_ / 2) : n);
         n_ = n;
     }
     void drop_front(size_t k) {  // keep [k, size)
@@ -739,9 +809,29 @@ public:
     }
 
 private:
+    static constexpr size_t kPoolMin = (size_t)8 << 20, kPoolMax = 12;
+    static std::mutex &pool_mutex() {
+        static auto *m = new std::mutex();
+        return *m;
+    }
+    static std::vector<std::pair<uint8_t *, size_t>> &pool_list() {
+        // never destroyed: a RawBuf may outlive every other static, and what the list holds at exit goes back with the process
+        static auto *v = new std::vector<std::pair<uint8_t *, size_t>>();
+        return *v;
+    }
     uint8_t *p_ = nullptr;
     size_t n_ = 0, cap_ = 0;
 };
+
+// wall time of the BAM reader's serial thread by step (annotate --timing)
+struct ReadProf {
+    double wait_io = 0, scan = 0, inflate = 0, frame = 0, carry = 0, layout = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+inline ReadProf &read_prof() {
+    static ReadProf p;
+    return p;
+}
 
 // Inflates BGZF blocks in parallel batches and serves the uncompressed byte stream, either copied out (read) or
 // in place (data / avail / consume / more) so that the BAM reader can frame records without a per-record copy loop.
@@ -780,84 +870,56 @@ public:
         out_.clear();
         pos_ = 0;
     }
-    // inflate the next batch of blocks onto the end of `dst` (the reader's own buffer or a RecordBlock's)
-    bool inflate_append(RawBuf &dst) {
-        // The compressed side is double-buffered: while the blocks of one gulp inflate (in parallel), a helper thread
-        // reads the next gulp from the file behind the bytes carried over (the block the previous gulp ended in).
-        RawBuf &comp_ = cbuf_[cur_];
-        if (!primed_) {
-            comp_.clear();
-            fetch(comp_);
-            primed_ = true;
-        } else if (pending_.valid()) {
-            pending_.get();
-        }
-        offs_.clear();
-        size_t o = 0;
-        const size_t have = comp_.size();
-        while (o + 18 <= have) {
-            const uint8_t *h = comp_.data() + o;
-            if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
-            uint16_t xlen;
-            memcpy(&xlen, h + 10, 2);
-            if (xlen < 6 || h[12] != 'B' || h[13] != 'C') throw std::runtime_error("BGZF block lacks the BC subfield first");
-            uint16_t bs;
-            memcpy(&bs, h + 16, 2);
-            const size_t bsize = (size_t)bs + 1;
-            // header (12 + XLEN) + at least an empty deflate stream + CRC32 + ISIZE: a smaller BSIZE would put the
-            // trailer reads below in front of the block
-            if (bsize < 12 + (size_t)xlen + 8) throw std::runtime_error("corrupt BGZF block (BSIZE smaller than its own header and trailer)");
-            if (o + bsize > have) break;
-            offs_.push_back({o, bsize, (size_t)xlen});
-            o += bsize;
-        }
-        if (offs_.empty()) {
-            if (have && eof_) throw std::runtime_error("truncated BGZF block");
-            if (eof_) return false;
-        }
-        // the incomplete block at the end opens the other buffer, and the next gulp is read behind it meanwhile
-        RawBuf &next = cbuf_[cur_ ^ 1];
-        next.resize(have - o);
-        if (have - o) memcpy(next.data(), comp_.data() + o, have - o);
-        if (!eof_) pending_ = std::async(std::launch::async, [this, &next] { fetch(next); });
-        cur_ ^= 1;
-        if (offs_.empty()) return inflate_append(dst);  // a gulp that ended inside its first block (cannot repeat: the gulp is 16 MiB)
-        const size_t base = dst.size();
-        std::vector<size_t> isz(offs_.size()), ooff(offs_.size() + 1, 0);
-        for (size_t k = 0; k < offs_.size(); k++) {
+    // Inflates the next blocks onto the end of `dst` (the reader's own buffer or a RecordBlock's): whole blocks of the
+    // current gulp until about `want` bytes have come out (all of the gulp's by default).  false at end of file.
+    bool inflate_append(RawBuf &dst, size_t want = (size_t)-1) {
+        while (blk_next_ == offs_.size())
+            if (!open_gulp()) return false;
+        const RawBuf &comp_ = cbuf_[cur_ ^ 1];  // (open_gulp flipped cur_: the gulp being served is the other buffer)
+        const double t1 = ReadProf::now();
+        const size_t first = blk_next_, base = dst.size();
+        std::vector<size_t> isz, ooff(1, 0);
+        size_t last = first;
+        while (last < offs_.size() && ooff.back() < want) {
             uint32_t v;
-            memcpy(&v, comp_.data() + offs_[k].off + offs_[k].size - 4, 4);
+            memcpy(&v, comp_.data() + offs_[last].off + offs_[last].size - 4, 4);
             if (v > 65536) throw std::runtime_error("corrupt BGZF block (ISIZE beyond 64 KiB)");  // the format's limit: 512 blocks cannot ask for more than 32 MiB
-            isz[k] = v;
-            ooff[k + 1] = ooff[k] + v;
+            isz.push_back(v);
+            ooff.push_back(ooff.back() + v);
+            last++;
         }
+        blk_next_ = last;
         dst.resize(base + ooff.back());
-        pool_->parallel_for(offs_.size(), [&](size_t k) {
-            if (isz[k] == 0) return;
+        const double t0 = ReadProf::now();
+        read_prof().scan += t0 - t1;
+        pool_->parallel_for(last - first, [&](size_t j) {
+            const size_t k = first + j;
+            if (isz[j] == 0) return;
             const size_t hl = 12 + offs_[k].xlen;
             if (offs_[k].size < hl + 8) { bad_ = true; return; }
             if (!bgzf_use_zlib()) {
                 static thread_local std::unique_ptr<FastInflate> fi;
                 if (!fi) fi.reset(new FastInflate());
-                if (!fi->inflate(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, dst.data() + base + ooff[k], isz[k]))
+                if (!fi->inflate(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, dst.data() + base + ooff[j], isz[j]))
                     bad_ = true;
             } else {
                 z_stream zs;
                 memset(&zs, 0, sizeof zs);
                 if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
-                zs.next_in = comp_.data() + offs_[k].off + hl;
+                zs.next_in = const_cast<uint8_t *>(comp_.data()) + offs_[k].off + hl;
                 zs.avail_in = (uInt)(offs_[k].size - hl - 8);
-                zs.next_out = dst.data() + base + ooff[k];
-                zs.avail_out = (uInt)isz[k];
+                zs.next_out = dst.data() + base + ooff[j];
+                zs.avail_out = (uInt)isz[j];
                 const int rc = inflate(&zs, Z_FINISH);
                 inflateEnd(&zs);
-                if (rc != Z_STREAM_END || zs.total_out != isz[k]) bad_ = true;
+                if (rc != Z_STREAM_END || zs.total_out != isz[j]) bad_ = true;
             }
             // the block's CRC32 (RFC 1952 trailer), as htslib checks it
-            uint32_t want;
-            memcpy(&want, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
-            if (crc32_fast(0, dst.data() + base + ooff[k], isz[k]) != want) bad_ = true;
-        });
+            uint32_t crc;
+            memcpy(&crc, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
+            if (crc32_fast(0, dst.data() + base + ooff[j], isz[j]) != crc) bad_ = true;
+        }, CPU_INFLATE);
+        read_prof().inflate += ReadProf::now() - t0;
         if (bad_) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
         return true;
     }
@@ -868,6 +930,57 @@ public:
 
 private:
     struct Blk { size_t off, size, xlen; };
+    // Makes the next gulp of compressed bytes the current one: waits for its read, finds its whole blocks (offs_), moves
+    // the incomplete block at its end to the other buffer and starts reading the following gulp behind it.  The
+    // compressed side is double-buffered: while the blocks of one gulp inflate, a helper thread reads the next.
+    // false at end of file.
+    bool open_gulp() {
+        for (;;) {
+            RawBuf &comp_ = cbuf_[cur_];
+            const double t0 = ReadProf::now();
+            if (!primed_) {
+                comp_.clear();
+                fetch(comp_);
+                primed_ = true;
+            } else if (pending_.valid()) {
+                pending_.get();
+            }
+            const double t1 = ReadProf::now();
+            read_prof().wait_io += t1 - t0;
+            offs_.clear();
+            blk_next_ = 0;
+            size_t o = 0;
+            const size_t have = comp_.size();
+            while (o + 18 <= have) {
+                const uint8_t *h = comp_.data() + o;
+                if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
+                uint16_t xlen;
+                memcpy(&xlen, h + 10, 2);
+                if (xlen < 6 || h[12] != 'B' || h[13] != 'C') throw std::runtime_error("BGZF block lacks the BC subfield first");
+                uint16_t bs;
+                memcpy(&bs, h + 16, 2);
+                const size_t bsize = (size_t)bs + 1;
+                // header (12 + XLEN) + at least an empty deflate stream + CRC32 + ISIZE: a smaller BSIZE would put the
+                // trailer reads in front of the block
+                if (bsize < 12 + (size_t)xlen + 8) throw std::runtime_error("corrupt BGZF block (BSIZE smaller than its own header and trailer)");
+                if (o + bsize > have) break;
+                offs_.push_back({o, bsize, (size_t)xlen});
+                o += bsize;
+            }
+            if (offs_.empty()) {
+                if (have && eof_) throw std::runtime_error("truncated BGZF block");
+                if (eof_) return false;
+            }
+            // the incomplete block at the end opens the other buffer, and the next gulp is read behind it meanwhile
+            RawBuf &next = cbuf_[cur_ ^ 1];
+            next.resize(have - o);
+            if (have - o) memcpy(next.data(), comp_.data() + o, have - o);
+            if (!eof_) pending_ = std::async(std::launch::async, [this, &next] { fetch(next); });
+            cur_ ^= 1;
+            read_prof().scan += ReadProf::now() - t1;
+            if (!offs_.empty()) return true;  // (a gulp that ended inside its first block: take the next; cannot repeat, a gulp is 16 MiB)
+        }
+    }
     // appends up to a gulp of file bytes to b; sets eof_ when the file ran out
     void fetch(RawBuf &b) {
         const size_t kGulp = (size_t)16 << 20, o = b.size();
@@ -883,7 +996,8 @@ private:
     bool primed_ = false;
     std::atomic<bool> eof_{false};
     std::future<void> pending_;
-    std::vector<Blk> offs_;
+    std::vector<Blk> offs_;  // the whole blocks of the gulp being served
+    size_t blk_next_ = 0;    // ... and the first of them not yet inflated
     size_t pos_ = 0;
     std::atomic<bool> bad_{false};
 };
@@ -925,17 +1039,26 @@ public:
         blk.buf.clear();
         blk.off.clear();
         blk.len.clear();
+        blk.off.reserve(max_n);
+        blk.len.reserve(max_n);
         if (!block_mode_) {  // bytes inflated while the header was read
             bgzf_->take_rest(carry_);
             block_mode_ = true;
         }
+        const double tc0 = ReadProf::now();
+        // room for what the previous batch took (+ a gulp): the buffer is then recycled or mapped once, not grown by copying
+        // (rounded up generously: batches of a file differ a little in size, and a recycled buffer must not need growing)
+        const size_t guess = last_block_recs_ ? last_block_bytes_ + last_block_bytes_ / 4 : max_n * 400;
+        blk.buf.reserve(std::max(carry_.size(), ((guess >> 25) + 2) << 25));
         blk.buf.resize(carry_.size());
         if (carry_.size()) memcpy(blk.buf.data(), carry_.data(), carry_.size());
         carry_.clear();
+        read_prof().carry += ReadProf::now() - tc0;
         size_t pos = 0;
         for (;;) {
             const uint8_t *b = blk.buf.data();
             const size_t av = blk.buf.size();
+            const double tf = ReadProf::now();
             while (blk.off.size() < max_n && pos + 4 <= av) {
                 uint32_t bs;
                 memcpy(&bs, b + pos, 4);
@@ -945,23 +1068,45 @@ public:
                 blk.off.push_back((uint32_t)(pos + 4));
                 blk.len.push_back(bs);
                 pos += 4 + (size_t)bs;
+                // The chain of block_size fields is serial and every link sits in a line another core just wrote (the
+                // inflater): ~50 ns each.  Records of a file are of similar size, so the links 6 and 7 records ahead
+                // are near pos + 6 * (4 + bs): fetch those lines now.
+                const size_t ahead = pos + 6 * (4 + (size_t)bs);
+                if (ahead + 384 < av) {
+                    __builtin_prefetch(b + ahead);
+                    __builtin_prefetch(b + ahead + 64);
+                    __builtin_prefetch(b + ahead + 4 + (size_t)bs);
+                    __builtin_prefetch(b + ahead + 4 + (size_t)bs + 64);
+                }
             }
+            read_prof().frame += ReadProf::now() - tf;
             if (blk.off.size() == max_n) break;
-            if (!bgzf_->inflate_append(blk.buf)) {
+            // about as many bytes as the records still missing take (so that little is inflated beyond this batch and has to
+            // be carried over), in pieces large enough to keep every inflating thread busy
+            const size_t have_n = blk.off.size();
+            const size_t per_rec = have_n ? pos / have_n + 1 : (last_block_recs_ ? last_block_bytes_ / last_block_recs_ + 1 : 512);
+            const size_t want = std::max<size_t>((max_n - have_n) * per_rec + ((size_t)64 << 10), (size_t)2 << 20);
+            if (!bgzf_->inflate_append(blk.buf, want)) {
                 if (pos < blk.buf.size()) throw std::runtime_error("truncated BAM record");
                 break;
             }
         }
         // what follows the last framed record belongs to the next block
         const size_t rest = blk.buf.size() - pos;
+        const double tc = ReadProf::now();
         carry_.resize(rest);
         if (rest) memcpy(carry_.data(), blk.buf.data() + pos, rest);
         blk.buf.resize(pos);
+        last_block_bytes_ = std::max(pos, (size_t)1 << 20);
+        last_block_recs_ = blk.off.size();
+        const double tl = ReadProf::now();
+        read_prof().carry += tl - tc;
         const size_t cnt = blk.off.size(), nt = (size_t)pool_->size() * 4;
         pool_->parallel_for(nt, [&](size_t t) {
             for (size_t i = cnt * t / nt; i < cnt * (t + 1) / nt; i++)
                 if (!blk.view(i).layout_ok()) bad_layout_ = true;
-        });
+        }, CPU_FRAME);
+        read_prof().layout += ReadProf::now() - tl;
         if (bad_layout_) throw std::runtime_error("corrupt BAM record (field lengths exceed the record)");
         return cnt;
     }
@@ -1000,7 +1145,7 @@ public:
                         out[base + i].d.assign(b + off[i] + 4, b + off[i] + 4 + bs);
                         if (!out[base + i].layout_ok()) bad_layout_ = true;
                     }
-                });
+                }, CPU_FRAME);
                 if (bad_layout_) throw std::runtime_error("corrupt BAM record (field lengths exceed the record)");
                 bgzf_->consume(o);
                 n += cnt;
@@ -1055,7 +1200,7 @@ public:
                     err = e.what();
                 }
             }
-        });
+        }, CPU_SAM_PARSE);
         if (bad) throw std::runtime_error(err);
         return lines.size();
     }
@@ -1103,6 +1248,7 @@ private:
     std::atomic<bool> bad_layout_{false};
     RawBuf carry_;          // read_block: inflated bytes behind the last framed record
     bool block_mode_ = false;
+    size_t last_block_bytes_ = 0, last_block_recs_ = 0;  // inflated size / records of the previous read_block (the next one reserves as much)
     std::string text_;      // SAM text not yet handed out (complete lines from text_pos_ on)
     size_t text_pos_ = 0;
     bool text_eof_ = false;
@@ -1199,7 +1345,7 @@ public:
                 std::string &s = parts[t];
                 s.reserve((hi - lo) * 400);
                 for (size_t i = lo; i < hi; i++) sam_format(recs[i], hdr_, s);
-            });
+            }, CPU_SAM_FORMAT);
             io_.put(std::move(parts));
             return;
         }
@@ -1216,7 +1362,7 @@ public:
                 memcpy(raw_.data() + off[i], &bs, 4);
                 memcpy(raw_.data() + off[i] + 4, recs[i].d.data(), bs);
             }
-        });
+        }, CPU_COPY);
         flush_blocks(false);
     }
     // What a stage adds to a RecordBlock's records: appended aux bytes per record (sfx_off[i] .. sfx_off[i + 1] of sfx),
@@ -1250,7 +1396,7 @@ public:
                         sam_format(RecView(tmp.data(), tmp.size()), hdr_, s);
                     }
                 }
-            });
+            }, CPU_SAM_FORMAT);
             io_.put(std::move(parts));
             return;
         }
@@ -1272,7 +1418,7 @@ public:
                     if (sfx_len(i)) memcpy(dst + 4 + blk.len[i], sfx_ptr(i), sfx_len(i));
                 }
             }
-        });
+        }, CPU_COPY);
         flush_blocks(false);
     }
     void close() {
@@ -1299,7 +1445,7 @@ private:
             const size_t o = k * B, n = std::min(B, raw_.size() - o);
             outs[k].reserve(n + 64);
             bgzf_compress_block(raw_.data() + o, n, level, outs[k]);
-        });
+        }, CPU_DEFLATE);
         io_.put(std::move(outs));
         const size_t used = std::min(raw_.size(), nblk * B);
         raw_.drop_front(used);

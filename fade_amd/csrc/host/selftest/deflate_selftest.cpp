@@ -93,7 +93,8 @@ static size_t zlib_block(const uint8_t *in, size_t n, int level, uint8_t *out, s
 int main(int argc, char **argv) {
     std::mt19937_64 rng(12345);
     int fails = 0, cases = 0;
-    for (int effort = 1; effort <= FastDeflate::MAX_EFFORT + 1; effort++) {
+    const bool speed_only = getenv("DEFLATE_SPEED_ONLY") != nullptr;  // with a file: efforts 1 and 2 only, no unit cases
+    for (int effort = 1; effort <= FastDeflate::MAX_EFFORT + 1 && !(speed_only && argc > 1); effort++) {
         // (the last round: a skip rule far beyond the shipped ones)
         FastDeflate fd = effort <= FastDeflate::MAX_EFFORT ? FastDeflate(effort) : FastDeflate(2, 1, 300);
         auto check = [&](const std::vector<uint8_t> &v, const char *what) {
@@ -197,15 +198,18 @@ int main(int argc, char **argv) {
         const size_t B = 0xff00;
         std::vector<uint8_t> out(B + 1024);
         const int NE = FastDeflate::MAX_EFFORT;
-        for (int mode = 0; mode < NE + 2; mode++) {  // FastDeflate effort 1..NE, then zlib 1 and zlib 6
-            FastDeflate fd(std::min(mode + 1, NE));
+        for (int mode = 0; mode < (speed_only ? 2 : NE + 2); mode++) {  // FastDeflate effort 1..NE, then zlib 1 and zlib 6
+            int sk_a = -1, sk_c = -1;  // DEFLATE_SKIP=after,cap overrides the effort's skip rule (experiments)
+            if (const char *e = getenv("DEFLATE_SKIP")) sscanf(e, "%d,%d", &sk_a, &sk_c);
+            FastDeflate fd(std::min(mode + 1, NE), sk_a, sk_c);
             size_t total = 0;
             const auto t0 = std::chrono::steady_clock::now();
             for (size_t o = 0; o < data.size(); o += B) {
                 const size_t n = std::min(B, data.size() - o);
                 if (mode < NE) {
                     size_t c = 0;
-                    if (!roundtrip(fd, data.data() + o, n, &c)) return 1;
+                    if (speed_only) c = fd.compress(data.data() + o, n, out.data());
+                    else if (!roundtrip(fd, data.data() + o, n, &c)) return 1;
                     total += c;
                 } else total += zlib_block(data.data() + o, n, mode == NE ? 1 : 6, out.data(), out.size());
             }
@@ -223,7 +227,7 @@ int main(int argc, char **argv) {
                    data.size(), total, (double)total / (double)data.size(), (double)data.size() / dt / 1e6);
         }
     }
-    if (argc > 1) {
+    if (argc > 1 && !speed_only) {
         FILE *f = fopen(argv[1], "rb");
         std::vector<uint8_t> data;
         uint8_t buf[1 << 16];

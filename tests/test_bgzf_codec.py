@@ -67,8 +67,8 @@ def test_writer_payload_is_codec_independent(tmp_path):
         assert b"".join(blocks[k]) == b"".join(blocks["zlib"])
     # binned qualities with runs are the payload where zlib level 6's deep search pays most (on uniform qualities the
     # default effort's output is smaller than zlib's)
-    assert len(outs["fast1"]) <= 1.07 * len(outs["zlib"])
-    assert len(outs["fast"]) <= 1.04 * len(outs["zlib"])
+    assert len(outs["fast1"]) <= 1.06 * len(outs["zlib"])
+    assert len(outs["fast"]) <= 1.035 * len(outs["zlib"])
     assert len(outs["fast3"]) <= 1.04 * len(outs["zlib"])
     assert len(outs["fast4"]) <= 1.015 * len(outs["zlib"])
     # and the BAM it wrote reads back through the BAM reader to the same records

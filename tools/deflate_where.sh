@@ -4,6 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
+mkdir -p gpurun_out; : > gpurun_out/deflate_where.txt
 make -C tools -s sam2bam
 python3 - <<'PY'
 import sys, subprocess, gzip
@@ -19,4 +20,8 @@ with open("/tmp/p.bam", "wb") as fo:
 open("/tmp/p.payload", "wb").write(gzip.decompress(open("/tmp/p.bam", "rb").read()))
 PY
 g++ -O2 -std=c++17 -DFADE_DEFLATE_TIMING -o /tmp/deflate_speed fade_amd/csrc/host/selftest/deflate_selftest.cpp -lz
-/tmp/deflate_speed /tmp/p.payload | tail -12
+/tmp/deflate_speed /tmp/p.payload | tail -12 | tee -a $R/gpurun_out/deflate_where.txt
+# DEFLATE_SKIPS="48,7 64,15": the same with other skip rules (after,cap) for efforts 1 and 2
+for v in ${DEFLATE_SKIPS:-}; do
+  (echo "== skip rule $v"; DEFLATE_SPEED_ONLY=1 DEFLATE_SKIP=$v /tmp/deflate_speed /tmp/p.payload | grep -B1 "effort [12]") | tee -a $R/gpurun_out/deflate_where.txt
+done
