@@ -500,8 +500,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
     } ctx_guard{ctxs, blocks};
     Pool pool(nthreads);
     try {
-        Pool rpool0(nthreads);
-        Reader reader(o.pos[1], &rpool0);   // anno.d:22 (the reader stage inflates / parses on its own pool)
+        Reader reader(o.pos[1], &pool);   // anno.d:22 (every stage's parallel work runs on the one pool)
         // (the reader starts at once: the first batches inflate while the FASTA loads and the genome goes to HBM)
         // Stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack into a pinned block, upload + run (both return
         // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
@@ -601,8 +600,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         fa.seqs.shrink_to_fit();
         // nothing is written to stdout before the GPU path is known to be usable
         const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;  // util.d:65-76
-        Pool wpool0(nthreads);
-        Writer writer(stdout, fmt, hdr, &wpool0);
+        Writer writer(stdout, fmt, hdr, &pool);
 
         StageThreads wstage;  // declared after the writer it uses: joined before the writer goes away
         wstage.unblock = [&] {
@@ -615,7 +613,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             try {
                 while (q_out.pop(c)) {
                     ck_tags.start();
-                    apply_tags(*c, hdr, wpool0);
+                    apply_tags(*c, hdr, pool);
                     ck_tags.stop();
                     ck_write.start();
                     if (c->is_block) writer.write_block(c->blk, c->bout);
@@ -736,6 +734,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 sum += sec;
             }
             fprintf(stderr, "%s total %.3f\n", line.c_str(), sum);
+            fprintf(stderr, "[timing] output thread: %.3f s inside fwrite\n", writer.io_seconds());
             const ReadProf &rp = read_prof();
             if (reader.is_bam())
                 fprintf(stderr, "[timing] BAM reader thread: wait for file bytes %.3f, scan %.3f, inflate (parallel) %.3f, frame %.3f, carry %.3f, "

@@ -52,10 +52,13 @@ inline int64_t thread_cpu_ns() {
     return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
 }
 
+// Worker threads shared by every stage of a pipeline: parallel_for may be called from several threads at once; their
+// jobs are served first come, first served, at task granularity.  (A pool per stage put twice the threads on the cores:
+// every fork-join then waited for whichever of its threads the scheduler had parked for a time slice.)
 class Pool {
 public:
     explicit Pool(int n) : n_(std::max(1, n)) {
-        for (int i = 1; i < n_; i++) th_.emplace_back([this, i] { worker(i); });
+        for (int i = 1; i < n_; i++) th_.emplace_back([this] { worker(); });
     }
     ~Pool() {
         {
@@ -66,7 +69,7 @@ public:
         for (auto &t : th_) t.join();
     }
     int size() const { return n_; }
-    // fn(i) for i in [0, count), dynamic distribution; returns when all are done
+    // fn(i) for i in [0, count), dynamic distribution; the caller works on its own job too and returns when all are done.
     // kind >= 0: the threads' CPU time inside fn is added to cpu_meter()[kind]
     void parallel_for(size_t count, const std::function<void(size_t)> &fn, int kind = -1) {
         if (count == 0) return;
@@ -76,59 +79,66 @@ public:
             if (kind >= 0) cpu_meter()[kind] += thread_cpu_ns() - t0;
             return;
         }
+        Job job;
+        job.fn = &fn;
+        job.count = count;
+        job.kind = kind;
         {
             std::lock_guard<std::mutex> l(m_);
-            kind_ = kind;
-            fn_ = &fn;
-            count_ = count;
-            next_.store(0);
-            pending_ = n_ - 1;
-            gen_++;
+            jobs_.push_back(&job);
         }
         cv_.notify_all();
-        run();
+        work_on(job);
+        // every index is handed out: take the job off the list (no new helpers), then wait for the helpers still inside fn
         std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));
+        job.idle.wait(l, [&] { return job.helpers == 0; });
     }
 
 private:
-    void run() {
-        const int kind = kind_;
-        const int64_t t0 = kind >= 0 ? thread_cpu_ns() : 0;
+    struct Job {
+        const std::function<void(size_t)> *fn = nullptr;
+        size_t count = 0;
+        int kind = -1;
+        std::atomic<size_t> next{0};
+        int helpers = 0;  // workers inside work_on (guarded by m_)
+        std::condition_variable idle;
+    };
+    static void work_on(Job &j) {
+        const int64_t t0 = j.kind >= 0 ? thread_cpu_ns() : 0;
         for (;;) {
-            size_t i = next_.fetch_add(1);
-            if (i >= count_) break;
-            (*fn_)(i);
+            const size_t i = j.next.fetch_add(1);
+            if (i >= j.count) break;
+            (*j.fn)(i);
         }
-        if (kind >= 0) cpu_meter()[kind] += thread_cpu_ns() - t0;
+        if (j.kind >= 0) cpu_meter()[j.kind] += thread_cpu_ns() - t0;
     }
-    void worker(int) {
-        uint64_t seen = 0;
+    void worker() {
+        std::unique_lock<std::mutex> l(m_);
         for (;;) {
-            {
-                std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
-            }
-            run();
-            {
-                std::lock_guard<std::mutex> l(m_);
-                if (--pending_ == 0) done_.notify_all();
-            }
+            Job *j = nullptr;
+            cv_.wait(l, [&] {
+                if (stop_) return true;
+                for (Job *c : jobs_)
+                    if (c->next.load() < c->count) {
+                        j = c;
+                        return true;
+                    }
+                return false;
+            });
+            if (stop_) return;
+            j->helpers++;
+            l.unlock();
+            work_on(*j);
+            l.lock();
+            if (--j->helpers == 0) j->idle.notify_all();
         }
     }
     int n_;
     std::vector<std::thread> th_;
     std::mutex m_;
-    std::condition_variable cv_, done_;
-    const std::function<void(size_t)> *fn_ = nullptr;
-    size_t count_ = 0;
-    int kind_ = -1;
-    std::atomic<size_t> next_{0};
-    int pending_ = 0;
-    uint64_t gen_ = 0;
+    std::condition_variable cv_;
+    std::vector<Job *> jobs_;
     bool stop_ = false;
 };
 
@@ -892,32 +902,53 @@ public:
         dst.resize(base + ooff.back());
         const double t0 = ReadProf::now();
         read_prof().scan += t0 - t1;
-        pool_->parallel_for(last - first, [&](size_t j) {
-            const size_t k = first + j;
-            if (isz[j] == 0) return;
-            const size_t hl = 12 + offs_[k].xlen;
-            if (offs_[k].size < hl + 8) { bad_ = true; return; }
-            if (!bgzf_use_zlib()) {
-                static thread_local std::unique_ptr<FastInflate> fi;
-                if (!fi) fi.reset(new FastInflate());
-                if (!fi->inflate(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, dst.data() + base + ooff[j], isz[j]))
-                    bad_ = true;
-            } else {
-                z_stream zs;
-                memset(&zs, 0, sizeof zs);
-                if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
-                zs.next_in = const_cast<uint8_t *>(comp_.data()) + offs_[k].off + hl;
-                zs.avail_in = (uInt)(offs_[k].size - hl - 8);
-                zs.next_out = dst.data() + base + ooff[j];
-                zs.avail_out = (uInt)isz[j];
-                const int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END || zs.total_out != isz[j]) bad_ = true;
+        // two blocks per task: inflate_fast.hpp decodes a pair in lockstep (their Huffman look-up chains overlap)
+        const size_t m = last - first;
+        pool_->parallel_for((m + 1) / 2, [&](size_t t) {
+            const uint8_t *src[2] = {nullptr, nullptr};
+            size_t slen[2] = {0, 0}, jj[2] = {0, 0};
+            int n = 0;
+            for (size_t j = 2 * t; j < std::min(m, 2 * t + 2); j++) {
+                const size_t k = first + j;
+                if (isz[j] == 0) continue;
+                const size_t hl = 12 + offs_[k].xlen;
+                if (offs_[k].size < hl + 8) { bad_ = true; return; }
+                src[n] = comp_.data() + offs_[k].off + hl;
+                slen[n] = offs_[k].size - hl - 8;
+                jj[n] = j;
+                n++;
             }
-            // the block's CRC32 (RFC 1952 trailer), as htslib checks it
-            uint32_t crc;
-            memcpy(&crc, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
-            if (crc32_fast(0, dst.data() + base + ooff[j], isz[j]) != crc) bad_ = true;
+            if (!bgzf_use_zlib()) {
+                static thread_local std::unique_ptr<FastInflate> fi[2];
+                if (!fi[0]) { fi[0].reset(new FastInflate()); fi[1].reset(new FastInflate()); }
+                if (n == 2) {
+                    if (!FastInflate::inflate2(*fi[0], src[0], slen[0], dst.data() + base + ooff[jj[0]], isz[jj[0]],
+                                               *fi[1], src[1], slen[1], dst.data() + base + ooff[jj[1]], isz[jj[1]]))
+                        bad_ = true;
+                } else if (n == 1) {
+                    if (!fi[0]->inflate(src[0], slen[0], dst.data() + base + ooff[jj[0]], isz[jj[0]])) bad_ = true;
+                }
+            } else {
+                for (int q = 0; q < n; q++) {
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2");
+                    zs.next_in = const_cast<uint8_t *>(src[q]);
+                    zs.avail_in = (uInt)slen[q];
+                    zs.next_out = dst.data() + base + ooff[jj[q]];
+                    zs.avail_out = (uInt)isz[jj[q]];
+                    const int rc = inflate(&zs, Z_FINISH);
+                    inflateEnd(&zs);
+                    if (rc != Z_STREAM_END || zs.total_out != isz[jj[q]]) bad_ = true;
+                }
+            }
+            // the blocks' CRC32 (RFC 1952 trailer), as htslib checks it
+            for (int q = 0; q < n; q++) {
+                const size_t k = first + jj[q];
+                uint32_t crc;
+                memcpy(&crc, comp_.data() + offs_[k].off + offs_[k].size - 8, 4);
+                if (crc32_fast(0, dst.data() + base + ooff[jj[q]], isz[jj[q]]) != crc) bad_ = true;
+            }
         }, CPU_INFLATE);
         read_prof().inflate += ReadProf::now() - t0;
         if (bad_) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
@@ -1286,6 +1317,7 @@ public:
         fflush(f_);
     }
     bool failed() const { return failed_; }
+    double busy_seconds() const { return busy_; }  // inside fwrite (valid after finish())
 
 private:
     void run() {
@@ -1299,8 +1331,10 @@ private:
                 q_.pop_front();
                 room_.notify_one();
             }
+            const double t0 = ReadProf::now();
             for (auto &o : b)
                 if (!o.empty() && fwrite(o.data(), 1, o.size(), f_) != o.size()) failed_ = true;
+            busy_ += ReadProf::now() - t0;
         }
     }
     FILE *f_;
@@ -1309,6 +1343,7 @@ private:
     std::deque<std::vector<std::vector<uint8_t>>> q_;
     bool done_ = false;
     std::atomic<bool> failed_{false};
+    double busy_ = 0;
     std::thread th_;
 };
 
@@ -1421,6 +1456,7 @@ public:
         }, CPU_COPY);
         flush_blocks(false);
     }
+    double io_seconds() const { return io_.busy_seconds(); }
     void close() {
         if (closed_) return;
         closed_ = true;

@@ -17,56 +17,92 @@ class FastInflate {
 public:
     // Decodes one DEFLATE stream into exactly out_len bytes.  false: malformed stream or size mismatch.
     bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) {
+        begin(in, in_len, out, out_len);
+        for (;;) {
+            const int r = next_block();
+            if (r < 0) return false;
+            if (r == 0) return op_ == oend_;
+            if (!decode_block()) return false;
+        }
+    }
+
+    // Two independent streams at once (two BGZF blocks).  Huffman decoding is a chain of dependent table look-ups
+    // (shift, mask, load: ~8 cycles per symbol whatever the core's width); while both streams are inside a Huffman block
+    // their literals are decoded in lockstep, so the two chains overlap.  Same checks and results as two inflate() calls.
+    static bool inflate2(FastInflate &A, const uint8_t *in_a, size_t in_len_a, uint8_t *out_a, size_t out_len_a,
+                         FastInflate &B, const uint8_t *in_b, size_t in_len_b, uint8_t *out_b, size_t out_len_b) {
+        A.begin(in_a, in_len_a, out_a, out_len_a);
+        B.begin(in_b, in_len_b, out_b, out_len_b);
+        int ra = A.next_block(), rb = B.next_block();
+        while (ra == 1 && rb == 1) {
+            const int f = pair_loop(A, B);
+            if (f & F_ERROR) return false;
+            if (f & F_A_EOB) ra = A.next_block();
+            else if (f & F_A_CAREFUL) ra = A.decode_block() ? A.next_block() : -1;
+            if (f & F_B_EOB) rb = B.next_block();
+            else if (f & F_B_CAREFUL) rb = B.decode_block() ? B.next_block() : -1;
+        }
+        while (ra == 1) ra = A.decode_block() ? A.next_block() : -1;
+        while (rb == 1) rb = B.decode_block() ? B.next_block() : -1;
+        return ra == 0 && rb == 0 && A.op_ == A.oend_ && B.op_ == B.oend_;
+    }
+
+private:
+    void begin(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) {
         ip_ = in;
         iend_ = in + in_len;
         bb_ = 0;
         bc_ = 0;
-        uint8_t *op = out, *const oend = out + out_len;
+        out_ = op_ = out;
+        oend_ = out + out_len;
+        final_seen_ = false;
+    }
+    // Reads block headers (and copies stored blocks) up to the next Huffman block: 1 = inside one, its tables in lit_ /
+    // dist_; 0 = the final block is behind us; -1 = malformed.
+    int next_block() {
         for (;;) {
+            if (final_seen_) return 0;
             refill();
-            if (bc_ < 3) return false;
+            if (bc_ < 3) return -1;
             const uint32_t bfinal = (uint32_t)bb_ & 1u, btype = ((uint32_t)bb_ >> 1) & 3u;
             drop(3);
+            final_seen_ = bfinal != 0;
             if (btype == 0) {
                 drop(bc_ & 7);  // to the byte boundary
                 refill();
-                if (bc_ < 32) return false;
+                if (bc_ < 32) return -1;
                 const uint32_t len = (uint32_t)bb_ & 0xffffu, nlen = ((uint32_t)(bb_ >> 16)) & 0xffffu;
-                if ((len ^ nlen) != 0xffffu) return false;
+                if ((len ^ nlen) != 0xffffu) return -1;
                 drop(32);
                 ip_ -= bc_ >> 3;  // whole bytes still in the bit buffer go back to the byte stream
                 bb_ = 0;
                 bc_ = 0;
-                if ((size_t)(iend_ - ip_) < len || (size_t)(oend - op) < len) return false;
-                memcpy(op, ip_, len);
-                op += len;
+                if ((size_t)(iend_ - ip_) < len || (size_t)(oend_ - op_) < len) return -1;
+                memcpy(op_, ip_, len);
+                op_ += len;
                 ip_ += len;
-            } else if (btype == 1 || btype == 2) {
-                if (btype == 1) {
-                    if (!fixed_built_) {
-                        uint8_t l[288 + 32];
-                        for (int i = 0; i < 288; i++) l[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
-                        for (int i = 0; i < 32; i++) l[288 + i] = 5;
-                        if (!build(l, 288, LIT_BITS, fix_lit_, FIX_LIT_SIZE, true) || !build(l + 288, 32, DIST_BITS, fix_dist_, FIX_DIST_SIZE, false))
-                            return false;
-                        fixed_built_ = true;
-                    }
-                    lit_ = fix_lit_;
-                    dist_ = fix_dist_;
-                } else {
-                    if (!read_dynamic()) return false;
-                    lit_ = dyn_lit_;
-                    dist_ = dyn_dist_;
+            } else if (btype == 1) {
+                if (!fixed_built_) {
+                    uint8_t l[288 + 32];
+                    for (int i = 0; i < 288; i++) l[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+                    for (int i = 0; i < 32; i++) l[288 + i] = 5;
+                    if (!build(l, 288, LIT_BITS, fix_lit_, FIX_LIT_SIZE, true) || !build(l + 288, 32, DIST_BITS, fix_dist_, FIX_DIST_SIZE, false))
+                        return -1;
+                    fixed_built_ = true;
                 }
-                if (!decode_block(out, op, oend)) return false;
+                lit_ = fix_lit_;
+                dist_ = fix_dist_;
+                return 1;
+            } else if (btype == 2) {
+                if (!read_dynamic()) return -1;
+                lit_ = dyn_lit_;
+                dist_ = dyn_dist_;
+                return 1;
             } else
-                return false;
-            if (bfinal) break;
+                return -1;
         }
-        return op == oend;
     }
 
-private:
     static constexpr int LIT_BITS = 10, DIST_BITS = 8;
     // entry: bits 0-7 code length to consume (sub-table pointer: primary bits), 8-11 kind, 12-15 extra bits or
     // sub-table index bits, 16-31 literal value / base / sub-table offset
@@ -241,8 +277,10 @@ private:
         return true;
     }
 
-    bool decode_block(uint8_t *out, uint8_t *&op_ref, uint8_t *const oend) {
-        uint8_t *op = op_ref;
+    // the rest of the current Huffman block, from wherever the stream stands
+    bool decode_block() {
+        uint8_t *op = op_;
+        uint8_t *const out = out_, *const oend = oend_;
         const uint32_t *lit = lit_, *dist = dist_;
         // Fast loop while a whole worst-case step fits on both sides: >= 8 input bytes for the word refill, room for
         // three literals and a 258-byte match with its 8-byte copy overshoot.  One refill (>= 56 bits) serves up to
@@ -280,7 +318,7 @@ private:
                 continue;
             }
             if (kind == K_EOB) {
-                op_ref = op;
+                op_ = op;
                 return true;
             }
             if (kind != K_LEN) return false;
@@ -370,11 +408,140 @@ private:
             }
             op += len;
         }
-        op_ref = op;
+        op_ = op;
         return true;
     }
 
+    // ---- two streams in lockstep (inflate2)
+    enum { F_A_EOB = 1, F_B_EOB = 2, F_A_CAREFUL = 4, F_B_CAREFUL = 8, F_ERROR = 16 };
+    struct Cur {  // a stream's hot state in registers
+        uint64_t bb;
+        int bc;
+        const uint8_t *ip;
+        uint8_t *op;
+    };
+    // one symbol whose primary entry is e (not yet consumed), with everything checked as in decode_block's fast loop:
+    // 0 = done, 1 = end of block, -1 = malformed
+    static inline __attribute__((always_inline)) int pair_symbol(Cur &c, uint32_t e, const uint32_t *lit, const uint32_t *dist,
+                                                                const uint8_t *out, const uint8_t *iend) {
+        if ((e & K_MASK) == K_SUB) {
+            c.bb >>= LIT_BITS;
+            c.bc -= LIT_BITS;
+            e = lit[(e >> 16) + ((uint32_t)c.bb & ((1u << ((e >> 12) & 15u)) - 1u))];
+        }
+        const int cl = (int)(e & 255u);
+        if (cl == 0) return -1;
+        c.bb >>= cl;
+        c.bc -= cl;
+        const uint32_t kind = e & K_MASK;
+        if (kind == K_LIT) {
+            *c.op++ = (uint8_t)(e >> 16);
+            return 0;
+        }
+        if (kind == K_EOB) return 1;
+        if (kind != K_LEN) return -1;
+        if (c.bc < 48) {  // (the pair loop guarantees >= 8 input bytes at its top; a refill moves ip by at most 7)
+            if (iend - c.ip >= 8) {
+                c.bb |= load64(c.ip) << c.bc;
+                c.ip += (63 - c.bc) >> 3;
+                c.bc |= 56;
+            } else {
+                while (c.bc <= 56 && c.ip < iend) {
+                    c.bb |= (uint64_t)*c.ip++ << c.bc;
+                    c.bc += 8;
+                }
+            }
+        }
+        const int lx = (int)((e >> 12) & 15u);
+        if (lx > c.bc) return -1;
+        const size_t len = (e >> 16) + ((uint32_t)c.bb & ((1u << lx) - 1u));
+        c.bb >>= lx;
+        c.bc -= lx;
+        uint32_t d = dist[(uint32_t)c.bb & ((1u << DIST_BITS) - 1u)];
+        if ((d & K_MASK) == K_SUB) {
+            c.bb >>= DIST_BITS;
+            c.bc -= DIST_BITS;
+            d = dist[(d >> 16) + ((uint32_t)c.bb & ((1u << ((d >> 12) & 15u)) - 1u))];
+        }
+        const int dl = (int)(d & 255u);
+        if (dl == 0 || dl > c.bc || (d & K_MASK) != K_DIST) return -1;
+        c.bb >>= dl;
+        c.bc -= dl;
+        const int dx = (int)((d >> 12) & 15u);
+        if (dx > c.bc) return -1;
+        const size_t distance = (d >> 16) + ((uint32_t)c.bb & ((1u << dx) - 1u));
+        c.bb >>= dx;
+        c.bc -= dx;
+        if (distance > (size_t)(c.op - out)) return -1;
+        const uint8_t *src = c.op - distance;
+        uint8_t *dst = c.op;
+        const uint8_t *const stop = c.op + len;
+        if (distance >= 8) {
+            do {
+                memcpy(dst, src, 8);
+                dst += 8;
+                src += 8;
+            } while (dst < stop);
+        } else if (distance == 1) {
+            memset(dst, *src, len);
+        } else {
+            do { *dst++ = *src++; } while (dst < stop);
+        }
+        c.op += len;
+        return 0;
+    }
+    // Runs while both streams have a whole worst-case step of room on both sides (as decode_block's fast loop); returns
+    // which stream reached its end of block or has to continue in decode_block's careful loop.
+    static int pair_loop(FastInflate &A, FastInflate &B) {
+        Cur a{A.bb_, A.bc_, A.ip_, A.op_}, b{B.bb_, B.bc_, B.ip_, B.op_};
+        const uint32_t *const la = A.lit_, *const lb = B.lit_;
+        constexpr uint32_t M = (1u << LIT_BITS) - 1u;
+        int flags = 0;
+        for (;;) {
+            if (!(A.iend_ - a.ip >= 8 && A.oend_ - a.op >= 3 + 258 + 8)) flags |= F_A_CAREFUL;
+            if (!(B.iend_ - b.ip >= 8 && B.oend_ - b.op >= 3 + 258 + 8)) flags |= F_B_CAREFUL;
+            if (flags) break;
+            a.bb |= load64(a.ip) << a.bc;
+            a.ip += (63 - a.bc) >> 3;
+            a.bc |= 56;
+            b.bb |= load64(b.ip) << b.bc;
+            b.ip += (63 - b.bc) >> 3;
+            b.bc |= 56;
+            uint32_t ea = la[(uint32_t)a.bb & M], eb = lb[(uint32_t)b.bb & M];
+            // up to three literals from each stream per refill (<= 45 of >= 56 bits), the two chains side by side
+            if (((ea & K_MASK) == K_LIT) & ((eb & K_MASK) == K_LIT)) {
+                a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); *a.op++ = (uint8_t)(ea >> 16);
+                b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); *b.op++ = (uint8_t)(eb >> 16);
+                ea = la[(uint32_t)a.bb & M];
+                eb = lb[(uint32_t)b.bb & M];
+                if (((ea & K_MASK) == K_LIT) & ((eb & K_MASK) == K_LIT)) {
+                    a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); *a.op++ = (uint8_t)(ea >> 16);
+                    b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); *b.op++ = (uint8_t)(eb >> 16);
+                    ea = la[(uint32_t)a.bb & M];
+                    eb = lb[(uint32_t)b.bb & M];
+                    if (((ea & K_MASK) == K_LIT) & ((eb & K_MASK) == K_LIT)) {
+                        a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); *a.op++ = (uint8_t)(ea >> 16);
+                        b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); *b.op++ = (uint8_t)(eb >> 16);
+                        continue;
+                    }
+                }
+            }
+            // at least one of the two is not a literal: one symbol of each the long way
+            const int sa = pair_symbol(a, ea, la, A.dist_, A.out_, A.iend_);
+            const int sb = pair_symbol(b, eb, lb, B.dist_, B.out_, B.iend_);
+            if ((sa < 0) | (sb < 0)) { flags = F_ERROR; break; }
+            if (sa) flags |= F_A_EOB;
+            if (sb) flags |= F_B_EOB;
+            if (flags) break;
+        }
+        A.bb_ = a.bb; A.bc_ = a.bc; A.ip_ = a.ip; A.op_ = a.op;
+        B.bb_ = b.bb; B.bc_ = b.bc; B.ip_ = b.ip; B.op_ = b.op;
+        return flags;
+    }
+
     const uint8_t *ip_ = nullptr, *iend_ = nullptr;
+    uint8_t *out_ = nullptr, *op_ = nullptr, *oend_ = nullptr;
+    bool final_seen_ = false;
     uint64_t bb_ = 0;
     int bc_ = 0;
     const uint32_t *lit_ = nullptr, *dist_ = nullptr;

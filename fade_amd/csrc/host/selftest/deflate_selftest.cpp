@@ -40,6 +40,41 @@ static bool roundtrip(FastDeflate &fd, const uint8_t *in, size_t n, size_t *clen
         fprintf(stderr, "FastInflate failed on a FastDeflate stream (n=%zu clen=%zu)\n", n, clen);
         return false;
     }
+    // the pair decoder: this stream next to the previous case's, in both orders, whole and damaged
+    {
+        static std::vector<uint8_t> prev_stream, prev_plain;
+        static bool have_prev = false;
+        static FastInflate fa, fb;
+        if (have_prev) {
+            const size_t pn = prev_plain.size();
+            for (int order = 0; order < 2; order++) {
+                std::vector<uint8_t> o1(pn + 1, 0xa5), o2(n + 1, 0xa5);
+                const bool ok = order == 0 ? FastInflate::inflate2(fa, prev_stream.data(), prev_stream.size(), o1.data(), pn, fb, out.data(), clen, o2.data(), n)
+                                           : FastInflate::inflate2(fa, out.data(), clen, o2.data(), n, fb, prev_stream.data(), prev_stream.size(), o1.data(), pn);
+                if (!ok || (pn && memcmp(o1.data(), prev_plain.data(), pn) != 0) || (n && memcmp(o2.data(), in, n) != 0) || o1[pn] != 0xa5 || o2[n] != 0xa5) {
+                    fprintf(stderr, "inflate2 failed (order %d, n=%zu, previous n=%zu)\n", order, n, pn);
+                    return false;
+                }
+            }
+            // a wrong size for either stream is refused; damaged streams stay inside the buffers (ASan watches)
+            std::vector<uint8_t> o1(pn + 1), o2(n + 1);
+            if (n && FastInflate::inflate2(fa, prev_stream.data(), prev_stream.size(), o1.data(), pn, fb, out.data(), clen, o2.data(), n - 1)) { fprintf(stderr, "inflate2: short output accepted\n"); return false; }
+            if (pn && FastInflate::inflate2(fa, prev_stream.data(), prev_stream.size(), o1.data(), pn - 1, fb, out.data(), clen, o2.data(), n)) { fprintf(stderr, "inflate2: short output accepted\n"); return false; }
+            if (clen > 4) {
+                std::vector<uint8_t> bad(out.begin(), out.begin() + (std::ptrdiff_t)clen);
+                static uint64_t lcg2 = 1234567;
+                for (int rep = 0; rep < 3; rep++) {
+                    lcg2 = lcg2 * 6364136223846793005ull + 1442695040888963407ull;
+                    bad[(size_t)(lcg2 >> 33) % clen] ^= (uint8_t)(1u << ((lcg2 >> 20) & 7));
+                    (void)FastInflate::inflate2(fa, prev_stream.data(), prev_stream.size(), o1.data(), pn, fb, bad.data(), clen, o2.data(), n);
+                    (void)FastInflate::inflate2(fa, bad.data(), clen / 2, o2.data(), n, fb, prev_stream.data(), prev_stream.size(), o1.data(), pn);
+                }
+            }
+        }
+        prev_stream.assign(out.begin(), out.begin() + (std::ptrdiff_t)clen);
+        prev_plain.assign(in, in + n);
+        have_prev = true;
+    }
     static const int settings[][2] = {{0, Z_DEFAULT_STRATEGY}, {1, Z_DEFAULT_STRATEGY}, {6, Z_DEFAULT_STRATEGY}, {9, Z_DEFAULT_STRATEGY},
                                       {6, Z_FIXED}, {6, Z_HUFFMAN_ONLY}, {6, Z_RLE}};
     std::vector<uint8_t> zbuf(n + n / 8 + 1024);
@@ -59,6 +94,16 @@ static bool roundtrip(FastDeflate &fd, const uint8_t *in, size_t n, size_t *clen
         if (!fi.inflate(zbuf.data(), zl, mine.data(), n) || (n && memcmp(mine.data(), in, n) != 0) || mine[n] != 0xa5) {
             fprintf(stderr, "FastInflate failed on a zlib stream (level %d strategy %d, n=%zu)\n", st[0], st[1], n);
             return false;
+        }
+        {  // a zlib stream and the FastDeflate stream of the same bytes as a pair
+            static FastInflate fa, fb;
+            std::vector<uint8_t> o2(n + 1, 0xa5);
+            std::fill(mine.begin(), mine.end(), 0xa5);
+            if (!FastInflate::inflate2(fa, zbuf.data(), zl, mine.data(), n, fb, out.data(), clen, o2.data(), n) ||
+                (n && (memcmp(mine.data(), in, n) != 0 || memcmp(o2.data(), in, n) != 0)) || mine[n] != 0xa5 || o2[n] != 0xa5) {
+                fprintf(stderr, "inflate2 failed on a zlib stream (level %d strategy %d, n=%zu)\n", st[0], st[1], n);
+                return false;
+            }
         }
         // wrong sizes and damaged streams must be refused or at least stay inside the buffers (ASan watches)
         if (n && fi.inflate(zbuf.data(), zl, mine.data(), n - 1)) { fprintf(stderr, "short output accepted\n"); return false; }
@@ -246,11 +291,18 @@ int main(int argc, char **argv) {
             blocks.push_back(c);
             sizes.push_back(n);
         }
-        std::vector<uint8_t> out(B + 16);
-        for (int mode = 0; mode < 2; mode++) {
+        std::vector<uint8_t> out(B + 16), out2(B + 16);
+        FastInflate fi2;
+        for (int mode = 0; mode < 3; mode++) {
             const auto t0 = std::chrono::steady_clock::now();
             for (size_t b = 0; b < blocks.size(); b++) {
-                if (mode == 0) {
+                if (mode == 2) {
+                    if (b + 1 < blocks.size()) {
+                        if (!FastInflate::inflate2(fi, blocks[b].data(), blocks[b].size() - 8, out.data(), sizes[b],
+                                                   fi2, blocks[b + 1].data(), blocks[b + 1].size() - 8, out2.data(), sizes[b + 1])) return 1;
+                        b++;
+                    } else if (!fi.inflate(blocks[b].data(), blocks[b].size() - 8, out.data(), sizes[b])) return 1;
+                } else if (mode == 0) {
                     if (!fi.inflate(blocks[b].data(), blocks[b].size() - 8, out.data(), sizes[b])) return 1;
                 } else {
                     z_stream zs;
@@ -265,7 +317,7 @@ int main(int argc, char **argv) {
                 }
             }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            printf("%-22s %7.1f MB/s (output bytes)\n", mode == 0 ? "FastInflate" : "zlib inflate", (double)data.size() / dt / 1e6);
+            printf("%-22s %7.1f MB/s (output bytes)\n", mode == 0 ? "FastInflate" : (mode == 1 ? "zlib inflate" : "FastInflate, pairs"), (double)data.size() / dt / 1e6);
         }
     }
     return 0;

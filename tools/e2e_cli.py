@@ -88,6 +88,12 @@ def main():
         print(tag, res[tag], flush=True)
 
     out_gpu, out_cpu = os.path.join(tmp, "e2e.gpu.bam"), os.path.join(tmp, "e2e.cpu.bam")
+    if os.environ.get("E2E_SAM_AB"):  # SAM -> BAM with this build and with another binary (A/B of host changes)
+        for rep in range(2):
+            run("sam_to_bam_other_%d" % rep, os.environ["E2E_SAM_AB"], ["-b", sam, fa], out_gpu, threads)
+            run("sam_to_bam_this_%d" % rep, fade, ["-b", sam, fa], out_gpu, threads)
+        json.dump(res, open(os.path.join(ROOT, "gpurun_out", "e2e_sweep.json"), "w"), indent=1)
+        return
     for t in [int(x) for x in os.environ.get("E2E_SWEEP", "").split(",") if x]:  # -t sweep of the BAM -> BAM leg only
         run("gpu_bam_to_bam_t%d" % t, fade, ["-b", bam, fa], out_gpu, t)
     if os.environ.get("E2E_SWEEP"):
