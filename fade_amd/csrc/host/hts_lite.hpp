@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <sys/mman.h>
 #include <atomic>
+#include <exception>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -79,6 +80,7 @@ public:
             if (kind >= 0) cpu_meter()[kind] += thread_cpu_ns() - t0;
             return;
         }
+        // (an exception thrown by fn on any thread ends the job early and is rethrown here, on the caller's thread)
         Job job;
         job.fn = &fn;
         job.count = count;
@@ -93,6 +95,7 @@ public:
         std::unique_lock<std::mutex> l(m_);
         jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));
         job.idle.wait(l, [&] { return job.helpers == 0; });
+        if (job.error) std::rethrow_exception(job.error);
     }
 
 private:
@@ -103,13 +106,21 @@ private:
         std::atomic<size_t> next{0};
         int helpers = 0;  // workers inside work_on (guarded by m_)
         std::condition_variable idle;
+        std::exception_ptr error;  // the first exception out of fn (guarded by err_m)
+        std::mutex err_m;
     };
     static void work_on(Job &j) {
         const int64_t t0 = j.kind >= 0 ? thread_cpu_ns() : 0;
-        for (;;) {
-            const size_t i = j.next.fetch_add(1);
-            if (i >= j.count) break;
-            (*j.fn)(i);
+        try {
+            for (;;) {
+                const size_t i = j.next.fetch_add(1);
+                if (i >= j.count) break;
+                (*j.fn)(i);
+            }
+        } catch (...) {
+            j.next.store(j.count);  // nothing more is handed out
+            std::lock_guard<std::mutex> l(j.err_m);
+            if (!j.error) j.error = std::current_exception();
         }
         if (j.kind >= 0) cpu_meter()[j.kind] += thread_cpu_ns() - t0;
     }

@@ -3,6 +3,7 @@
 // Every case must be REJECTED (exception or layout_ok() == false) without touching memory outside the record.
 //   make -C fade_amd/csrc build/hts_selftest && fade_amd/csrc/build/hts_selftest
 #include "../hts_lite.hpp"
+#include <thread>
 
 #include <cstdio>
 
@@ -133,6 +134,53 @@ int main() {
         CHECK(reader_rejects(bgzf_block(payload, -1, 65537)));
         CHECK(reader_rejects(bgzf_block(payload, -1, 0x7fffffff)));
         CHECK(reader_rejects(bgzf_block(payload, -1, 999)));  // ISIZE that the stream does not inflate to
+    }
+    // ---- Pool: jobs from several threads at once; every index runs exactly once; an exception reaches its caller only
+    {
+        Pool pool(4);
+        std::atomic<long> sums[3];
+        for (auto &v : sums) v = 0;
+        std::atomic<int> caught{0};
+        std::vector<std::thread> callers;
+        for (int c = 0; c < 3; c++)
+            callers.emplace_back([&, c] {
+                for (int rep = 0; rep < 200; rep++) {
+                    std::vector<std::atomic<int>> seen(97 + (size_t)c);
+                    for (auto &v : seen) v = 0;
+                    pool.parallel_for(seen.size(), [&](size_t i) {
+                        seen[i]++;
+                        sums[c] += (long)i;
+                    });
+                    for (auto &v : seen)
+                        if (v != 1) failures++;
+                    if (c == 2 && rep % 50 == 7) {
+                        try {
+                            pool.parallel_for(64, [&](size_t i) { if (i == 13) throw std::runtime_error("task 13"); });
+                        } catch (const std::runtime_error &) {
+                            caught++;
+                        }
+                    }
+                }
+            });
+        for (auto &t : callers) t.join();
+        for (int c = 0; c < 3; c++) {
+            const long n = 97 + c;
+            CHECK(sums[c] == 200 * (n * (n - 1) / 2));
+        }
+        CHECK(caught == 4);
+    }
+    // ---- RawBuf: recycled buffers keep nothing of their previous size; reserve never shrinks the contents
+    {
+        for (int rep = 0; rep < 6; rep++) {
+            RawBuf b;
+            b.reserve((size_t)9 << 20);
+            CHECK(b.size() == 0 && b.capacity() >= ((size_t)9 << 20));
+            b.resize(100);
+            memset(b.data(), rep, 100);
+            b.resize((size_t)20 << 20);  // grows: the first 100 bytes survive
+            CHECK(b.data()[0] == rep && b.data()[99] == rep);
+            b.data()[b.size() - 1] = 1;
+        }
     }
     if (failures) {
         fprintf(stderr, "%d check(s) failed\n", failures);
