@@ -153,6 +153,41 @@ private:
     bool stop_ = false;
 };
 
+// ------------------------------------------------------------------ stage hand-off
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        not_full_.wait(l, [&] { return q_.size() < cap_ || closed_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    bool pop(T &v) {  // false once closed and drained
+        std::unique_lock<std::mutex> l(m_);
+        not_empty_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> l(m_);
+        closed_ = true;
+        not_empty_.notify_all();
+        not_full_.notify_all();
+    }
+
+private:
+    size_t cap_;
+    std::deque<T> q_;
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    bool closed_ = false;
+};
+
 // ------------------------------------------------------------------ header
 struct Header {
     std::string text;                // SAM header text (lines end with '\n')
