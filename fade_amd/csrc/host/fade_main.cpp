@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <deque>
 #include <functional>
+#include <future>
 #include <unistd.h>
 
 #ifndef FADE_VERSION
@@ -472,7 +473,9 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
         // pool; chunks keep their input order.  The device calls are asynchronous, so this one thread keeps every slot
         // of every device busy: batch k goes to device k % N, slot (k / N) % kSlotsInUse.
-        BoundedQueue<std::unique_ptr<Chunk>> q_in(2), q_out(3);
+        // the reader may run ahead by about two million records (0.6 GB inflated) while the GPU path comes up
+        const size_t ahead = (size_t)std::max(2, std::min(8, (2 << 20) / std::max(o.batch, 1)));
+        BoundedQueue<std::unique_ptr<Chunk>> q_in(ahead), q_out(3);
         std::string stage_err;
         std::mutex err_m;
         auto set_stage_err = [&](const std::string &e) {
@@ -503,6 +506,35 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             }
             q_in.close();
         });
+        // --gpus N uses devices 0..N-1; FADE_DEVICE_MAP="0,0" (tests on a one-GPU box) maps the N contexts elsewhere
+        std::vector<int> devmap((size_t)ngpu);
+        for (int d = 0; d < ngpu; d++) devmap[(size_t)d] = d;
+        bool distinct_devices = true;
+        if (const char *dm = getenv("FADE_DEVICE_MAP")) {
+            int d = 0;
+            for (const char *q = dm; *q && d < ngpu; d++) {
+                devmap[(size_t)d] = atoi(q);
+                q = strchr(q, ',');
+                if (!q) break;
+                q++;
+            }
+            for (int a = 0; a < ngpu; a++)
+                for (int b2 = a + 1; b2 < ngpu; b2++)
+                    if (devmap[(size_t)a] == devmap[(size_t)b2]) distinct_devices = false;
+        }
+        fadehip_params prm;
+        fadehip_params_default(&prm);  // max_ref_len 2^20: any window the kernels can serve, whatever -w is
+        prm.max_batch_reads = std::max(o.batch, 1);
+        // the HIP runtime and the contexts come up on a helper thread while this one reads the FASTA
+        std::string create_err;
+        std::future<int> creating = std::async(std::launch::async, [&]() -> int {
+            for (int d = 0; d < ngpu; d++)
+                if (fadehip_create(&ctxs[(size_t)d], devmap[(size_t)d], &prm)) {
+                    create_err = fadehip_last_error(nullptr);  // (the library keeps it per thread)
+                    return 1;
+                }
+            return 0;
+        });
         ck_fasta.start();
         Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
         ck_fasta.stop();
@@ -532,32 +564,16 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n");
             return 1;
         }
-        // --gpus N uses devices 0..N-1; FADE_DEVICE_MAP="0,0" (tests on a one-GPU box) maps the N contexts elsewhere
-        std::vector<int> devmap((size_t)ngpu);
-        for (int d = 0; d < ngpu; d++) devmap[(size_t)d] = d;
-        bool distinct_devices = true;
-        if (const char *dm = getenv("FADE_DEVICE_MAP")) {
-            int d = 0;
-            for (const char *q = dm; *q && d < ngpu; d++) {
-                devmap[(size_t)d] = atoi(q);
-                q = strchr(q, ',');
-                if (!q) break;
-                q++;
-            }
-            for (int a = 0; a < ngpu; a++)
-                for (int b2 = a + 1; b2 < ngpu; b2++)
-                    if (devmap[(size_t)a] == devmap[(size_t)b2]) distinct_devices = false;
-        }
-        fadehip_params prm;
-        fadehip_params_default(&prm);  // max_ref_len 2^20: any window the kernels can serve, whatever -w is
-        prm.max_batch_reads = std::max(o.batch, 1);
         auto die = [&](fadehip_ctx *c, const char *what) {
             fprintf(stderr, "[E::fade annotate] %s: %s\n", what, fadehip_last_error(c));
             return 1;
         };
         ck_upload.start();
+        if (creating.get()) {
+            fprintf(stderr, "[E::fade annotate] cannot open the GPU path: %s\n", create_err.c_str());
+            return 1;
+        }
         for (int d = 0; d < ngpu; d++) {
-            if (fadehip_create(&ctxs[(size_t)d], devmap[(size_t)d], &prm)) return die(nullptr, "cannot open the GPU path");
             blocks[(size_t)d].ctx = ctxs[(size_t)d];
             if (fadehip_genome_upload(ctxs[(size_t)d], (int)lens.size(), lens.data(), ptrs.data())) return die(ctxs[(size_t)d], "genome upload");
         }
