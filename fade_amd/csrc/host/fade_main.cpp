@@ -494,7 +494,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 while (!abort_stages) {
                     std::unique_ptr<Chunk> c(new Chunk());
                     ck_read.start();
-                    c->is_block = reader.is_bam();
+                    c->is_block = true;  // (SAM lines are parsed into the same block layout)
                     const size_t got = c->is_block ? reader.read_block(c->blk, (size_t)std::max(o.batch, 1))
                                                    : reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
                     ck_read.stop();

@@ -1110,12 +1110,13 @@ public:
     }
     const Header &header() const { return hdr_; }
     bool is_bam() const { return bam_; }
-    // BAM only: the next up-to-max_n records, framed in place in blk.buf; returns their number (0 at end of file)
+    // the next up-to-max_n records as one block: BAM records framed in place in the inflated bytes, SAM lines parsed into
+    // the same layout; returns their number (0 at end of file)
     size_t read_block(RecordBlock &blk, size_t max_n) {
-        if (!bam_) throw std::runtime_error("read_block needs BAM input");
         blk.buf.clear();
         blk.off.clear();
         blk.len.clear();
+        if (!bam_) return read_block_sam(blk, max_n);
         blk.off.reserve(max_n);
         blk.len.reserve(max_n);
         if (!block_mode_) {  // bytes inflated while the header was read
@@ -1231,36 +1232,7 @@ public:
         }
         // SAM: pull text in 16 MiB pieces, frame the lines (memchr), parse them in parallel straight from the buffer
         std::vector<std::pair<size_t, size_t>> lines;  // offset, length in text_
-        for (;;) {
-            lines.clear();
-            size_t o = text_pos_;
-            while (lines.size() < max_n) {
-                const char *b = text_.data() + o;
-                const char *nl = (const char *)memchr(b, '\n', text_.size() - o);
-                if (!nl) break;
-                size_t len = (size_t)(nl - b);
-                const size_t next = o + len + 1;
-                if (len && b[len - 1] == '\r') len--;
-                if (len) lines.push_back({o, len});
-                o = next;
-            }
-            if (lines.size() < max_n && !text_eof_) {
-                // not enough complete lines buffered: drop the consumed prefix, append more text, frame again
-                text_.erase(0, text_pos_);
-                text_pos_ = 0;
-                const size_t have = text_.size(), want = (size_t)16 << 20;
-                text_.resize(have + want);
-                const size_t got = src_->read((uint8_t *)&text_[have], want);
-                text_.resize(have + got);
-                if (got < want) {
-                    text_eof_ = true;
-                    if (!text_.empty() && text_.back() != '\n') text_.push_back('\n');
-                }
-                continue;
-            }
-            text_pos_ = o;
-            break;
-        }
+        frame_sam_lines(max_n, lines);
         const size_t base = out.size();
         out.resize(base + lines.size());
         std::atomic<bool> bad{false};
@@ -1270,7 +1242,7 @@ public:
         pool_->parallel_for(nt, [&](size_t t) {
             for (size_t i = cnt * t / nt; i < cnt * (t + 1) / nt; i++) {
                 try {
-                    sam_parse(text_.data() + lines[i].first, lines[i].second, hdr_, out[base + i]);
+                    sam_parse((const char *)text_.data() + lines[i].first, lines[i].second, hdr_, out[base + i]);
                 } catch (const std::exception &e) {
                     std::lock_guard<std::mutex> l(em);
                     bad = true;
@@ -1283,12 +1255,99 @@ public:
     }
 
 private:
+    // the next up-to-max_n complete SAM lines of the text buffer (offset, length in text_), reading more text as needed
+    void frame_sam_lines(size_t max_n, std::vector<std::pair<size_t, size_t>> &lines) {
+        for (;;) {
+            lines.clear();
+            size_t o = text_pos_;
+            while (lines.size() < max_n) {
+                const char *b = (const char *)text_.data() + o;
+                const char *nl = (const char *)memchr(b, '\n', text_.size() - o);
+                if (!nl) break;
+                size_t len = (size_t)(nl - b);
+                const size_t next = o + len + 1;
+                if (len && b[len - 1] == '\r') len--;
+                if (len) lines.push_back({o, len});
+                o = next;
+            }
+            if (lines.size() < max_n && !text_eof_) {
+                // not enough complete lines buffered: drop the consumed prefix, append more text, frame again
+                text_.drop_front(text_pos_);
+                text_pos_ = 0;
+                const size_t have = text_.size(), want = (size_t)16 << 20;
+                text_.resize(have + want);  // (not zero-filled: a RawBuf)
+                const size_t got = src_->read(text_.data() + have, want);
+                text_.resize(have + got);
+                if (got < want) {
+                    text_eof_ = true;
+                    if (text_.size() && text_.data()[text_.size() - 1] != '\n') {
+                        text_.resize(text_.size() + 1);
+                        text_.data()[text_.size() - 1] = '\n';
+                    }
+                }
+                continue;
+            }
+            text_pos_ = o;
+            break;
+        }
+    }
+    // SAM input as a RecordBlock: every task parses its share of the lines into one buffer of its own (a reused Rec, no
+    // allocation per record), then the pieces are laid end to end in blk.buf
+    size_t read_block_sam(RecordBlock &blk, size_t max_n) {
+        std::vector<std::pair<size_t, size_t>> lines;
+        frame_sam_lines(max_n, lines);
+        const size_t cnt = lines.size(), nt = (size_t)pool_->size() * 4;
+        if (!cnt) return 0;
+        std::vector<std::vector<uint8_t>> piece(nt);
+        std::vector<std::vector<uint32_t>> plen(nt);
+        std::atomic<bool> bad{false};
+        std::string err;
+        std::mutex em;
+        pool_->parallel_for(nt, [&](size_t t) {
+            const size_t lo = cnt * t / nt, hi = cnt * (t + 1) / nt;
+            Rec r;
+            piece[t].reserve((hi - lo) * 320);
+            plen[t].reserve(hi - lo);
+            try {
+                for (size_t i = lo; i < hi; i++) {
+                    sam_parse((const char *)text_.data() + lines[i].first, lines[i].second, hdr_, r);
+                    piece[t].insert(piece[t].end(), r.d.begin(), r.d.end());
+                    plen[t].push_back((uint32_t)r.d.size());
+                }
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> l(em);
+                bad = true;
+                err = e.what();
+            }
+        }, CPU_SAM_PARSE);
+        if (bad) throw std::runtime_error(err);
+        std::vector<size_t> base(nt + 1, 0);
+        for (size_t t = 0; t < nt; t++) base[t + 1] = base[t] + piece[t].size();
+        if (base[nt] > 0xffffffffull) throw std::runtime_error("record block beyond 4 GiB: lower --batch");
+        blk.buf.reserve(base[nt]);
+        blk.buf.resize(base[nt]);
+        blk.off.resize(cnt);
+        blk.len.resize(cnt);
+        pool_->parallel_for(nt, [&](size_t t) {
+            if (!piece[t].empty()) memcpy(blk.buf.data() + base[t], piece[t].data(), piece[t].size());
+            size_t o = base[t], i = cnt * t / nt;
+            for (uint32_t l : plen[t]) {
+                blk.off[i] = (uint32_t)o;
+                blk.len[i] = l;
+                o += l;
+                i++;
+            }
+        }, CPU_COPY);
+        return cnt;
+    }
     void read_sam_header() {
         std::string s;
         while (src_->getline(s)) {
             if (!s.empty() && s[0] == '@') hdr_.text += s + "\n";
             else {
-                text_ = s + "\n";  // first record line: goes back in front of the text buffer
+                text_.resize(s.size() + 1);  // first record line: goes back in front of the text buffer
+                memcpy(text_.data(), s.data(), s.size());
+                text_.data()[s.size()] = '\n';
                 break;
             }
         }
@@ -1326,7 +1385,7 @@ private:
     RawBuf carry_;          // read_block: inflated bytes behind the last framed record
     bool block_mode_ = false;
     size_t last_block_bytes_ = 0, last_block_recs_ = 0;  // inflated size / records of the previous read_block (the next one reserves as much)
-    std::string text_;      // SAM text not yet handed out (complete lines from text_pos_ on)
+    RawBuf text_;           // SAM text not yet handed out (complete lines from text_pos_ on)
     size_t text_pos_ = 0;
     bool text_eof_ = false;
 };

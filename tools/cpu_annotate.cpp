@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
             try {
                 for (;;) {
                     std::unique_ptr<Work> w(new Work());
-                    w->is_block = reader.is_bam();
+                    w->is_block = true;
                     const size_t got = w->is_block ? reader.read_block(w->blk, (size_t)batch) : reader.read_chunk(w->recs, (size_t)batch);
                     if (!got) break;
                     q_in.push(std::move(w));
