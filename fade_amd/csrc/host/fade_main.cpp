@@ -166,11 +166,9 @@ struct BlockPool {
 };
 
 struct Chunk {
-    std::vector<Rec> recs;       // SAM input: parsed records
-    RecordBlock blk;             // BAM input: records framed in place in the inflated bytes (no per-record copy)
+    RecordBlock blk;             // the records, framed in place (BAM: in the inflated bytes; SAM: parsed into the same layout)
     Writer::BlockOut bout;       // ... and what annotate adds to them
-    bool is_block = false;
-    size_t n_records() const { return is_block ? blk.size() : recs.size(); }
+    size_t n_records() const { return blk.size(); }
     // anno.d:61-65: an unmapped record, or one without an S op, gets rs = 0 and nothing else: such records are not sent.
     std::vector<uint32_t> sent;  // indices (into recs) of the records that are
     fadehip_read_batch b;        // bound into `block`
@@ -256,8 +254,7 @@ static void pack_chunk_t(Chunk &c, Pool &pool, BlockPool &blocks, const Get &get
     c.b.ref_span_bound = (int32_t)std::min<int64_t>(span, INT32_MAX);
 }
 static void pack_chunk(Chunk &c, Pool &pool, BlockPool &blocks) {
-    if (c.is_block) pack_chunk_t(c, pool, blocks, [&](size_t i) { return c.blk.view(i); });
-    else pack_chunk_t(c, pool, blocks, [&](size_t i) -> const Rec & { return c.recs[i]; });
+    pack_chunk_t(c, pool, blocks, [&](size_t i) { return c.blk.view(i); });
 }
 
 static std::string cigar_string(const uint32_t *ops, int n) {
@@ -339,13 +336,6 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
         art_of[c.sent[(size_t)si]] = (int)k;
     }
     const size_t nt = (size_t)pool.size();
-    if (!c.is_block) {
-        pool.parallel_for(nt, [&](size_t t) {
-            for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++)
-                tag_owned_record(c.recs[i], rs[i], art_of[i] >= 0 ? &c.art[(size_t)art_of[i]] : nullptr, h);
-        }, CPU_TAGS);
-        return;
-    }
     // Records framed in place: the new tags become a suffix behind the record's bytes (htslib appends an absent tag).
     // A record that already carries one of the five tags (annotating an annotated file) is rebuilt as a whole instead,
     // with htslib's update-in-place semantics.
@@ -494,9 +484,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 while (!abort_stages) {
                     std::unique_ptr<Chunk> c(new Chunk());
                     ck_read.start();
-                    c->is_block = true;  // (SAM lines are parsed into the same block layout)
-                    const size_t got = c->is_block ? reader.read_block(c->blk, (size_t)std::max(o.batch, 1))
-                                                   : reader.read_chunk(c->recs, (size_t)std::max(o.batch, 1));
+                    const size_t got = reader.read_block(c->blk, (size_t)std::max(o.batch, 1));  // (SAM lines are parsed into the same layout)
                     ck_read.stop();
                     if (got == 0) break;
                     q_in.push(std::move(c));
@@ -598,8 +586,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                     apply_tags(*c, hdr, pool);
                     ck_tags.stop();
                     ck_write.start();
-                    if (c->is_block) writer.write_block(c->blk, c->bout);
-                    else writer.write(c->recs);
+                    writer.write_block(c->blk, c->bout);
                     ck_write.stop();
                 }
             } catch (const std::exception &e) {
