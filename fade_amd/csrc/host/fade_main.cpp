@@ -31,7 +31,7 @@
 using namespace htsl;
 
 // the driver double-buffers: two of the ctx's slots per device (one batch computes while the previous one is collected)
-static constexpr size_t kSlotsInUse = 2;
+static size_t kSlotsInUse = 1;  // batches in flight per device (FADE_SLOTS=2: two; see annotate_main)
 static const char *kHeader = "Fragmentase Artifact Detection and Elimination\nversion: " FADE_VERSION "\n";
 
 static void print_full_help() {
@@ -513,6 +513,12 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         fadehip_params prm;
         fadehip_params_default(&prm);  // max_ref_len 2^20: any window the kernels can serve, whatever -w is
         prm.max_batch_reads = std::max(o.batch, 1);
+        // Batches in flight per device.  A device annotates a batch in about a millisecond and the host needs thirty for
+        // it, so one slot is enough here, and with one batch at a time nothing competes with the score pass for CUs: the
+        // run then needs three HSA queues fewer (a slot's two streams and the CU-masked one; each is a 173 MB context-save
+        // area to set up and to give back: ~80 ms per run in all).  FADE_SLOTS=2 restores the double-buffered form.
+        if (const char *sl = getenv("FADE_SLOTS")) kSlotsInUse = (size_t)std::max(1, std::min(atoi(sl), FADEHIP_NUM_SLOTS));
+        if (kSlotsInUse == 1) setenv("FADEHIP_TAIL_CUS", "0", 0);
         // the HIP runtime and the contexts come up on a helper thread while this one reads the FASTA
         std::string create_err;
         std::future<int> creating = std::async(std::launch::async, [&]() -> int {
@@ -628,15 +634,15 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             c->dev = (int)(seq_no % (size_t)ngpu);
             c->slot = (int)((seq_no / (size_t)ngpu) % kSlotsInUse);
             seq_no++;
+            ck_pack.start();
+            pack_chunk(*c, pool, blocks[(size_t)c->dev]);  // (while the device works on the batch before)
+            ck_pack.stop();
             // one batch per (device, slot): the batch that had this slot is fetched before the slot is handed the next
             while (!failed && inflight.size() >= (size_t)ngpu * kSlotsInUse) {
                 if (finish(std::move(inflight.front()))) failed = true;
                 inflight.pop_front();
             }
             if (failed) break;
-            ck_pack.start();
-            pack_chunk(*c, pool, blocks[(size_t)c->dev]);
-            ck_pack.stop();
             ck_submit.start();
             const int src = fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &c->b, o.floor_len, o.window);
             ck_submit.stop();

@@ -89,9 +89,10 @@ def test_cli_flag_errors_and_help():
     assert p.returncode == 0 and b"read count:\t600" in p.stderr
 
 
-def test_cli_gpus_2_on_one_device_equals_gpus_1(tmp_path):
-    """`fade annotate --gpus 2`: batches dealt round-robin to two fadehip contexts, two slots each, all driven by one
-    asynchronous host thread.  On a one-GPU box FADE_DEVICE_MAP=0,0 puts both contexts on device 0 (their stats are
+@pytest.mark.parametrize("slots", ["1", "2"])
+def test_cli_gpus_2_on_one_device_equals_gpus_1(tmp_path, slots):
+    """`fade annotate --gpus 2`: batches dealt round-robin to two fadehip contexts, one or two slots each (FADE_SLOTS:
+    one batch in flight per device is the default, two the double-buffered form), all driven by one asynchronous host thread.  On a one-GPU box FADE_DEVICE_MAP=0,0 puts both contexts on device 0 (their stats are
     then summed on the host: RCCL takes one rank per device).  Output identical to --gpus 1, --stats included."""
     from fade_amd import synth
     cfg, g, b = synth.make_config("C5", 6000, contig_len=150_000)
@@ -103,7 +104,7 @@ def test_cli_gpus_2_on_one_device_equals_gpus_1(tmp_path):
     fa.write_bytes(g.fasta_bytes())
     base = ["annotate", "--stats", "--batch", "500", "--min-length", "5", "-w", "100"]
     one = _run(base + [str(sam), str(fa)])
-    two = _run(base + ["--gpus", "2", str(sam), str(fa)], env=dict(os.environ, FADE_DEVICE_MAP="0,0"))
+    two = _run(base + ["--gpus", "2", str(sam), str(fa)], env=dict(os.environ, FADE_DEVICE_MAP="0,0", FADE_SLOTS=slots))
     assert one.returncode == 0 and two.returncode == 0, one.stderr.decode() + two.stderr.decode()
     strip_pg = lambda out: [l for l in out.decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
     assert strip_pg(one.stdout) == strip_pg(two.stdout) and len(strip_pg(one.stdout)) > 6000

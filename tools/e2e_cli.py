@@ -96,6 +96,8 @@ def main():
         return
     for t in [int(x) for x in os.environ.get("E2E_SWEEP", "").split(",") if x]:  # -t sweep of the BAM -> BAM leg only
         run("gpu_bam_to_bam_t%d" % t, fade, ["-b", bam, fa], out_gpu, t)
+        if os.environ.get("E2E_SLOTS2"):  # A/B: the double-buffered form of the driver
+            run("gpu_bam_to_bam_t%d_slots2" % t, fade, ["-b", bam, fa], out_gpu, t, env={"FADE_SLOTS": "2"})
     if os.environ.get("E2E_SWEEP"):
         json.dump(res, open(os.path.join(ROOT, "gpurun_out", "e2e_sweep.json"), "w"), indent=1)
         return
