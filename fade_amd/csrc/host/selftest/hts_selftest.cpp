@@ -135,6 +135,82 @@ int main() {
         CHECK(reader_rejects(bgzf_block(payload, -1, 0x7fffffff)));
         CHECK(reader_rejects(bgzf_block(payload, -1, 999)));  // ISIZE that the stream does not inflate to
     }
+    // ---- block reading equals record reading: SAM text and the BAM written from it (records that span BGZF blocks and
+    // gulps, batches that end in the middle of a block), and a block written back equals the records written back
+    {
+        const char *sam_path = "/tmp/hts_selftest.sam", *bam_path = "/tmp/hts_selftest.bam", *bam2_path = "/tmp/hts_selftest2.bam";
+        {
+            FILE *f = fopen(sam_path, "w");
+            fprintf(f, "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:100000\n@SQ\tSN:chr2\tLN:5000\n");
+            uint64_t lcg = 99;
+            auto rnd = [&](uint32_t m) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(lcg >> 33) % m; };
+            for (int i = 0; i < 30000; i++) {
+                const int lq = 20 + (int)rnd(180);
+                std::string seq, qual;
+                for (int k = 0; k < lq; k++) { seq += "ACGTN"[rnd(5)]; qual += (char)(33 + rnd(41)); }
+                const int clip = (int)rnd(3) ? 0 : 1 + (int)rnd(10);
+                char cig[64];
+                if (clip && clip < lq) snprintf(cig, sizeof cig, "%dS%dM", clip, lq - clip);
+                else snprintf(cig, sizeof cig, "%dM", lq);
+                fprintf(f, "read%d\t%d\tchr%d\t%u\t60\t%s\t*\t0\t0\t%s\t%s\tNM:i:%u\tXS:Z:tag%u\n", i, rnd(2) ? 16 : 0, 1 + (int)rnd(2),
+                        1 + rnd(4000), cig, seq.c_str(), qual.c_str(), rnd(5), rnd(1000));
+            }
+            fclose(f);
+        }
+        auto read_all = [&](const char *path, bool blocks, size_t batch, Header *hdr_out) {
+            Pool pool(3);
+            Reader rd(path, &pool);
+            if (hdr_out) *hdr_out = rd.header();
+            std::vector<std::vector<uint8_t>> recs;
+            if (blocks) {
+                RecordBlock blk;
+                while (rd.read_block(blk, batch))
+                    for (size_t i = 0; i < blk.size(); i++) recs.emplace_back(blk.view(i).bytes(), blk.view(i).bytes() + blk.view(i).nbytes());
+            } else {
+                std::vector<Rec> v;
+                while (rd.read_chunk(v, batch)) {
+                    for (auto &r : v) recs.push_back(r.d);
+                    v.clear();
+                }
+            }
+            return recs;
+        };
+        Header hdr;
+        const auto sam_recs = read_all(sam_path, false, 7001, &hdr);
+        const auto sam_blocks = read_all(sam_path, true, 4999, nullptr);
+        CHECK(sam_recs.size() == 30000 && sam_recs == sam_blocks);
+        {  // SAM -> BAM through the record writer, BAM -> BAM through the block writer
+            Pool pool(3);
+            FILE *fo = fopen(bam_path, "wb");
+            {
+                Reader rd(sam_path, &pool);
+                Writer w(fo, OutFmt::BAM, hdr, &pool);
+                std::vector<Rec> v;
+                while (rd.read_chunk(v, 6000)) {
+                    w.write(v);
+                    v.clear();
+                }
+                w.close();
+            }
+            fclose(fo);
+            fo = fopen(bam2_path, "wb");
+            {
+                Reader rd(bam_path, &pool);
+                Writer w(fo, OutFmt::BAM, hdr, &pool);
+                RecordBlock blk;
+                Writer::BlockOut none;
+                while (rd.read_block(blk, 3333)) w.write_block(blk, none);
+                w.close();
+            }
+            fclose(fo);
+        }
+        const auto bam_recs = read_all(bam_path, false, 5000, nullptr);
+        const auto bam_blocks = read_all(bam_path, true, 1234, nullptr);
+        const auto bam2_blocks = read_all(bam2_path, true, 100000, nullptr);
+        CHECK(bam_recs == sam_recs);
+        CHECK(bam_blocks == sam_recs);
+        CHECK(bam2_blocks == sam_recs);
+    }
     // ---- Pool: jobs from several threads at once; every index runs exactly once; an exception reaches its caller only
     {
         Pool pool(4);
