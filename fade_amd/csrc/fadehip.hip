@@ -1009,7 +1009,11 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     ctx->debug = getenv("FADEHIP_DEBUG") != nullptr;
     uint8_t table[256];
     fill_ascii_table(table);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_ascii_code), table, 256) != hipSuccess) {
+    // (everything the library enqueues goes to streams of its own: the null stream would be one more HSA queue, i.e. one
+    // more 173 MB context-save area in host memory, for two copies)
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMemcpyToSymbolAsync(HIP_SYMBOL(c_ascii_code), table, 256, 0, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->copy_stream) != hipSuccess) {
         set_err(ctx, FADEHIP_E_HIP, "hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(FADEHIP_E_HIP);
     }
@@ -1233,9 +1237,11 @@ int fadehip_genome_upload(fadehip_ctx *ctx, int32_t n_contigs, const int64_t *le
     if ((rc = reserve(ctx, ctx->genome, (size_t)(total / 2 + 16)))) return rc;
     if ((rc = reserve(ctx, ctx->contig_len, sizeof(int64_t) * n_contigs))) return rc;
     if ((rc = reserve(ctx, ctx->contig_base, sizeof(uint64_t) * n_contigs))) return rc;
-    HIPCHK(ctx, hipMemset(ctx->genome.p, 0, ctx->genome.cap));
-    HIPCHK(ctx, hipMemcpy(ctx->contig_len.p, lengths, sizeof(int64_t) * n_contigs, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->contig_base.p, ctx->h_contig_base.data(), sizeof(uint64_t) * n_contigs, hipMemcpyHostToDevice));
+    hipStream_t st = ctx->copy_stream;
+    HIPCHK(ctx, hipMemsetAsync(ctx->genome.p, 0, ctx->genome.cap, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->contig_len.p, lengths, sizeof(int64_t) * n_contigs, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->contig_base.p, ctx->h_contig_base.data(), sizeof(uint64_t) * n_contigs, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));  // (the two host arrays are pageable)
     const size_t CH = (size_t)64 << 20;  // staging chunk, even
     DevBuf stage, bad;
     if ((rc = reserve(ctx, stage, CH)) || (rc = reserve(ctx, bad, 4))) {
@@ -1243,21 +1249,22 @@ int fadehip_genome_upload(fadehip_ctx *ctx, int32_t n_contigs, const int64_t *le
         release(bad);
         return rc;
     }
-    hipError_t e = hipMemset(bad.p, 0, 4);
+    hipError_t e = hipMemsetAsync(bad.p, 0, 4, st);
     for (int c = 0; c < n_contigs && e == hipSuccess; c++) {
         for (int64_t off = 0; off < lengths[c] && e == hipSuccess; off += (int64_t)CH) {
             const size_t nb = (size_t)std::min<int64_t>((int64_t)CH, lengths[c] - off);
-            e = hipMemcpy(stage.p, seqs[c] + off, nb, hipMemcpyHostToDevice);
+            e = hipMemcpyAsync(stage.p, seqs[c] + off, nb, hipMemcpyHostToDevice, st);
             if (e != hipSuccess) break;
-            hipLaunchKernelGGL(pack_ascii_kernel, dim3((unsigned)((nb / 2 + 256) / 256)), dim3(256), 0, 0,
+            hipLaunchKernelGGL(pack_ascii_kernel, dim3((unsigned)((nb / 2 + 256) / 256)), dim3(256), 0, st,
                                (const uint8_t *)stage.p, (uint64_t)nb, ctx->h_contig_base[c] + (uint64_t)off,
                                (uint8_t *)ctx->genome.p, 1, (int *)bad.p);
             e = hipGetLastError();
-            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);  // the staging chunk is reused
         }
     }
     int h_bad = 0;
-    if (e == hipSuccess) e = hipMemcpy(&h_bad, bad.p, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     release(stage);
     release(bad);
     if (e != hipSuccess) return set_err(ctx, FADEHIP_E_HIP, "genome upload failed: %s", hipGetErrorString(e));

@@ -1,7 +1,13 @@
 """Which library call creates the large host mappings a finished run still holds (GPU box): counts the anonymous
 mappings >= 64 MB in /proc/self/smaps after each phase of one batch through the ABI."""
 import gc
+import os
 import sys
+
+LEAN = os.environ.get("PROBE_LEAN") == "1"  # what `fade annotate` does: one slot, no CU-masked stream
+if LEAN:
+    os.environ["FADEHIP_TAIL_CUS"] = "0"
+SLOTS = (0,) if LEAN else (0, 1)
 
 sys.path.insert(0, ".")
 import fade_amd
@@ -36,17 +42,17 @@ big("genome uploaded")
 sub, _ = ctx.clipped_only(b)
 pb = ctx.pinned_batch(sub)
 big("pinned batch")
-for slot in (0, 1):
+for slot in SLOTS:
     ctx.annotate_upload(slot, pb)
     big("slot %d uploaded" % slot)
     ctx.annotate_run(slot, cfg["floor_len"], cfg["window"])
     ctx.annotate_results(slot)
     big("slot %d run + results" % slot)
 for rep in range(3):
-    for slot in (0, 1):
+    for slot in SLOTS:
         ctx.annotate_upload(slot, pb)
         ctx.annotate_run(slot, cfg["floor_len"], cfg["window"])
-    for slot in (0, 1):
+    for slot in SLOTS:
         ctx.annotate_results(slot)
 big("six more runs")
 del pb
