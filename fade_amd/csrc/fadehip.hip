@@ -994,8 +994,8 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         ctx->two_pass = strcmp(kv, "twopass") == 0;
     }
     // Value ranges of the packed kernels at the longest query (512): the score pass keeps 16-bit keys of 32 * score
-    // (64 * score per row pair below the f16 infinity pattern for the row classes <= 14), DP values are 8 * score in
-    // int16 compared as f16 patterns.  FADE's scoring (match 2) fits everything; larger match scores take the path
+    // (per row pair and below the f16 infinity pattern 0x7c00: 64 * score for the row classes <= 14, i.e. scores <= 448,
+    // 32 * score for 16 .. 24, i.e. scores <= 768), DP values are 8 * score in int16 compared as f16 patterns.  FADE's scoring (match 2) fits everything; larger match scores take the path
     // whose ranges still hold: the single-pass packed kernel (32-bit keys) up to match 7, the int32 kernel beyond.
     if (ctx->prm.match > 2) ctx->two_pass = false;
     if (8 * (ctx->prm.match * FADEHIP_MAX_QUERY + ctx->prm.open + std::max(ctx->prm.match, 0)) >= 0x7c00) ctx->use_packed = false;
