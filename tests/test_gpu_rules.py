@@ -96,3 +96,38 @@ def test_rules_are_refused_where_they_do_not_exist(monkeypatch):
     with pytest.raises(fade_amd.FadeHipError) as e:
         fade_amd.Context(device=0, rules=DEFAULT & ~HDIR_F_E)  # the single-pass A/B kernels carry the default rules only
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("rules", [DEFAULT, DEFAULT & ~END_MIN_REF], ids=["default", "end_min_query_then_ref"])
+def test_full_length_matches_at_each_row_class(oracle, rules):
+    """The largest scores each key layout of the score pass has to hold (fadehip_kernels.hpp: 64 * score + 6 bits for
+    row classes <= 14, 32 * score + 5 bits and 16-step windows for 16 .. 24, one key per row for 32): the whole query
+    matches the window exactly, at window ends that fall on every position of a key window, twice (a tie between two
+    end cells of the same score), under both A.3 rules."""
+    rng = np.random.default_rng(2024)
+    qs, rs = [], []
+    for lq in (150, 160, 176, 192, 208, 223, 224, 225, 240, 255, 256, 257, 300, 319, 320, 321, 352, 383, 384, 385, 448, 511, 512):
+        for rep in range(6):
+            q = rng.integers(0, 4, lq)
+            q_txt = np.frombuffer(b"ACGT", np.uint8)[q]
+            lead = int(rng.integers(0, 70))
+            gap = int(rng.integers(1, 40))
+            flank = lambda n: np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)]
+            copies = [q_txt] if rep % 2 == 0 else [q_txt, flank(gap), q_txt]  # one exact copy, or two (equal end cells)
+            r_txt = np.concatenate([flank(lead)] + copies + [flank(int(rng.integers(0, 50)))])
+            qs.append(q_txt.tobytes())
+            rs.append(r_txt.tobytes())
+    qc, qo = concat([np.frombuffer(x, np.uint8) for x in qs])
+    rc, ro = concat([np.frombuffer(x, np.uint8) for x in rs])
+    c = fade_amd.Context(device=0, rules=rules)
+    try:
+        got = c.sw_batch_packed(qc, qo, rc, ro)
+    finally:
+        c.close()
+    exp, exp_ops = oracle.sw_batch(qc, qo, rc, ro, threads=8, max_ops=16, params=oracle.default_params(rules=rules))
+    for k in range(len(qs)):
+        g = tuple(int(got[k][f]) for f in ("score", "end_query", "end_ref", "beg_query", "beg_ref", "n_ops"))
+        assert g == tuple(int(x) for x in exp[k]), (k, len(qs[k]), g, exp[k])
+        assert g[0] == 2 * len(qs[k])
+        m = min(int(exp[k][5]), 16)
+        assert list(got[k]["ops"][:m]) == list(exp_ops[k][:m]), k
