@@ -1329,10 +1329,20 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     }
     const uint8_t *wt = reinterpret_cast<const uint8_t *>(wtab);
     constexpr int GROUP = (MODE == 1) ? KW / 4 : (1 << 30);  // blocks (of 4 steps) per key window
+    // (score pass: a block's four class words are fetched a block ahead, so that their LDS latency runs beside the block
+    // before: +0.5-1 % in tools/stream_probe.py, within noise in bench.py, no register more.  The traced passes have no
+    // registers to spare and are not issue-bound.)
+    uint64_t rw_next = *reinterpret_cast<const uint64_t *>(lref);
     for (int blk0 = 0; blk0 < n_blocks; blk0 += GROUP) {
     const int blk_end = (MODE == 1) ? min(n_blocks, blk0 + GROUP) : n_blocks;
     for (int blk = blk0; blk < blk_end; blk++) {
-        const uint64_t rw = *reinterpret_cast<const uint64_t *>(lref + blk * 4);
+        uint64_t rw;
+        if constexpr (MODE == 1) {
+            rw = rw_next;
+            rw_next = *reinterpret_cast<const uint64_t *>(lref + min(blk + 1, n_blocks - 1) * 4);
+        } else {
+            rw = *reinterpret_cast<const uint64_t *>(lref + blk * 4);
+        }
         uint32_t acc[R];
         if constexpr (MODE != 1) {
 #pragma unroll
