@@ -204,3 +204,23 @@ def test_cli_input_without_soft_clips(tmp_path):
         q = _run(["annotate"] + args + [str(empty), str(fa)])
         assert q.returncode == 0, q.stderr.decode()
     assert not [l for l in _run(["annotate", str(empty), str(fa)]).stdout.decode().splitlines() if not l.startswith("@")]
+
+
+def test_cli_reads_standard_input():
+    """`fade annotate - ref.fa`: SAM text and BAM bytes from a pipe (htslib's "-"), same records as from the files."""
+    tag = "anno_c5"
+    exp, floor_len, window = _expected(tag)
+    base = ["annotate", "--min-length", str(floor_len), "-w", str(window)]
+    sam, fa = os.path.join(GOLD, tag + ".sam"), os.path.join(GOLD, tag + ".fa")
+    from_file = _run(base + [sam, fa])
+    assert from_file.returncode == 0, from_file.stderr.decode()
+    piped = _run(base + ["-", fa], input=open(sam, "rb").read())
+    assert piped.returncode == 0, piped.stderr.decode()
+    strip_pg = lambda out: [l for l in out.decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
+    assert strip_pg(piped.stdout) == strip_pg(from_file.stdout)
+    bam = _run(base + ["-b", sam, fa])
+    assert bam.returncode == 0
+    piped_bam = _run(base + ["-", fa], input=bam.stdout)  # annotated BAM in through the pipe: tags replaced in place
+    assert piped_bam.returncode == 0, piped_bam.stderr.decode()
+    _, recs = samutil.parse_sam(piped_bam.stdout.decode())
+    _check_records(recs, exp)
