@@ -31,7 +31,7 @@
 using namespace htsl;
 
 // the driver double-buffers: two of the ctx's slots per device (one batch computes while the previous one is collected)
-static size_t kSlotsInUse = 1;  // batches in flight per device (FADE_SLOTS=2: two; see annotate_main)
+static size_t kSlotsInUse = 1;  // batches in flight per device: one, a second when the device falls behind (annotate_main)
 static const char *kHeader = "Fragmentase Artifact Detection and Elimination\nversion: " FADE_VERSION "\n";
 
 static void print_full_help() {
@@ -462,7 +462,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         // Stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack into a pinned block, upload + run (both return
         // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
         // pool; chunks keep their input order.  The device calls are asynchronous, so this one thread keeps every slot
-        // of every device busy: batch k goes to device k % N, slot (k / N) % kSlotsInUse.
+        // of every device busy: batch k goes to device k % N, the device's slots in turn.
         // the reader may run ahead by about two million records (0.6 GB inflated) while the GPU path comes up
         const size_t ahead = (size_t)std::max(2, std::min(8, (2 << 20) / std::max(o.batch, 1)));
         BoundedQueue<std::unique_ptr<Chunk>> q_in(ahead), q_out(3);
@@ -517,6 +517,10 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         // it, so one slot is enough here, and with one batch at a time nothing competes with the score pass for CUs: the
         // run then needs three HSA queues fewer (a slot's two streams and the CU-masked one; each is a 173 MB context-save
         // area to set up and to give back: ~80 ms per run in all).  FADE_SLOTS=2 restores the double-buffered form.
+        // If the host ever waits for the device (more than 15 % of the time since the first batch went out), the second slot
+        // is taken into use for the rest of the run: upload and run of a batch then overlap the one before.
+        const bool slots_fixed = getenv("FADE_SLOTS") != nullptr;
+        const double wait_frac = getenv("FADE_SLOT_WAIT") ? atof(getenv("FADE_SLOT_WAIT")) : 0.15;  // (tests: 0 forces the switch)
         if (const char *sl = getenv("FADE_SLOTS")) kSlotsInUse = (size_t)std::max(1, std::min(atoi(sl), FADEHIP_NUM_SLOTS));
         if (kSlotsInUse == 1) setenv("FADEHIP_TAIL_CUS", "0", 0);
         // the HIP runtime and the contexts come up on a helper thread while this one reads the FASTA
@@ -629,10 +633,14 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             return 0;
         };
         size_t seq_no = 0;
+        std::vector<int> next_slot((size_t)ngpu, 0);
+        std::chrono::steady_clock::time_point t_first;
         std::unique_ptr<Chunk> c;
         while (!failed && q_in.pop(c)) {
             c->dev = (int)(seq_no % (size_t)ngpu);
-            c->slot = (int)((seq_no / (size_t)ngpu) % kSlotsInUse);
+            c->slot = next_slot[(size_t)c->dev];
+            next_slot[(size_t)c->dev] = (c->slot + 1) % (int)kSlotsInUse;
+            if (seq_no == 0) t_first = std::chrono::steady_clock::now();
             seq_no++;
             ck_pack.start();
             pack_chunk(*c, pool, blocks[(size_t)c->dev]);  // (while the device works on the batch before)
@@ -652,6 +660,12 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 break;
             }
             inflight.push_back(std::move(c));
+            if (!slots_fixed && kSlotsInUse == 1 && seq_no >= 4 * (size_t)ngpu &&
+                ck_collect.t > wait_frac * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_first).count()) {
+                kSlotsInUse = 2;  // the batches in flight keep slot 0; the next one of every device takes slot 1
+                std::fill(next_slot.begin(), next_slot.end(), 1);
+                if (o.timing) fprintf(stderr, "[timing] the host waited for the device: two batches in flight per device from batch %zu on\n", seq_no);
+            }
         }
         while (!failed && !inflight.empty()) {
             if (finish(std::move(inflight.front()))) failed = true;

@@ -89,7 +89,7 @@ def test_cli_flag_errors_and_help():
     assert p.returncode == 0 and b"read count:\t600" in p.stderr
 
 
-@pytest.mark.parametrize("slots", ["1", "2"])
+@pytest.mark.parametrize("slots", ["1", "2", "switch"])
 def test_cli_gpus_2_on_one_device_equals_gpus_1(tmp_path, slots):
     """`fade annotate --gpus 2`: batches dealt round-robin to two fadehip contexts, one or two slots each (FADE_SLOTS:
     one batch in flight per device is the default, two the double-buffered form), all driven by one asynchronous host thread.  On a one-GPU box FADE_DEVICE_MAP=0,0 puts both contexts on device 0 (their stats are
@@ -104,11 +104,15 @@ def test_cli_gpus_2_on_one_device_equals_gpus_1(tmp_path, slots):
     fa.write_bytes(g.fasta_bytes())
     base = ["annotate", "--stats", "--batch", "500", "--min-length", "5", "-w", "100"]
     one = _run(base + [str(sam), str(fa)])
-    two = _run(base + ["--gpus", "2", str(sam), str(fa)], env=dict(os.environ, FADE_DEVICE_MAP="0,0", FADE_SLOTS=slots))
+    # "switch": the driver starts with one batch in flight per device and takes the second slot into use in mid-run
+    # (FADE_SLOT_WAIT=0: as if the host had waited for the device)
+    env = dict(os.environ, FADE_DEVICE_MAP="0,0", **({"FADE_SLOT_WAIT": "0"} if slots == "switch" else {"FADE_SLOTS": slots}))
+    two = _run(base + ["--gpus", "2", "--timing", str(sam), str(fa)], env=env)
+    assert (b"two batches in flight per device from batch" in two.stderr) == (slots == "switch")
     assert one.returncode == 0 and two.returncode == 0, one.stderr.decode() + two.stderr.decode()
     strip_pg = lambda out: [l for l in out.decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
     assert strip_pg(one.stdout) == strip_pg(two.stdout) and len(strip_pg(one.stdout)) > 6000
-    stats = lambda err: err.decode().split("read count:")[1]
+    stats = lambda err: "\n".join(l for l in err.decode().split("read count:")[1].splitlines() if not l.startswith("[timing]")) + "\n"
     assert stats(one.stderr) == stats(two.stderr) and stats(one.stderr).startswith("\t6000\n")
 
 
