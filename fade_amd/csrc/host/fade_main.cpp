@@ -22,6 +22,7 @@
 #include <deque>
 #include <functional>
 #include <future>
+#include <sched.h>
 #include <unistd.h>
 
 #ifndef FADE_VERSION
@@ -413,6 +414,35 @@ struct StageThreads {
     }
 };
 
+// Threads when -t is not given: the CPUs this process may actually use — its affinity mask and, in a container, the
+// cgroup's CPU quota (a 16-CPU share of a 256-thread host must not get 255 threads) — at most 64.
+static int default_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
+    auto quota = [](const char *path, const char *period_path) -> double {
+        FILE *f = fopen(path, "r");
+        if (!f) return 0;
+        char a[64] = "", b[64] = "";
+        const int got = fscanf(f, "%63s %63s", a, b);
+        fclose(f);
+        if (got < 1 || strcmp(a, "max") == 0 || atof(a) <= 0) return 0;
+        double period = got == 2 ? atof(b) : 0;
+        if (period_path) {
+            period = 0;
+            if (FILE *g = fopen(period_path, "r")) {
+                if (fscanf(g, "%lf", &period) != 1) period = 0;
+                fclose(g);
+            }
+        }
+        return period > 0 ? atof(a) / period : 0;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", nullptr);  // cgroup v2: "<quota|max> <period>"
+    if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");  // v1
+    if (q > 0) n = std::min(n, (int)(q + 0.999));
+    return std::max(1, std::min(n, 64));
+}
+
 // seconds since the kernel started this process (/proc/self/stat field 22 against /proc/uptime), for -T only
 static double since_process_start() {
     FILE *f = fopen("/proc/self/stat", "r");
@@ -439,9 +469,10 @@ static int annotate_main(const std::string &cl, const Opts &o) {
     StageClock ck_total, ck_fasta, ck_upload, ck_read, ck_pack, ck_submit, ck_collect, ck_tags, ck_write;
     ck_total.start();
     if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (annotate begins)\n", since_process_start());
+    if (o.timing) fprintf(stderr, "[timing] %d threads%s\n", o.threads > 0 ? o.threads : default_threads(), o.threads > 0 ? "" : " (default: affinity and cgroup quota)");
     // anno.d:18-19 (htslib log format)
     fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
-    const int nthreads = o.threads > 0 ? o.threads : std::max(1u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u);
+    const int nthreads = o.threads > 0 ? o.threads : default_threads();
     const int ngpu = std::max(1, o.gpus);
     std::vector<fadehip_ctx *> ctxs((size_t)ngpu, nullptr);
     std::vector<BlockPool> blocks((size_t)ngpu);
