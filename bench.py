@@ -53,7 +53,7 @@ def cpu_baseline(genome, cfg, full_batches, reps=3):
     per qualifying clip as the reference does, median of `reps`.  Checker code: never on the product path."""
     from oracle import pyoracle as O
     # one GPU's share of the host: the box exposes the whole node's threads, a 1-GPU job is sized to its share
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FADE_BENCH_CPU_THREADS", "32")))
+    cores = min(usable_cpus(), int(os.environ.get("FADE_BENCH_CPU_THREADS", "32")))
     G = O.GenomeHolder(genome.names, [a.tobytes() for a in genome.ascii_contigs()])
     n = sum(len(b["pos"]) for b in full_batches)
     times = []
@@ -74,6 +74,24 @@ def cpu_baseline(genome, cfg, full_batches, reps=3):
     return dict(value=n / dt, unit="reads/s", cores=cores, kind="port",
                 sample="%d reads of the same synthetic workload, median of %d passes (%.2f s wall = %.0f core-seconds each; striped "
                        "AVX2 int16 SW+trace oracle, one call per qualifying clip, on %d threads)" % (n, reps, dt, dt * cores, cores))
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the container's cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2: "<quota|max> <period>"
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                n = min(n, max(1, -(-q // period)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def spawn_ranks(args):
