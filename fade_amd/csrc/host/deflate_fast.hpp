@@ -573,8 +573,8 @@ private:
         }
         bw.finish();  // the header, to a byte boundary at most 7 bits short: the symbol loop has its own 64-bit writer
         // Symbols: code and length of a literal / length symbol come from one 32-bit table entry; the bit buffer is
-        // flushed without a branch (8 bytes stored, the pointer advanced by the whole bytes), after every two literals
-        // (<= 30 bits) or one match (<= 48 bits) on top of the <= 7 bits left over.
+        // flushed without a branch (8 bytes stored, the pointer advanced by the whole bytes), after every three literals
+        // (<= 45 bits) or one match (<= 48 bits) on top of the <= 7 bits left over.
         uint32_t lt[288];
         for (int i = 0; i < 288; i++) lt[i] = (uint32_t)lc[i] | ((uint32_t)ll[i] << 16);
         uint8_t *op = bw.p;
@@ -600,6 +600,13 @@ private:
                     buf |= (uint64_t)(e1 & 0xffffu) << cnt;
                     cnt += (int)(e1 >> 16);
                     i++;
+                    const uint32_t v2 = sym_[i];
+                    if (!(v2 & 0x8000u)) {
+                        const uint32_t e2 = lt[v2];
+                        buf |= (uint64_t)(e2 & 0xffffu) << cnt;
+                        cnt += (int)(e2 >> 16);
+                        i++;
+                    }
                 }
                 flush();
             } else {
