@@ -36,8 +36,17 @@ public:
         init_static();
     }
 
+    // What the caller knows about the layout of the bytes (efforts 1 and 2): from input offset `pos` on, the parser's count
+    // of probes in vain is `miss` — a large value where a stretch without repeats begins (a BAM record's bases and
+    // qualities: the skip-ahead starts at once instead of after skip_after probes), 0 where structure resumes (its tags and
+    // the next record's fixed fields: every position probed again, and no skip reaches across).  Sorted by pos.
+    struct Hint { uint32_t pos, miss; };
+    static constexpr uint32_t HINT_SKIP = 1u << 20;
+
     // Compresses in[0, n), n <= MAX_IN, into one final DEFLATE block at out; returns the byte count (<= bound(n)).
-    size_t compress(const uint8_t *in, size_t n, uint8_t *out) {
+    size_t compress(const uint8_t *in, size_t n, uint8_t *out, const Hint *hints = nullptr, size_t n_hints = 0) {
+        hints_ = hints;
+        n_hints_ = hints ? n_hints : 0;
 #ifdef FADE_DEFLATE_TIMING  // selftest only: where a block's time goes
         const auto t0 = std::chrono::steady_clock::now();
 #endif
@@ -71,8 +80,9 @@ private:
     //   zlib level 6   : 0.5908 / 0.3957 at 8-14 MB/s on the same core
     // The parse is 78 % of a block's time and nearly all of it is probes that find nothing, so efforts 1 and 2 probe
     // four positions per round and skip ahead in match-free stretches (parse_fast).  On an idle core of the GPU box's
-    // host, uniform qualities (tools/deflate_where.sh): effort 1 564 MB/s 0.5954, effort 2 462 MB/s 0.5729, effort 3
-    // 201 MB/s 0.5709, effort 4 86 MB/s 0.5691; zlib level 1 88 MB/s 0.6123, zlib level 6 40 MB/s 0.5915.
+    // host, uniform qualities (tools/deflate_where.sh): effort 1 564 MB/s 0.5954, effort 2 462 MB/s 0.5729 (with the BAM
+    // writer's layout hints: 642 MB/s 0.5741 and 636 MB/s 0.5696), effort 3 201 MB/s 0.5709, effort 4 86 MB/s 0.5691;
+    // zlib level 1 88 MB/s 0.6123, zlib level 6 40 MB/s 0.5915.
     static constexpr int MIN_MATCH = 5, MAX_MATCH = 258;
     static constexpr uint64_t MASK5 = 0xffffffffffull;
     static inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -204,9 +214,15 @@ private:
         extra_bits_ = 0;
         const size_t hash_end = n >= 8 ? n - 7 : 0;  // positions < hash_end can be hashed
         size_t p = 0, miss = 0, lit_start = 0;  // lit_start: first position after the last match
+        size_t hi = 0, next_hint = n_hints_ ? hints_[0].pos : (size_t)-1, region_miss = 0;
         while (p < n) {
             // rounds of four probes while nothing is found
             while (p + 4 <= hash_end) {
+                while (p >= next_hint) {  // the caller's layout hints
+                    miss = region_miss = hints_[hi].miss;
+                    hi++;
+                    next_hint = hi < n_hints_ ? hints_[hi].pos : (size_t)-1;
+                }
                 const uint64_t w = load64(in + p);
                 const uint64_t v0 = w & MASK5, v1 = (w >> 8) & MASK5, v2 = (w >> 16) & MASK5, v3 = w >> 24;
                 const uint32_t h0 = hash5<HB>(v0), h1 = hash5<HB>(v1), h2 = hash5<HB>(v2), h3 = hash5<HB>(v3);
@@ -246,6 +262,7 @@ private:
                     miss += 4;
                     size_t k = 4 * std::min<size_t>(miss / skip_after_, skip_cap_);
                     k = std::min(k, n - p);
+                    if (next_hint != (size_t)-1) k = std::min(k, next_hint > p ? next_hint - p : 0);  // never across a hint
                     for (size_t j = 0; j < k; j++) put_literal_counted(in[p + j], p + j);
                     p += k;
                 }
@@ -254,7 +271,7 @@ private:
             int len = 0, dist = 0;
             if (p < hash_end) len = find16<HB>(in, n, p, dist);
             if (len >= MIN_MATCH) {
-                miss = 0;
+                miss = region_miss ? skip_after_ : 0;  // (inside a hinted stretch the skip-ahead resumes mildly)
                 bool probed = false;  // whether p + 1 is already in the table
                 if (lazy_) {
                     // defer while the next position starts a strictly longer match
@@ -633,6 +650,8 @@ private:
         return (size_t)(op - out);
     }
 
+    const Hint *hints_ = nullptr;
+    size_t n_hints_ = 0;
     size_t skip_after_ = 0, skip_cap_ = 0;  // 0: every position is probed
     int effort_;
     bool lazy_;

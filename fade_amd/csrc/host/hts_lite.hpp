@@ -691,7 +691,8 @@ inline bool bgzf_use_zlib() {
 }
 
 // compress one block of <= 0xff00 bytes into out (appended); level 0 gives stored (uBAM)
-inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::vector<uint8_t> &out) {
+inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::vector<uint8_t> &out,
+                                const FastDeflate::Hint *hints = nullptr, size_t n_hints = 0) {
     uint8_t buf[0x10000 + 64];
     size_t clen;
     if (level > 0 && !bgzf_use_zlib()) {
@@ -700,7 +701,7 @@ inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::ve
             const char *e = getenv("FADE_BGZF_EFFORT");  // 1 fastest ... 4 smallest (deflate_fast.hpp)
             fd.reset(new FastDeflate(e ? atoi(e) : 2));
         }
-        clen = fd->compress(src, n, buf + 18);
+        clen = fd->compress(src, n, buf + 18, hints, n_hints);
     } else {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
@@ -1545,6 +1546,11 @@ public:
         for (size_t i = 0; i < n; i++)
             off[i + 1] = off[i] + 4 + ((!own.empty() && own[i] >= 0) ? o.owned[(size_t)own[i]].second.d.size() : (size_t)blk.len[i] + sfx_len(i));
         raw_.resize(off[n]);
+        // what the compressor is told about the bytes (FastDeflate::Hint): a record's bases and qualities hold no repeats
+        // worth probing for, its tags and the next record's fixed fields do
+        const size_t h0 = hints_.size();
+        const bool hinted = fmt_ == OutFmt::BAM && off[n] < 0xffffffffull;
+        if (hinted) hints_.resize(h0 + 2 * n);
         const size_t nt = (size_t)pool_->size() * 4;
         pool_->parallel_for(nt, [&](size_t t) {
             for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
@@ -1556,6 +1562,12 @@ public:
                 } else {
                     memcpy(dst + 4, blk.buf.data() + blk.off[i], blk.len[i]);
                     if (sfx_len(i)) memcpy(dst + 4 + blk.len[i], sfx_ptr(i), sfx_len(i));
+                }
+                if (hinted) {
+                    const RecView v(dst + 4, bs);  // (layout checked when the record was read / built)
+                    const size_t s0 = std::min<size_t>(v.seq_off(), bs), s1 = std::min<size_t>(v.aux_off(), bs);
+                    hints_[h0 + 2 * i] = {(uint32_t)(off[i] + 4 + s0), FastDeflate::HINT_SKIP};
+                    hints_[h0 + 2 * i + 1] = {(uint32_t)(off[i] + 4 + s1), 0};
                 }
             }
         }, CPU_COPY);
@@ -1585,17 +1597,38 @@ private:
         pool_->parallel_for(nblk, [&](size_t k) {
             const size_t o = k * B, n = std::min(B, raw_.size() - o);
             outs[k].reserve(n + 64);
-            bgzf_compress_block(raw_.data() + o, n, level, outs[k]);
+            // the block's share of the layout hints, relative to the block; a block that begins inside a hinted stretch
+            // opens with it
+            static thread_local std::vector<FastDeflate::Hint> bh;
+            bh.clear();
+            if (!hints_.empty()) {
+                auto it = std::lower_bound(hints_.begin(), hints_.end(), o, [](const FastDeflate::Hint &h, size_t v) { return h.pos < v; });
+                if (it != hints_.begin() && std::prev(it)->miss) bh.push_back({0, FastDeflate::HINT_SKIP});
+                for (; it != hints_.end() && it->pos < o + n; ++it) bh.push_back({(uint32_t)(it->pos - o), it->miss});
+            }
+            bgzf_compress_block(raw_.data() + o, n, level, outs[k], bh.data(), bh.size());
         }, CPU_DEFLATE);
         io_.put(std::move(outs));
         const size_t used = std::min(raw_.size(), nblk * B);
         raw_.drop_front(used);
+        // the hints follow the bytes that stay: positions move down by `used`; a stretch the cut went through reopens at 0
+        if (!hints_.empty()) {
+            auto it = std::lower_bound(hints_.begin(), hints_.end(), used, [](const FastDeflate::Hint &h, size_t v) { return h.pos < v; });
+            const bool inside = it != hints_.begin() && std::prev(it)->miss;
+            std::vector<FastDeflate::Hint> rest;
+            if (raw_.size()) {
+                if (inside) rest.push_back({0, FastDeflate::HINT_SKIP});
+                for (; it != hints_.end(); ++it) rest.push_back({(uint32_t)(it->pos - used), it->miss});
+            }
+            hints_.swap(rest);
+        }
     }
     FILE *f_;
     OutFmt fmt_;
     Header hdr_;
     Pool *pool_;
     RawBuf raw_;
+    std::vector<FastDeflate::Hint> hints_;  // layout hints for the bytes in raw_ (positions relative to its start, sorted)
     bool closed_ = false;
     OutThread io_;  // last member: started after, and joined before, everything it writes from
 };

@@ -2,6 +2,7 @@
 // Every block is compressed by FastDeflate (all effort levels), inflated by zlib and compared; with a file argument
 // the file is cut into 0xff00-byte BGZF-sized blocks and the sizes and rates of both compressors are printed.
 #include <zlib.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,37 @@ static bool roundtrip(FastDeflate &fd, const uint8_t *in, size_t n, size_t *clen
         return false;
     }
     if (clen_out) *clen_out = clen;
+    // layout hints (what the BGZF writer passes for BAM records) change which positions are probed, never the bytes that
+    // come back: random stretches marked as free of repeats, right or wrong
+    {
+        static uint64_t lcg = 424242;
+        std::vector<FastDeflate::Hint> hints;
+        uint32_t pos = 0;
+        bool skip = true;
+        while (pos < n) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            pos += (uint32_t)((lcg >> 33) % 400);
+            if (pos >= n) break;
+            hints.push_back({pos, skip ? FastDeflate::HINT_SKIP : 0u});
+            skip = !skip;
+        }
+        std::vector<uint8_t> out2(FastDeflate::bound(n) + 16), back2(n + 1);
+        const size_t c2 = fd.compress(in, n, out2.data(), hints.data(), hints.size());
+        z_stream z3;
+        memset(&z3, 0, sizeof z3);
+        inflateInit2(&z3, -15);
+        z3.next_in = out2.data();
+        z3.avail_in = (uInt)c2;
+        z3.next_out = back2.data();
+        z3.avail_out = (uInt)back2.size();
+        const int r3 = inflate(&z3, Z_FINISH);
+        const size_t got3 = z3.total_out;
+        inflateEnd(&z3);
+        if (c2 > FastDeflate::bound(n) || r3 != Z_STREAM_END || got3 != n || (n && memcmp(back2.data(), in, n) != 0)) {
+            fprintf(stderr, "round trip with layout hints failed (n=%zu, %zu hints)\n", n, hints.size());
+            return false;
+        }
+    }
     // the same stream, and zlib's own streams at several settings, through FastInflate
     static FastInflate fi;
     std::vector<uint8_t> mine(n + 1);
@@ -242,6 +274,33 @@ int main(int argc, char **argv) {
         fclose(f);
         const size_t B = 0xff00;
         std::vector<uint8_t> out(B + 1024);
+        // DEFLATE_HINTS=1: the payload is a BAM stream; give the compressor each record's bases + qualities as a stretch
+        // without repeats and its tags / the next record's fixed fields as structure (what the BGZF writer does)
+        std::vector<FastDeflate::Hint> hints;
+        if (getenv("DEFLATE_HINTS") && data.size() > 12 && memcmp(data.data(), "BAM\1", 4) == 0) {
+            auto rd32 = [&](size_t o) { int32_t v; memcpy(&v, data.data() + o, 4); return v; };
+            size_t o = 8 + (size_t)rd32(4);
+            const int nref = rd32(o);
+            o += 4;
+            for (int k = 0; k < nref; k++) o += 8 + (size_t)rd32(o);
+            while (o + 36 <= data.size()) {
+                const size_t bs = (size_t)rd32(o), rec = o + 4;
+                if (rec + bs > data.size()) break;
+                const size_t lname = data[rec + 8], ncig = (size_t)(data[rec + 12] | (data[rec + 13] << 8)), lseq = (size_t)rd32(rec + 16);
+                const size_t seq0 = rec + 32 + lname + 4 * ncig, qend = seq0 + (lseq + 1) / 2 + lseq;
+                hints.push_back({(uint32_t)seq0, FastDeflate::HINT_SKIP});
+                hints.push_back({(uint32_t)qend, 0});
+                o = rec + bs;
+            }
+            printf("%zu layout hints\n", hints.size());
+        }
+        std::vector<FastDeflate::Hint> bh;
+        auto block_hints = [&](size_t o, size_t n) {  // the hints of [o, o + n), block-relative; a block that starts inside a stretch opens with it
+            bh.clear();
+            auto it = std::lower_bound(hints.begin(), hints.end(), o, [](const FastDeflate::Hint &h, size_t v) { return h.pos < v; });
+            if (it != hints.begin() && std::prev(it)->miss) bh.push_back({0, FastDeflate::HINT_SKIP});
+            for (; it != hints.end() && it->pos < o + n; ++it) bh.push_back({(uint32_t)(it->pos - o), it->miss});
+        };
         const int NE = FastDeflate::MAX_EFFORT;
         for (int mode = 0; mode < (speed_only ? 2 : NE + 2); mode++) {  // FastDeflate effort 1..NE, then zlib 1 and zlib 6
             int sk_a = -1, sk_c = -1;  // DEFLATE_SKIP=after,cap overrides the effort's skip rule (experiments)
@@ -253,7 +312,10 @@ int main(int argc, char **argv) {
                 const size_t n = std::min(B, data.size() - o);
                 if (mode < NE) {
                     size_t c = 0;
-                    if (speed_only) c = fd.compress(data.data() + o, n, out.data());
+                    if (speed_only && !hints.empty()) {
+                        block_hints(o, n);
+                        c = fd.compress(data.data() + o, n, out.data(), bh.data(), bh.size());
+                    } else if (speed_only) c = fd.compress(data.data() + o, n, out.data());
                     else if (!roundtrip(fd, data.data() + o, n, &c)) return 1;
                     total += c;
                 } else total += zlib_block(data.data() + o, n, mode == NE ? 1 : 6, out.data(), out.size());
@@ -261,7 +323,10 @@ int main(int argc, char **argv) {
             double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (mode < NE) {  // time compression alone (the loop above also inflates)
                 const auto t1 = std::chrono::steady_clock::now();
-                for (size_t o = 0; o < data.size(); o += B) fd.compress(data.data() + o, std::min(B, data.size() - o), out.data());
+                for (size_t o = 0; o < data.size(); o += B) {
+                    if (!hints.empty()) block_hints(o, std::min(B, data.size() - o));
+                    fd.compress(data.data() + o, std::min(B, data.size() - o), out.data(), hints.empty() ? nullptr : bh.data(), bh.size());
+                }
                 dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
             }
 #ifdef FADE_DEFLATE_TIMING

@@ -25,3 +25,5 @@ g++ -O2 -std=c++17 -DFADE_DEFLATE_TIMING -o /tmp/deflate_speed fade_amd/csrc/hos
 for v in ${DEFLATE_SKIPS:-}; do
   (echo "== skip rule $v"; DEFLATE_SPEED_ONLY=1 DEFLATE_SKIP=$v /tmp/deflate_speed /tmp/p.payload | grep -B1 "effort [12]") | tee -a $R/gpurun_out/deflate_where.txt
 done
+# ... and with the layout hints the BGZF writer gives for BAM records (bases + qualities marked as free of repeats)
+(echo "== with layout hints"; DEFLATE_HINTS=1 DEFLATE_SPEED_ONLY=1 /tmp/deflate_speed /tmp/p.payload | grep -B1 "effort [12]") | tee -a $R/gpurun_out/deflate_where.txt
