@@ -41,7 +41,8 @@ public:
     // qualities: the skip-ahead starts at once instead of after skip_after probes), 0 where structure resumes (its tags and
     // the next record's fixed fields: every position probed again, and no skip reaches across).  Sorted by pos.
     struct Hint { uint32_t pos, miss; };
-    static constexpr uint32_t HINT_SKIP = 1u << 20;
+    static constexpr uint32_t HINT_SKIP = 1u << 20;  // nothing to find here (packed bases)
+    static constexpr uint32_t HINT_MILD = 1;         // probably nothing, but runs happen (qualities): the first skip step only
 
     // Compresses in[0, n), n <= MAX_IN, into one final DEFLATE block at out; returns the byte count (<= bound(n)).
     size_t compress(const uint8_t *in, size_t n, uint8_t *out, const Hint *hints = nullptr, size_t n_hints = 0) {
@@ -81,7 +82,7 @@ private:
     // The parse is 78 % of a block's time and nearly all of it is probes that find nothing, so efforts 1 and 2 probe
     // four positions per round and skip ahead in match-free stretches (parse_fast).  On an idle core of the GPU box's
     // host, uniform qualities (tools/deflate_where.sh): effort 1 564 MB/s 0.5954, effort 2 462 MB/s 0.5729 (with the BAM
-    // writer's layout hints: 642 MB/s 0.5741 and 636 MB/s 0.5696), effort 3 201 MB/s 0.5709, effort 4 86 MB/s 0.5691;
+    // writer's layout hints: 590 MB/s 0.5709 and 540 MB/s 0.5704), effort 3 201 MB/s 0.5709, effort 4 86 MB/s 0.5691;
     // zlib level 1 88 MB/s 0.6123, zlib level 6 40 MB/s 0.5915.
     static constexpr int MIN_MATCH = 5, MAX_MATCH = 258;
     static constexpr uint64_t MASK5 = 0xffffffffffull;
@@ -219,7 +220,7 @@ private:
             // rounds of four probes while nothing is found
             while (p + 4 <= hash_end) {
                 while (p >= next_hint) {  // the caller's layout hints
-                    miss = region_miss = hints_[hi].miss;
+                    miss = region_miss = hints_[hi].miss == HINT_MILD ? (uint32_t)skip_after_ : hints_[hi].miss;
                     hi++;
                     next_hint = hi < n_hints_ ? hints_[hi].pos : (size_t)-1;
                 }
@@ -271,7 +272,7 @@ private:
             int len = 0, dist = 0;
             if (p < hash_end) len = find16<HB>(in, n, p, dist);
             if (len >= MIN_MATCH) {
-                miss = region_miss ? skip_after_ : 0;  // (inside a hinted stretch the skip-ahead resumes mildly)
+                miss = region_miss = 0;  // (a repeat inside a hinted stretch: the hint was wrong for this one, e.g. runs of equal qualities)
                 bool probed = false;  // whether p + 1 is already in the table
                 if (lazy_) {
                     // defer while the next position starts a strictly longer match

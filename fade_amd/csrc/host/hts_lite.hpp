@@ -1546,11 +1546,11 @@ public:
         for (size_t i = 0; i < n; i++)
             off[i + 1] = off[i] + 4 + ((!own.empty() && own[i] >= 0) ? o.owned[(size_t)own[i]].second.d.size() : (size_t)blk.len[i] + sfx_len(i));
         raw_.resize(off[n]);
-        // what the compressor is told about the bytes (FastDeflate::Hint): a record's bases and qualities hold no repeats
-        // worth probing for, its tags and the next record's fixed fields do
+        // what the compressor is told about the bytes (FastDeflate::Hint): a record's packed bases hold no repeats worth
+        // probing for, its qualities rarely (runs), its tags and the next record's fixed fields do
         const size_t h0 = hints_.size();
         const bool hinted = fmt_ == OutFmt::BAM && off[n] < 0xffffffffull;
-        if (hinted) hints_.resize(h0 + 2 * n);
+        if (hinted) hints_.resize(h0 + 3 * n);
         const size_t nt = (size_t)pool_->size() * 4;
         pool_->parallel_for(nt, [&](size_t t) {
             for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
@@ -1565,9 +1565,10 @@ public:
                 }
                 if (hinted) {
                     const RecView v(dst + 4, bs);  // (layout checked when the record was read / built)
-                    const size_t s0 = std::min<size_t>(v.seq_off(), bs), s1 = std::min<size_t>(v.aux_off(), bs);
-                    hints_[h0 + 2 * i] = {(uint32_t)(off[i] + 4 + s0), FastDeflate::HINT_SKIP};
-                    hints_[h0 + 2 * i + 1] = {(uint32_t)(off[i] + 4 + s1), 0};
+                    const size_t s0 = std::min<size_t>(v.seq_off(), bs), q0 = std::min<size_t>(v.qual_off(), bs), s1 = std::min<size_t>(v.aux_off(), bs);
+                    hints_[h0 + 3 * i] = {(uint32_t)(off[i] + 4 + s0), FastDeflate::HINT_SKIP};      // packed bases: nothing to find
+                    hints_[h0 + 3 * i + 1] = {(uint32_t)(off[i] + 4 + q0), FastDeflate::HINT_MILD};  // qualities: runs happen
+                    hints_[h0 + 3 * i + 2] = {(uint32_t)(off[i] + 4 + s1), 0};                       // tags, then the next record's fixed fields
                 }
             }
         }, CPU_COPY);
@@ -1603,7 +1604,7 @@ private:
             bh.clear();
             if (!hints_.empty()) {
                 auto it = std::lower_bound(hints_.begin(), hints_.end(), o, [](const FastDeflate::Hint &h, size_t v) { return h.pos < v; });
-                if (it != hints_.begin() && std::prev(it)->miss) bh.push_back({0, FastDeflate::HINT_SKIP});
+                if (it != hints_.begin() && std::prev(it)->miss) bh.push_back({0, std::prev(it)->miss});
                 for (; it != hints_.end() && it->pos < o + n; ++it) bh.push_back({(uint32_t)(it->pos - o), it->miss});
             }
             bgzf_compress_block(raw_.data() + o, n, level, outs[k], bh.data(), bh.size());
@@ -1614,10 +1615,10 @@ private:
         // the hints follow the bytes that stay: positions move down by `used`; a stretch the cut went through reopens at 0
         if (!hints_.empty()) {
             auto it = std::lower_bound(hints_.begin(), hints_.end(), used, [](const FastDeflate::Hint &h, size_t v) { return h.pos < v; });
-            const bool inside = it != hints_.begin() && std::prev(it)->miss;
+            const uint32_t inside = it != hints_.begin() ? std::prev(it)->miss : 0;
             std::vector<FastDeflate::Hint> rest;
             if (raw_.size()) {
-                if (inside) rest.push_back({0, FastDeflate::HINT_SKIP});
+                if (inside) rest.push_back({0, inside});
                 for (; it != hints_.end(); ++it) rest.push_back({(uint32_t)(it->pos - used), it->miss});
             }
             hints_.swap(rest);

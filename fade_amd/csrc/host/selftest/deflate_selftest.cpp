@@ -274,8 +274,9 @@ int main(int argc, char **argv) {
         fclose(f);
         const size_t B = 0xff00;
         std::vector<uint8_t> out(B + 1024);
-        // DEFLATE_HINTS=1: the payload is a BAM stream; give the compressor each record's bases + qualities as a stretch
-        // without repeats and its tags / the next record's fixed fields as structure (what the BGZF writer does)
+        // DEFLATE_HINTS=2: the payload is a BAM stream; give the compressor each record's layout as the BGZF writer does
+        // (packed bases: nothing to find; qualities: mild; tags and the next record's fixed fields: structure).  =1: bases
+        // and qualities as one stretch without repeats
         std::vector<FastDeflate::Hint> hints;
         if (getenv("DEFLATE_HINTS") && data.size() > 12 && memcmp(data.data(), "BAM\1", 4) == 0) {
             auto rd32 = [&](size_t o) { int32_t v; memcpy(&v, data.data() + o, 4); return v; };
@@ -289,6 +290,7 @@ int main(int argc, char **argv) {
                 const size_t lname = data[rec + 8], ncig = (size_t)(data[rec + 12] | (data[rec + 13] << 8)), lseq = (size_t)rd32(rec + 16);
                 const size_t seq0 = rec + 32 + lname + 4 * ncig, qend = seq0 + (lseq + 1) / 2 + lseq;
                 hints.push_back({(uint32_t)seq0, FastDeflate::HINT_SKIP});
+                if (getenv("DEFLATE_HINTS")[0] != '1') hints.push_back({(uint32_t)(seq0 + (lseq + 1) / 2), FastDeflate::HINT_MILD});
                 hints.push_back({(uint32_t)qend, 0});
                 o = rec + bs;
             }
@@ -298,7 +300,7 @@ int main(int argc, char **argv) {
         auto block_hints = [&](size_t o, size_t n) {  // the hints of [o, o + n), block-relative; a block that starts inside a stretch opens with it
             bh.clear();
             auto it = std::lower_bound(hints.begin(), hints.end(), o, [](const FastDeflate::Hint &h, size_t v) { return h.pos < v; });
-            if (it != hints.begin() && std::prev(it)->miss) bh.push_back({0, FastDeflate::HINT_SKIP});
+            if (it != hints.begin() && std::prev(it)->miss) bh.push_back({0, std::prev(it)->miss});
             for (; it != hints.end() && it->pos < o + n; ++it) bh.push_back({(uint32_t)(it->pos - o), it->miss});
         };
         const int NE = FastDeflate::MAX_EFFORT;

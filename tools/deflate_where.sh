@@ -26,4 +26,4 @@ for v in ${DEFLATE_SKIPS:-}; do
   (echo "== skip rule $v"; DEFLATE_SPEED_ONLY=1 DEFLATE_SKIP=$v /tmp/deflate_speed /tmp/p.payload | grep -B1 "effort [12]") | tee -a $R/gpurun_out/deflate_where.txt
 done
 # ... and with the layout hints the BGZF writer gives for BAM records (bases + qualities marked as free of repeats)
-(echo "== with layout hints"; DEFLATE_HINTS=1 DEFLATE_SPEED_ONLY=1 /tmp/deflate_speed /tmp/p.payload | grep -B1 "effort [12]") | tee -a $R/gpurun_out/deflate_where.txt
+(echo "== with layout hints"; DEFLATE_HINTS=2 DEFLATE_SPEED_ONLY=1 /tmp/deflate_speed /tmp/p.payload | grep -B1 "effort [12]") | tee -a $R/gpurun_out/deflate_where.txt
