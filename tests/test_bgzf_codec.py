@@ -137,3 +137,43 @@ def test_reader_rejects_a_record_whose_fields_overrun_it(tmp_path):
     bad.write_bytes(bgzf(payload))
     q = subprocess.run([FADE, "out", "-t", "1", str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert q.returncode != 0 and b"corrupt BAM record" in q.stderr
+
+
+def test_block_writer_with_layout_hints(tmp_path):
+    """The path `fade annotate` writes through (Writer::write_block: records framed in place, layout hints to the
+    compressor — packed bases skipped, qualities probed mildly) on qualities with long runs, where wrong hints would cost
+    most: the payload must come back byte for byte, and the file must not be larger than zlib level 6's."""
+    tools = os.path.join(ROOT, "tools")
+    subprocess.run(["make", "-s", "-C", tools, "sam2bam"], check=True, timeout=600)
+    rng = np.random.default_rng(7)
+    sam = tmp_path / "runny.sam"
+    with open(sam, "w") as f:
+        f.write("@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000000\n")
+        for i in range(20000):
+            lq = int(rng.integers(100, 151))
+            seq = "".join("ACGT"[k] for k in rng.integers(0, 4, lq))
+            change = rng.random(lq) < 0.08
+            vals = rng.choice([2, 11, 25, 37], lq, p=[0.05, 0.1, 0.15, 0.7])
+            q, cur = [], 37
+            for k in range(lq):
+                if change[k]:
+                    cur = int(vals[k])
+                q.append(chr(33 + cur))
+            f.write("read%d\t0\tchr1\t%d\t60\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\n" % (i, int(rng.integers(1, 900000)), lq, seq, "".join(q),
+                                                                              int(rng.integers(0, 4))))
+    outs = {}
+    for codec in ("fast", "zlib"):
+        p = subprocess.run([os.path.join(tools, "sam2bam"), str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                           env=dict(os.environ, FADE_BGZF_CODEC=codec))
+        assert p.returncode == 0, p.stderr.decode()
+        outs[codec] = p.stdout
+    assert b"".join(_bgzf_blocks(outs["fast"])) == b"".join(_bgzf_blocks(outs["zlib"]))
+    assert len(outs["fast"]) <= 1.0 * len(outs["zlib"]), (len(outs["fast"]), len(outs["zlib"]))
+    # and the records are the ones `fade out` (the per-record reader / writer) makes of the same SAM
+    q = subprocess.run([FADE, "out", "-b", "-t", "4", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode == 0
+    a, b = gzip.decompress(outs["fast"]), gzip.decompress(q.stdout)
+    la, lb = int.from_bytes(a[4:8], "little"), int.from_bytes(b[4:8], "little")
+    skip = lambda x, l: x[8 + l:]  # (the header texts differ by the @PG line `fade out` adds)
+    ra, rb = skip(a, la), skip(b, lb)
+    assert ra[ra.index(b"read0\0") - 36:] == rb[rb.index(b"read0\0") - 36:]
