@@ -810,13 +810,13 @@ static bool parse_cigar_string(const std::string &s, std::vector<uint32_t> &ops)
 static int extract_main(const std::string &cl, const Opts &o) {
     fprintf(stderr, "[W::fade extract] Output SAM/BAM will not be sorted\n");  // remap.d:13
     const int nthreads = o.threads > 0 ? o.threads : 2;
-    Pool pool(nthreads), wpool(nthreads);
+    Pool pool(nthreads);  // (reader and writer share it)
     try {
         Reader reader(o.pos[1], &pool);  // remap.d:17
         Header hdr = reader.header();
         hdr.add_pg("fade-extract", "fade", FADE_VERSION, cl);  // remap.d:18-26
         const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;
-        Writer writer(stdout, fmt, hdr, &wpool);
+        Writer writer(stdout, fmt, hdr, &pool);
         static const uint8_t comp[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
         std::vector<Rec> in, out;
         for (;;) {
@@ -1081,13 +1081,13 @@ static void clip_read(Rec &rec, uint32_t rsv) {
 // filter.d:169-268
 static int out_main(const std::string &cl, const Opts &o) {
     const int nthreads = o.threads > 0 ? o.threads : 2;
-    Pool pool(nthreads), wpool(nthreads);
+    Pool pool(nthreads);  // (reader and writer share it)
     try {
         Reader reader(o.pos[1], &pool);
         Header hdr = reader.header();
         hdr.add_pg("fade-extract", "fade", FADE_VERSION, cl);  // filter.d:173-180 (the reference reuses this ID)
         const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;
-        Writer writer(stdout, fmt, hdr, &wpool);
+        Writer writer(stdout, fmt, hdr, &pool);
         OutStats stats;
         std::vector<Rec> in, out;
         auto next_chunk = [&]() { in.clear(); return reader.read_chunk(in, 65536) > 0; };
