@@ -5,12 +5,17 @@
 A step = the whole configuration once: 10 DISTINCT batches of 1 M reads each (10 M reads) streamed through the C ABI
 the way the `fade` driver does — pinned batch block -> fadehip_annotate_upload (one hipMemcpyAsync) -> fadehip_annotate_run
 (asynchronous: gate, score pass, selection, device-planned traced pass, traceback, D2H of the results) ->
-fadehip_annotate_results — with several slots in flight, all driven by one host thread.  Records that anno.d:61-65 gives
-rs = 0 outright (unmapped, no S op) are left out of the batches by the packing step, as the driver's reader threads do;
-they are counted in `value` (they are reads the path has annotated) and in the device's read_count.
-Each batch's upload is issued right after the previous run of its slot (the ABI's prefetching upload), so H2D, kernels and
-D2H of different batches overlap.  `value` is that streamed, PCIe-inclusive rate; `value_resident` is the same path with
-the batches already in HBM.
+fadehip_annotate_results — with several slots in flight, all driven by one host thread.
+
+`value` counts only work done inside the clock: EVERY record of the 10 M is sent to the device in every step and the
+device's gate kernel does anno.d:61-65 (unmapped / no S op -> rs = 0) for all of them.  What the packing step (outside
+the clock: it is the reader's job, htslib's in the reference) does is what a BAM decoder does anyway: it lays the records'
+fixed fields and CIGARs out as the batch block, and copies the packed bases only of records that have a soft clip (the
+only ones anno.d:61 lets through), passing the block's bounds along (ABI 3).  Nothing is filtered out.
+`value_prefiltered` is round 2's figure (records without an S op left out of the batches by the packing step, counted via
+n_skipped); `value_resident` the all-records path with the batches already in HBM.  The `e2e` block is the whole program
+on a 10 M-read BAM file: `fade annotate -b` (GPU) and tools/cpu_annotate (the same reader / writer around the CPU oracle)
+on the same host threads, wall time of the process.
 
 One process per GPU: `python bench.py --gpus N` spawns N ranks itself (before anything touches the GPU); under
 torchrun it is one of the ranks.  Reads shard per rank with no data-path collective; the only collective is the final
@@ -28,23 +33,31 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# int VALU issue: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured by fade_amd/csrc/bench/valu_peak.hip: one
-# wave-instruction per 4 cycles per SIMD for v_pk_*, v_add/max, v_bfe, DPP moves alike)
+# Integer / packed-16 VALU issue ceiling: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-instr/s.  It is the rate
+# fade_amd/csrc/bench/valu_peak.hip measures for the opcodes the sweep is made of (v_pk_*16, v_perm, DPP moves, int32
+# add / max: one wave-instruction per ~4.4 cycles per SIMD with 8 waves, profiles/r01_valu_peak.txt).  Plain f32 VALU
+# issues at twice that on this chip (2.6 cycles measured, 78.6 T nominal "SIMD-32"); `frac_of_f32_issue_peak` prices the
+# kernel against that ceiling too, although no integer or packed-16 opcode reaches it.
 VALU_PEAK_TLANE = 39.3
+VALU_F32_PEAK_TLANE = 78.6
 STAT_NAMES = ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"]
 BATCHES_PER_STEP = 10
+ROUND = "r03"
 
 
 def pmc_summary(config):
     """The committed rocprofv3 --pmc passes of this build and config (profiles/collect.sh + summarize_pmc.py), or None.
     Replayed, not measured in this run: the fields that come from it carry `source`."""
-    path = os.path.join(ROOT, "profiles", "r02_%s_pmc_summary.json" % config)
-    try:
-        return json.load(open(path)), os.path.relpath(path, ROOT)
-    except (OSError, ValueError):
-        return None, None
+    for rnd in (ROUND, "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (rnd, config))
+        try:
+            return json.load(open(path)), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(genome, cfg, full_batches, reps=3):
@@ -72,6 +85,8 @@ def cpu_baseline(genome, cfg, full_batches, reps=3):
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
     return dict(value=n / dt, unit="reads/s", cores=cores, kind="port",
+                work="every record of the sample goes through annotateTask: the anno.d:61-65 check for all of them, one SW call per "
+                     "qualifying clip — the same work `value` times on the device (the packing of the batch blocks is outside both clocks)",
                 sample="%d reads of the same synthetic workload, median of %d passes (%.2f s wall = %.0f core-seconds each; striped "
                        "AVX2 int16 SW+trace oracle, one call per qualifying clip, on %d threads)" % (n, reps, dt, dt * cores, cores))
 
@@ -108,19 +123,51 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
+def e2e_legs(bam, fa, n_reads, cfg, threads, tmp):
+    """The whole program on a BAM file, GPU driver and CPU comparator on the same threads: wall time of each process
+    (start-up, FASTA load and genome upload, BGZF inflate, annotate, tags, BGZF deflate, exit), best of 2 runs each."""
+    fade = os.path.join(ROOT, "fade_amd", "fade")
+    cpu = os.path.join(ROOT, "tools", "cpu_annotate")
+    res = {}
+
+    def run(tag, exe, reps):
+        best = None
+        out = os.path.join(tmp, "bench_e2e.%s.bam" % tag)
+        for _ in range(reps):
+            if os.path.exists(out):
+                os.remove(out)  # (truncating the previous output is not part of the run)
+            t1 = time.perf_counter()
+            with open(out, "wb") as fo:
+                p = subprocess.run([exe, "annotate", "--timing", "-t", str(threads), "-w", str(cfg["window"]), "--min-length",
+                                    str(cfg["floor_len"]), "-b", bam, fa], stdout=fo, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t1
+            if p.returncode != 0:
+                return dict(error=p.stderr.decode(errors="replace")[-400:])
+            r = dict(seconds=dt, reads_per_s=n_reads / dt, out_bytes=os.path.getsize(out),
+                     timing=[l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]")][:8])
+            if best is None or r["seconds"] < best["seconds"]:
+                best = r
+        os.remove(out)
+        return best
+
+    res["gpu"] = run("gpu", fade, 2)
+    res["cpu"] = run("cpu", cpu, 1)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--batch-reads", type=int, default=1_000_000, help="reads per batch; a step is %d batches" % BATCHES_PER_STEP)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (fade annotate / tools/cpu_annotate on a BAM file)")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000)
     ap.add_argument("--slots", type=int, default=2, help="batches in flight per GPU")
-    ap.add_argument("--full-batches", action="store_true", help="send every record (no anno.d:61-65 filter in the packing step)")
-    ap.add_argument("--all-sent", action="store_true", help="also measure the secondary figure with every record sent "
-                    "(value_all_records_sent: nothing left to the packing step, PCIe-bound)")
-    ap.add_argument("--no-all-sent", action="store_true", help=argparse.SUPPRESS)  # (the default now; accepted for old command lines)
+    ap.add_argument("--synth", default="native", choices=["native", "numpy"], help="generator of the synthetic reads "
+                    "(tools/synthgen.cpp on all host threads, or fade_amd/synth.py: the same laws, another random stream)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -150,27 +197,56 @@ def main():
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
 
     cfg = synth.config(args.config)
-    genome = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    t_setup = {}
+    t0 = time.perf_counter()
+    if args.synth == "native":
+        import synthgen as sg
+        genome = sg.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    else:
+        genome = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    t_setup["genome"] = time.perf_counter() - t0
     n_slots = max(1, min(int(args.slots), fade_amd._lib.NUM_SLOTS))
     ctx = fade_amd.Context(device=local, max_batch_reads=max(args.batch_reads, 1 << 20))
     ctx.genome_upload(genome.names, genome.ascii_contigs())
-    # per-GPU record range: each rank owns its own shard of the reads (seed 100 (k + 1) + rank)
-    full, pinned, pinned_all = [], [], []
-    t_gen = time.perf_counter()
+    do_cpu = rank == 0 and not args.no_cpu and world == 1
+    do_e2e = rank == 0 and not args.no_e2e and world == 1 and args.synth == "native"
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    bam_path, fa_path = os.path.join(tmp, "bench_e2e.bam"), os.path.join(tmp, "bench_e2e.fa")
+    bam_writer = None
+    if do_e2e:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s"])
+        genome.write_fasta(fa_path)
+        bam_writer = sg.BamWriter(bam_path, genome)
+    # per-GPU record range: each rank owns its own shard of the reads (stream 100 (k + 1) + rank)
+    full, pinned, pinned_pre = [], [], []
+    t_gen = t_pack = t_bam = 0.0
+    e2e_written = 0
     for k in range(BATCHES_PER_STEP):
-        b = synth.make_reads(genome, args.batch_reads, 100 * (k + 1) + rank, **cfg)
-        b.pop("_truth", None)
-        if args.full_batches:
-            sub = dict(b)
+        t0 = time.perf_counter()
+        if args.synth == "native":
+            b = sg.make_reads(genome, args.batch_reads, 100 * (k + 1) + rank, cfg)
         else:
-            sub, _ = ctx.clipped_only(b)  # what the driver's reader threads do while they pack a batch
-        pinned.append(ctx.pinned_batch(sub))
-        if args.all_sent and not args.full_batches and k < 4:
-            allrec = dict(b)  # every record, for the secondary figure: nothing left to the packing step
-            allrec["ref_span_bound"] = sub["ref_span_bound"]
-            pinned_all.append(ctx.pinned_batch(allrec))
-        full.append(b if (rank == 0 and not args.no_cpu and world == 1) else None)
-    t_gen = time.perf_counter() - t_gen
+            b = synth.make_reads(genome, args.batch_reads, 100 * (k + 1) + rank, **cfg)
+            b.pop("_truth", None)
+        t1 = time.perf_counter()
+        # what a packing thread hands over: every record, bases only where the device can align, the block's bounds
+        allrec = sg.with_bounds(b) if args.synth == "native" else ctx.with_bounds(b)
+        pinned.append(ctx.pinned_batch(allrec))
+        sub, _ = ctx.clipped_only(b)  # round 2's form: the records anno.d:61-65 settles left out by the packing step
+        pinned_pre.append(ctx.pinned_batch(sub))
+        t2 = time.perf_counter()
+        if bam_writer is not None and e2e_written < args.e2e_reads:
+            m = min(len(b["pos"]), args.e2e_reads - e2e_written)
+            bam_writer.write(b if m == len(b["pos"]) else synth.take(b, np.arange(m)), e2e_written // 2)
+            e2e_written += m
+        t3 = time.perf_counter()
+        t_gen, t_pack, t_bam = t_gen + t1 - t0, t_pack + t2 - t1, t_bam + t3 - t2
+        full.append(b if (do_cpu and k < 2) else None)  # the CPU leg's bounded sample: 2 M reads
+    if bam_writer is not None:
+        t0 = time.perf_counter()
+        bam_writer.close()
+        t_bam += time.perf_counter() - t0
+    t_setup.update(synthetic_batches=t_gen, pack_pinned_blocks=t_pack, e2e_bam=t_bam)
     floor_len, window = cfg["floor_len"], cfg["window"]
 
     def barrier():
@@ -178,7 +254,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n_steps, resident, profs=None, pinned=pinned):
+    def run_steps(n_steps, resident, profs=None, pinned=pinned, n_slots=n_slots):
         """n_steps x BATCHES_PER_STEP batches through the slots; returns the summed stats.d counters."""
         stats = np.zeros(8, np.int64)
         busy = [False] * n_slots
@@ -213,7 +289,7 @@ def main():
                 finish((seq + slot) % n_slots)
         return stats
 
-    # ---- the measured metric: streamed steps
+    # ---- the measured metric: streamed steps, every record sent
     run_steps(args.warmup, False)
     barrier()
     profs = []
@@ -222,49 +298,47 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # ---- the same path with the inputs already in HBM (the slots keep the batches they were last handed)
-    res_steps = max(1, min(args.steps, 5))
+    res_steps = max(1, min(args.steps, 20))
     run_steps(1, True)
     barrier()
     t0 = time.perf_counter()
     run_steps(res_steps, True)
     barrier()
     dt_res = time.perf_counter() - t0
-    # ---- secondary: every record sent (the packing step leaves nothing out): 10x the bytes over PCIe, 10x the records
-    # through upload's validation pass and the gate
-    dt_all = None
-    if pinned_all:
-        run_steps(1, False, pinned=pinned_all)
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(2, False, pinned=pinned_all)
-        barrier()
-        dt_all = time.perf_counter() - t0
-    # ---- the dominant kernel alone on the device (one slot, serial): its HIP-event time without a neighbour
+    # ---- round 2's figure: records without an S op left out by the packing step (a tenth of the records cross PCIe)
+    run_steps(1, False, pinned=pinned_pre)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(res_steps, False, pinned=pinned_pre)
+    barrier()
+    dt_pre = time.perf_counter() - t0
+    # ---- the dominant kernel alone on the device (one slot, serial): the HIP-event times the roofline is priced with
     solo = []
-    for k in range(3):
-        ctx.annotate_upload(0, pinned[k])
+    for k in range(2 * BATCHES_PER_STEP + 2):
+        ctx.annotate_upload(0, pinned[k % BATCHES_PER_STEP])
         ctx.annotate_run(0, floor_len, window)
         ctx.annotate_results(0)
-        solo.append(ctx.last_profile(0))
+        if k >= 2:
+            solo.append(ctx.last_profile(0))
 
-    t = torch.tensor([dt, dt_res], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, dt_res, dt_pre], dtype=torch.float64, device=dev)
     st = torch.tensor(stats, dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(st, op=dist.ReduceOp.SUM)  # RCCL: the final stats reduction
-    dt_max, dt_res_max = (float(x) for x in t.tolist())
+    dt_max, dt_res_max, dt_pre_max = (float(x) for x in t.tolist())
     reads_per_step = args.batch_reads * BATCHES_PER_STEP
     total_reads = reads_per_step * world * args.steps
 
     if rank == 0:
         R = fade_amd._lib.row_class(cfg["read_len"])
         kernel = "sw_pk_kernel<%d,1> (score pass)" % R
-        fwd = float(np.mean([p["forward_ms"] for p in profs]))        # every fourth launch of the timed region, slots sharing the device
-        fwd_solo = float(np.mean([p["forward_ms"] for p in solo[1:]]))  # launches that had the device to themselves
-        units = float(np.mean([p["alignments"] for p in profs]))
-        alg = float(np.mean([p["algorithmic_bytes"] for p in profs]))  # packed query + window + 16 + 64 per unit
+        fwd_streamed = float(np.mean([p["forward_ms"] for p in profs]))  # every fourth launch of the timed region, slots sharing the device
+        fwd = float(np.mean([p["forward_ms"] for p in solo]))            # launches that had the device to themselves
+        units = float(np.mean([p["alignments"] for p in solo]))
+        alg = float(np.mean([p["algorithmic_bytes"] for p in solo]))  # packed query + window + 16 + 64 per unit
         snap = float(np.mean([p["snapshot_bytes"] for p in profs]))
-        cells = float(np.mean([p["cells"] for p in profs]))
+        cells = float(np.mean([p["cells"] for p in solo]))
         achieved = alg / (fwd * 1e-3) / 1e9
         workload = "%s: %d x %d bp PE reads per GPU per step in %d distinct batches, -w %d, --min-length %d, p_softclip %.2f" % (
             args.config, reads_per_step, cfg["read_len"], BATCHES_PER_STEP, window, floor_len, cfg["p_sc"])
@@ -288,45 +362,67 @@ def main():
             "dtype": "int16",
             "data": "synthetic",
             "parity": "bit-exact vs the restated reference semantics (oracle/; unpinned: the reference has no tests or fixtures and cannot be built here)",
-            "value_is": "streamed: pinned host batch -> upload (1 hipMemcpyAsync) -> run -> results on the host, %d slots in flight, one host thread" % n_slots,
+            "value_is": "streamed, every record sent: pinned host batch of all %d records -> upload (1 hipMemcpyAsync) -> run (the device's gate does "
+                        "anno.d:61-65 for every record) -> results on the host, %d slots in flight, one host thread; the packing of the "
+                        "batch blocks (the BAM decoder's job) is outside the clock, as is the reference's htslib decode" % (reads_per_step, n_slots),
             "value_resident": reads_per_step * world * res_steps / dt_res_max,
-            "value_all_records_sent": None if dt_all is None else reads_per_step * 2 / dt_all,  # this rank's rate, per GPU
+            "value_prefiltered": reads_per_step * world * res_steps / dt_pre_max,
+            "value_prefiltered_is": "round 2's headline: the packing step leaves records without an S op out (n_skipped); not an all-work rate",
             "config": {"workload": workload, "batches_per_step": BATCHES_PER_STEP,
                        "records_sent_per_step": int(sum(p.n for p in pinned)),
                        "upload_bytes_per_step": int(sum(p.nbytes for p in pinned)),
+                       "records_with_bases_per_step": int(sum(p.c.n_with_seq for p in pinned)),
                        "alignments_per_batch": units, "dp_cells_per_batch": cells, "slots_in_flight": n_slots,
-                       "records_left_out": "unmapped or no S op (anno.d:61-65: rs = 0); counted in value and read_count" if not args.full_batches else "none"},
+                       "records_left_out": "none"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pk["hbm_bytes_per_launch"] if pk else None,
                          "traffic_source": pmc_path if pk else None,
                          "algorithmic_bytes_per_launch": alg, "units_per_launch": units,
                          "bytes_per_unit": alg / max(units, 1.0),
-                         "kernel_ms": fwd, "kernel_ms_alone_on_device": fwd_solo,
-                         "frac_with_snapshots": (alg + snap) / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms": fwd, "kernel_ms_is": "HIP events around the kernel on its stream, launches that had the device to themselves "
+                                                           "(one slot, serial; %d launches after the timed region)" % len(solo),
+                         "kernel_ms_streamed": fwd_streamed,
                          "snapshot_bytes_per_launch": snap,
-                         "gcups": cells / (fwd_solo * 1e-3) / 1e9},
+                         "gcups": cells / (fwd * 1e-3) / 1e9},
             # the kernel is integer-VALU issue bound, not HBM bound; instruction count from the committed PMC pass
             "roofline_valu": None if not pk else {
                 "bound": "valu_int_issue", "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s",
-                "achieved": pk["SQ_INSTS_VALU"] * 64 / (fwd_solo * 1e-3) / 1e12,
-                "frac": pk["SQ_INSTS_VALU"] * 64 / (fwd_solo * 1e-3) / 1e12 / VALU_PEAK_TLANE,
+                "peak_is": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz: the measured issue rate of the integer / packed-16 opcodes the sweep consists of "
+                           "(profiles/r01_valu_peak.txt), NOT the f32 rate (%.1f T: twice as fast, but no int or packed-16 opcode issues at it)" % VALU_F32_PEAK_TLANE,
+                "achieved": pk["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12,
+                "frac": pk["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12 / VALU_PEAK_TLANE,
+                "frac_of_f32_issue_peak": pk["SQ_INSTS_VALU"] * 64 / (fwd * 1e-3) / 1e12 / VALU_F32_PEAK_TLANE,
                 "valu_busy_frac_pmc": pk["valu_busy_frac"], "source": pmc_path + " (committed profile, not measured in this run)"},
-            "kernels_ms": {"gate": float(np.mean([p["gate_ms"] for p in solo[1:]])), "score_pass": fwd_solo,
-                           "after_score_pass": float(np.mean([p["traceback_ms"] for p in solo[1:]])),
-                           "whole_run": float(np.mean([p["total_ms"] for p in solo[1:]])), "measured": "one batch alone on the device"},
+            "kernels_ms": {"gate": float(np.mean([p["gate_ms"] for p in solo])), "score_pass": fwd,
+                           "after_score_pass": float(np.mean([p["traceback_ms"] for p in solo])),
+                           "whole_run": float(np.mean([p["total_ms"] for p in solo])), "measured": "one batch alone on the device"},
             "stats": {k: int(v) for k, v in zip(STAT_NAMES, st.tolist())},
-            "setup_s": {"synthetic_batches": t_gen},
+            "setup_s": t_setup,
         }
         assert out["stats"]["read_count"] == total_reads, (out["stats"], total_reads)
-        if not args.no_cpu and world == 1:
+    ctx.close()
+    if rank == 0:
+        if do_e2e:
+            e = e2e_legs(bam_path, fa_path, e2e_written, cfg, usable_cpus(), tmp)
+            g, c = e.get("gpu") or {}, e.get("cpu") or {}
+            out["e2e"] = {"what": "`fade annotate -b` BAM -> BAM on a %d-read file of this workload, wall time of the whole process, %d host threads; "
+                                  "cpu = tools/cpu_annotate: the same reader / writer / codec around the CPU oracle" % (e2e_written, usable_cpus()),
+                          "gpu_reads_per_s": g.get("reads_per_s"), "cpu_reads_per_s": c.get("reads_per_s"),
+                          "gpu_over_cpu": (g["reads_per_s"] / c["reads_per_s"]) if g.get("reads_per_s") and c.get("reads_per_s") else None,
+                          "gpu": g, "cpu": c}
+            for pth in (bam_path, fa_path):
+                if os.path.exists(pth):
+                    os.remove(pth)
+        else:
+            out["e2e"] = None
+        if do_cpu:
             cb = cpu_baseline(genome, cfg, [b for b in full if b is not None])
             cb["gpu_over_cpu"] = out["value"] / cb["value"]
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FADEHIP_LIB") or os.path.join(HERE, "libfadehip.so") 
 
 MAX_OPS = 16
 NUM_SLOTS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 RULES_DEFAULT = 0x7f
 REF_CONSUMING_OPS = (0, 2, 3, 7, 8)  # include/fadehip.h FADEHIP_REF_CONSUMING_OPS (dhtslib Cigar.alignedLength: M, D, N, =, X)
 ROW_CLASSES = (4, 6, 8, 10, 12, 14, 16, 20, 24, 32)  # query rows per lane of the wave kernels (fadehip_kernels.hpp class_rows)
@@ -61,7 +61,8 @@ class ReadBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p),
                 ("has_sa", C.c_void_p), ("l_seq", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar_ops", C.c_void_p),
                 ("seq_off", C.c_void_p), ("seq_packed", C.c_void_p), ("n_skipped", C.c_int32),
-                ("ref_span_bound", C.c_int32)]
+                ("ref_span_bound", C.c_int32), ("n_with_seq", C.c_int32), ("l_seq_min", C.c_int32),
+                ("l_seq_max", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AnnoOut(C.Structure):

@@ -116,9 +116,18 @@ class Context:
         b.n_reads = n
         for k, _ in self._ARRAYS:
             setattr(b, k, keep[k].ctypes.data)
+        self._hints(b, batch)
+        return b, keep, n
+
+    @staticmethod
+    def _hints(b, batch):
+        """What the caller knows about the batch travels with it (include/fadehip.h: n_skipped, ref_span_bound and the
+        ABI-3 bounds n_with_seq / l_seq_min / l_seq_max; see with_bounds)."""
         b.n_skipped = int(batch.get("n_skipped", 0))
         b.ref_span_bound = int(batch.get("ref_span_bound", 0))
-        return b, keep, n
+        b.n_with_seq = int(batch.get("n_with_seq", 0))
+        b.l_seq_min = int(batch.get("l_seq_min", 0))
+        b.l_seq_max = int(batch.get("l_seq_max", 0))
 
     def pinned_batch(self, batch):
         """The batch as ONE pinned block in the canonical layout (fadehip_batch_bytes / fadehip_batch_bind), what a
@@ -138,8 +147,7 @@ class Context:
             a = arrs[k]
             if a.nbytes:
                 C.memmove(getattr(b, k), a.ctypes.data, a.nbytes)
-        b.n_skipped = int(batch.get("n_skipped", 0))
-        b.ref_span_bound = int(batch.get("ref_span_bound", 0))
+        self._hints(b, batch)
         return PinnedBatch(b, n, ptr, nbytes)
 
     @staticmethod
@@ -179,6 +187,28 @@ class Context:
         out = dict(batch)
         out["seq_packed"] = np.asarray(batch["seq_packed"])[np.repeat(keep, so[1:] - so[:-1])]
         out["seq_off"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        return out
+
+    @staticmethod
+    def with_bounds(batch):
+        """What a packing thread knows when it has filled a block, passed along so that upload does no per-record host
+        work (ABI 3): every record is sent, the ones the device never aligns (unmapped, or no S op; anno.d:61) without
+        their bases; `ref_span_bound` = max cigar.alignedLength over the records that carry bases, `n_with_seq` their
+        number, `l_seq_min` / `l_seq_max` their shortest / longest read."""
+        out = Context.compact_sequences(batch)
+        so = np.asarray(out["seq_off"], dtype=np.int64)
+        has = (so[1:] - so[:-1]) > 0
+        ls = np.asarray(out["l_seq"])[has]
+        out["n_with_seq"] = int(has.sum())
+        out["l_seq_min"] = int(ls.min()) if len(ls) else 0
+        out["l_seq_max"] = int(ls.max()) if len(ls) else 0
+        co = np.asarray(out["cigar_off"], dtype=np.int64)
+        ops = np.asarray(out["cigar_ops"])
+        ref = np.isin(ops & 15, _lib.REF_CONSUMING_OPS) * (ops >> 4).astype(np.int64)
+        cr = np.concatenate([[0], np.cumsum(ref)])
+        al = (cr[co[1:]] - cr[co[:-1]])[has]
+        out["ref_span_bound"] = int(al.max()) if len(al) else 1
+        out["n_skipped"] = 0
         return out
 
     def annotate_upload(self, slot, batch):

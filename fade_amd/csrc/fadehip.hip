@@ -54,6 +54,9 @@ Layout batch_layout(int64_t n, int64_t n_cig, int64_t n_seq) {
     return L;
 }
 
+// upload keeps the reads whose cigar.alignedLength exceeds this (spliced reads, large deletions) for plan_run
+constexpr int64_t WIDE_MIN_SPAN = 1024;
+
 struct Slot {
     hipStream_t stream = nullptr;
     // The score pass fills every wave slot it may use for ~0.8 ms; the small, latency-bound kernels of the other
@@ -78,7 +81,11 @@ struct Slot {
         int64_t span_bound = 0;
         int n_reads = 0, n_skipped = 0;
         int buf = 0;
-    } next;
+        uint32_t out_bound = 0;  // alignments the batch can produce at most (records that carry bases)
+        // reads whose cigar.alignedLength alone is long (spliced reads, large deletions): (alignedLength, l_seq), so that
+        // run can bound the long list for its window size without looking at the caller's arrays again
+        std::vector<std::pair<int64_t, int>> wide;
+        } next;
     DevBuf rs, fwd, aln, trace;
     DevBuf ckpt, cand;  // two-pass path
     // All small counters of a run live in one block so that one memset clears them and one copy brings them to the host.
@@ -110,10 +117,12 @@ struct Slot {
     size_t res_aln_off = 0;
     // host-side bounds of the batch in flight (what the launches are sized from)
     uint32_t bound[NUM_LISTS] = {};     // items per work list, at most
-    uint32_t aln_base[NUM_LISTS] = {};  // first result entry of each list
     uint32_t hist[NUM_LISTS] = {};      // upload: records per read-length class (gate-passing ones when the CIGARs were scanned)
     int64_t span_bound = 0;             // upload: max cigar.alignedLength (the caller's bound or the scan's)
     int max_lq = 0;                     // upload: longest read
+    uint32_t out_bound = 0, out_cap = 0;  // upload: alignments at most; run: entries of the result array
+    std::vector<std::pair<int64_t, int>> wide;
+    bool use_ckpt = false;              // this run's score passes leave wave snapshots (see run_class_two_pass)
     int wave_lr_bound = 0, long_max_lq = 0, long_max_lr = 0;
     int floor_len = 0, window = 0;
     int n_reads = 0, n_skipped = 0;
@@ -128,6 +137,8 @@ struct Slot {
     int64_t prof_counts[6] = {0, 0, 0, 0, 0, 0};
     int64_t n_cand = 0, n_rerun = 0;  // two-pass: candidates traced / candidates re-run from further back
     int p2_last_octs[NUM_CLASSES];    // octets pass 2 served for this class in the slot's previous run (-1: none yet)
+    int64_t last_cand = 0, last_aln = 0;  // previous run of this slot: candidates traced by pass 2 / alignments
+    std::vector<void *> trash;        // scratch buffers outgrown while a run was being enqueued (freed after the slot's sync)
 };
 
 }  // namespace
@@ -210,6 +221,20 @@ int reserve_pinned(fadehip_ctx *ctx, PinBuf &b, size_t bytes) {
     size_t want = std::max<size_t>(bytes + bytes / 8, 4096);  // some headroom: batches of a stream differ a little in size
     want = (want + 4095) & ~(size_t)4095;
     HIPCHK(ctx, hipHostMalloc((void **)&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+// Growing a scratch buffer while a run is being enqueued: kernels already queued may still use the old allocation, so it
+// is only parked here and freed once the slot has been waited for (hipFree would also stall every other stream).
+int reserve_run(fadehip_ctx *ctx, std::vector<void *> &trash, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    if (b.p) trash.push_back(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    want = (want + 255) & ~(size_t)255;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
     b.cap = want;
     return 0;
 }
@@ -352,49 +377,87 @@ struct ClassRun {
     bool timed;
 };
 
-// Two-pass path for one class list, enqueued without a read-back: pass 1 scores every alignment and
-// leaves wave snapshots every CK_COLS steps; the selection finishes what needs no DP (non-candidates, forced diagonals),
-// buckets the remaining candidates by the steps to re-compute, and its last block turns the bucket counts into the
-// pass-2 table; pass 2 — ONE persistent launch — re-computes those steps with trace, walks the tracebacks and traces
-// again, from further back, the few paths that left their steps.
-int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c) {
+// Sizes of the two-pass path for one class list: launch geometry and scratch.  Computed for every class of a run before
+// its first launch, so that the slot's scratch buffers are sized ONCE per run (to the maximum over the classes) and
+// nothing is re-allocated between kernels that are already queued.
+struct TwoPassPlan {
+    int n_ck = 0;
+    uint64_t ck_stride = 0;
+    int n_blocks1 = 0, ref_stride1 = 0;
+    size_t lds1 = 0;
+    int mode2 = 2;
+    int64_t chunk_oct = 1;
+    int total_oct = 0;
+    uint64_t wave_stride = 0;
+    int p2_waves = 1;
+    size_t ckpt_bytes = 0, fwd_bytes = 0, trace_bytes = 0, cand_bytes = 0;
+};
+
+int plan_two_pass(fadehip_ctx *ctx, const Slot &s, const ClassRun &c, TwoPassPlan &p) {
     const int cls = c.cls, R = class_rows(cls), max_lr = c.max_lr, n_items = c.n_bound;
-    const int n_ck = (max_lr + 15 + CK_COLS - 1) / CK_COLS;
-    const uint64_t ck_stride = (uint64_t)n_ck * ck_dwords(R) * 64;  // dwords per pass-1 octet
-    const int n_blocks1 = (max_lr + 15 + 3) / 4;
-    const int ref_stride1 = (((n_blocks1 * 4) * 2 + 15) / 16) * 16;
-    const size_t lds1 = (size_t)ref_stride1 * 4;
-    if (lds1 > 64 * 1024)
-        return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, lds1);
+    // Wave snapshots (every CK_COLS steps, so that pass 2 can resume a sweep instead of repeating it) are only worth
+    // their stores — four times the algorithmic bytes of the score pass at C2, twelve times at C3 — when pass 2 has many
+    // candidates.  The forced-diagonal shortcut leaves it a few hundred per million reads, so a run leaves snapshots
+    // only if the slot's previous run sent more than 1/32 of its alignments to pass 2; without them a candidate is
+    // traced from step 0 (same bytes out: test_snapshots_on_and_off_give_the_same_bytes).
+    p.n_ck = s.use_ckpt ? (max_lr + 15 + CK_COLS - 1) / CK_COLS : 0;
+    p.ck_stride = (uint64_t)p.n_ck * ck_dwords(R) * 64;  // dwords per pass-1 octet
+    p.n_blocks1 = (max_lr + 15 + 3) / 4;
+    p.ref_stride1 = (((p.n_blocks1 * 4) * 2 + 15) / 16) * 16;
+    p.lds1 = (size_t)p.ref_stride1 * 4;
+    if (p.lds1 > 64 * 1024)
+        return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, p.lds1);
     const bool alt_rules = (ctx->sc.rules & (FADEHIP_RULE_HDIR_DIAG_F_E | FADEHIP_RULE_GAP_TIE_EXTENDS)) !=
                            (FADEHIP_RULE_HDIR_DIAG_F_E | FADEHIP_RULE_GAP_TIE_EXTENDS);
-    const int mode2 = alt_rules ? 3 : 2;
+    p.mode2 = alt_rules ? 3 : 2;
     // chunk so that the snapshots of a chunk fit half the budget (the other half is pass-2 trace scratch)
-    const int64_t ck_bytes = (int64_t)ck_stride * 4;
-    const int total_oct = (n_items + 7) / 8;
-    const int64_t chunk_oct = std::max<int64_t>(1, std::min<int64_t>(total_oct, (c.budget / 2) / std::max<int64_t>(ck_bytes, 1)));
-    int rc;
-    if ((rc = reserve(ctx, s.ckpt, (size_t)(chunk_oct * ck_bytes))) || (rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd)))) return rc;
+    const int64_t ck_bytes = (int64_t)p.ck_stride * 4;
+    p.total_oct = (n_items + 7) / 8;
+    p.chunk_oct = std::max<int64_t>(1, std::min<int64_t>(p.total_oct, (c.budget / 2) / std::max<int64_t>(ck_bytes, 1)));
     // Pass 2 is a persistent launch; a wave traces into its own scratch region, sized for a whole window (a path that
     // left its steps is traced again from step 0).  How many waves: what the previous batch of this class needed (its
     // octets are known by the time its results are fetched), twice over, within what the device holds at once; before
     // any batch has run, a moderate guess.  Few waves cost time only when candidates abound; many cost time always,
     // because each must find a wave slot next to the other slots' score passes before it can see that nothing is left.
-    const uint64_t wave_stride = (uint64_t)n_blocks1 * R * 64;  // dwords
-    const int resident = resident_waves(ctx, cls, mode2, lds1);
-    const int bound_waves = (int)std::min<int64_t>(chunk_oct + NUM_BUCKETS, resident);
+    p.wave_stride = (uint64_t)p.n_blocks1 * R * 64;  // dwords
+    const int resident = resident_waves(ctx, cls, p.mode2, p.lds1);
+    const int bound_waves = (int)std::min<int64_t>(p.chunk_oct + NUM_BUCKETS, resident);
     int p2_waves = s.p2_last_octs[cls] >= 0 ? std::min(2 * s.p2_last_octs[cls] + 64, bound_waves) : std::min(1024, bound_waves);
     if (ctx->p2_waves_fixed > 0) p2_waves = std::min(ctx->p2_waves_fixed, bound_waves);
     // ... and within the scratch the budget allows
-    p2_waves = (int)std::max<int64_t>(1, std::min<int64_t>(p2_waves, (c.budget / 2) / std::max<int64_t>((int64_t)wave_stride * 4, 1)));
-    if ((rc = reserve(ctx, s.trace, (size_t)p2_waves * (size_t)wave_stride * 4))) return rc;
-    s.prof_counts[2] = std::max<int64_t>(s.prof_counts[2], (int64_t)p2_waves * (int64_t)wave_stride * 4);
+    p.p2_waves = (int)std::max<int64_t>(1, std::min<int64_t>(p2_waves, (c.budget / 2) / std::max<int64_t>((int64_t)p.wave_stride * 4, 1)));
+    p.ckpt_bytes = (size_t)(p.chunk_oct * ck_bytes);
+    p.fwd_bytes = (size_t)n_items * sizeof(Fwd);
+    p.trace_bytes = (size_t)p.p2_waves * (size_t)p.wave_stride * 4;
+    p.cand_bytes = sizeof(Cand) * (size_t)NUM_BUCKETS * (size_t)std::min<int64_t>(n_items, p.chunk_oct * 8);
+    return 0;
+}
+
+// Two-pass path for one class list, enqueued without a read-back: pass 1 scores every alignment (and,
+// when the run asks for them, leaves wave snapshots every CK_COLS steps); the selection — inside the score pass's waves —
+// finishes what needs no DP (non-candidates, forced diagonals) and buckets the remaining candidates by the steps to
+// re-compute; pass 2 — ONE persistent launch — turns the bucket counts into its table, re-computes those steps with
+// trace, walks the tracebacks and traces again, from further back, the few paths that left their steps.
+int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c) {
+    const int cls = c.cls, n_items = c.n_bound;
+    TwoPassPlan p;
+    int rc;
+    if ((rc = plan_two_pass(ctx, s, c, p))) return rc;
+    const int n_ck = p.n_ck, ref_stride1 = p.ref_stride1, mode2 = p.mode2, total_oct = p.total_oct, p2_waves = p.p2_waves;
+    const uint64_t ck_stride = p.ck_stride, wave_stride = p.wave_stride;
+    const size_t lds1 = p.lds1;
+    const int64_t chunk_oct = p.chunk_oct;
+    // (level 2 sized these for all classes before the run's first launch; a buffer that still has to grow here is parked,
+    // not freed: earlier launches of this run may be using it)
+    if ((rc = reserve_run(ctx, s.trash, s.ckpt, p.ckpt_bytes)) || (rc = reserve_run(ctx, s.trash, s.fwd, p.fwd_bytes)) ||
+        (rc = reserve_run(ctx, s.trash, s.trace, p.trace_bytes)) || (rc = reserve_run(ctx, s.trash, s.cand, p.cand_bytes)))
+        return rc;
+    s.prof_counts[2] = std::max<int64_t>(s.prof_counts[2], (int64_t)p.trace_bytes);
     uint32_t *const sel_counters = s.d_sel(cls);
     for (int64_t o0 = 0; o0 < total_oct; o0 += chunk_oct) {
         const int octs = (int)std::min<int64_t>(chunk_oct, total_oct - o0);
         const int i0 = (int)(o0 * 8);
         const int n = std::min(n_items - i0, octs * 8);
-        if ((rc = reserve(ctx, s.cand, sizeof(Cand) * (size_t)NUM_BUCKETS * (size_t)n))) return rc;
         if (!s.sel_fresh[cls]) HIPCHK(ctx, hipMemsetAsync(sel_counters, 0, sizeof(uint32_t) * NUM_BUCKETS, st));
         s.sel_fresh[cls] = false;
         SwArgs a;
@@ -416,6 +479,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
         a.item_base = (uint32_t)i0;
         // the selection rides in the score pass's waves
         a.sel.enabled = 1;
+        a.sel.no_ckpt = n_ck == 0 ? 1 : 0;
         a.sel.meta = c.meta ? c.meta + i0 : nullptr;
         a.sel.floor_len = c.floor_len;
         a.sel.trace_all = ctx->prm.trace_all;
@@ -423,7 +487,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
         a.sel.cand = (Cand *)s.cand.p;
         a.sel.cap = (uint32_t)n;
         a.sel.bucket_n = sel_counters;
-        a.sel.out = c.out + i0;
+        a.sel.out = c.out;
         a.sel.rs = c.rs;
         a.sel.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
         a.sel.gate = c.gate;
@@ -456,7 +520,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
         b2.count_dev = nullptr;
         b2.ticket = s.d_ticket(s.tickets_used++);
         b2.meta = c.meta ? c.meta + i0 : nullptr;
-        b2.out = c.out + i0;
+        b2.out = c.out;
         b2.rs = c.rs;
         b2.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
         b2.floor_len = c.floor_len;
@@ -490,9 +554,9 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
     int64_t max_quads = std::max<int64_t>(1, c.budget / quad_bytes);
     const int total_quads = (n_items + per_wave - 1) / per_wave;
     const int64_t chunk_quads = std::min<int64_t>(max_quads, total_quads);
-    int rc = reserve(ctx, s.trace, (size_t)(chunk_quads * quad_bytes));
+    int rc = reserve_run(ctx, s.trash, s.trace, (size_t)(chunk_quads * quad_bytes));
     if (rc) return rc;
-    rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd));
+    rc = reserve_run(ctx, s.trash, s.fwd, (size_t)n_items * sizeof(Fwd));
     if (rc) return rc;
     for (int64_t q0 = 0; q0 < total_quads; q0 += chunk_quads) {
         const int quads = (int)std::min<int64_t>(chunk_quads, total_quads - q0);
@@ -526,7 +590,7 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
         t.trace = (const uint32_t *)s.trace.p;
         t.quad_stride = quad_stride;
         t.sc = ctx->sc;
-        t.out = c.out + i0;
+        t.out = c.out;
         t.rs = c.rs;
         t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
         t.floor_len = c.floor_len;
@@ -556,11 +620,11 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int m
         return set_err(ctx, FADEHIP_E_UNSUPPORTED, "a %d x %d alignment needs %lld B of trace, more than trace_bytes", max_lq, max_lr,
                        (long long)per_item);
     int rc;
-    if ((rc = reserve(ctx, s.fwd, (size_t)n_items * sizeof(Fwd)))) return rc;
+    if ((rc = reserve_run(ctx, s.trash, s.fwd, (size_t)n_items * sizeof(Fwd)))) return rc;
     for (int64_t i0 = 0; i0 < n_items; i0 += chunk) {
         const int n = (int)std::min<int64_t>(chunk, n_items - i0);
-        if ((rc = reserve(ctx, s.trace, (size_t)max_lq * (size_t)lhalf * (size_t)n)) ||
-            (rc = reserve(ctx, s.lrows, 8 * (size_t)max_lr * (size_t)n)))
+        if ((rc = reserve_run(ctx, s.trash, s.trace, (size_t)max_lq * (size_t)lhalf * (size_t)n)) ||
+            (rc = reserve_run(ctx, s.trash, s.lrows, 8 * (size_t)max_lr * (size_t)n)))
             return rc;
         LongArgs a;
         memset(&a, 0, sizeof a);
@@ -593,7 +657,7 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int m
         t.q_nib = c.q_nib;
         t.r_nib = c.r_nib;
         t.sc = ctx->sc;
-        t.out = c.out + i0;
+        t.out = c.out;
         t.rs = c.rs;
         t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
         t.floor_len = c.floor_len;
@@ -659,8 +723,6 @@ int check_slot(fadehip_ctx *ctx, int slot) {
 
 // typed views of the batch in flight, on the host and on the device
 template <class T>
-const T *h_arr(const Slot &s, int k) { return (const T *)(s.h_base + s.L.off[k]); }
-template <class T>
 const T *d_arr(const Slot &s, int k) { return (const T *)((const uint8_t *)s.in[s.cur].p + s.L.off[k]); }
 
 // anno.d:61 + util.d:37-62 + dhtslib alignedLength over one record's CIGAR, as gate_kernel computes them
@@ -688,7 +750,6 @@ inline CigarSummary summarize_cigar(const uint32_t *ops, uint32_t c0, uint32_t c
 // Host-side bounds of a run (the launches are sized from these; the device keeps the real counts and checks every bound
 // before it writes: a record beyond one is reported at results, never trusted).
 int plan_run(fadehip_ctx *ctx, Slot &s) {
-    const int n = s.n_reads;
     const int64_t w = s.window;
     for (int c = 0; c < NUM_LISTS; c++) s.bound[c] = s.hist[c];
     const int64_t lr_bound = std::min<int64_t>(s.span_bound + 2 * w, ctx->prm.max_ref_len);
@@ -696,40 +757,30 @@ int plan_run(fadehip_ctx *ctx, Slot &s) {
     s.long_max_lq = s.max_lq;
     s.long_max_lr = (int)std::max<int64_t>(lr_bound, 1);
     if (lr_bound > WAVE_MAX_WINDOW) {
-        // some window may exceed what the wave kernels stage in LDS: count exactly which records go to the long list
-        // (analysis.d:45-59 per record), so that its buffers are sized for those and not for the whole batch
-        const int32_t *tid = h_arr<int32_t>(s, A_TID), *pos = h_arr<int32_t>(s, A_POS), *lseq = h_arr<int32_t>(s, A_LSEQ);
-        const uint16_t *flag = h_arr<uint16_t>(s, A_FLAG);
-        const uint32_t *coff = h_arr<uint32_t>(s, A_CIGOFF), *cops = h_arr<uint32_t>(s, A_CIG);
-        uint32_t n_long = 0;
+        // Some window may exceed what the wave kernels stage in LDS.  Which records go to the long list depends on the
+        // window size, which only the run knows; upload kept the reads whose alignedLength alone is long (spliced reads,
+        // large deletions), so the count needs no second look at the caller's arrays (they need not outlive results).
+        uint32_t n_long = s.hist[LONG_LIST];  // reads beyond 512 bases
         int64_t max_lr = 1;
-        int max_lq = 1;
-        for (int i = 0; i < n; i++) {
-            const int lq = lseq[i];
-            const bool by_len = lq > 16 * class_rows(NUM_CLASSES - 1);
-            bool is_long = by_len;
-            int64_t lr = 0;
-            if ((flag[i] & 4u) == 0 && tid[i] >= 0 && tid[i] < ctx->n_contigs) {
-                const CigarSummary cs = summarize_cigar(cops, coff[i], coff[i + 1]);
-                const int64_t start = std::max<int64_t>((int64_t)pos[i] - w, 0);
-                const int64_t end = std::min<int64_t>((int64_t)pos[i] + cs.aligned + w, ctx->h_contig_len[(size_t)tid[i]]);
-                lr = end - start;
-                if (cs.n_soft > 0 && lr > WAVE_MAX_WINDOW) is_long = true;
-            }
-            if (is_long && lq > 0) {
-                n_long++;
-                max_lq = std::max(max_lq, lq);
-                max_lr = std::max(max_lr, std::min<int64_t>(lr > 0 ? lr : lr_bound, lr_bound));
-            }
+        int max_lq = s.hist[LONG_LIST] ? std::min(s.max_lq, MAX_LONG_QUERY) : 1;
+        if (2 * w + WIDE_MIN_SPAN > WAVE_MAX_WINDOW) {
+            // with this window size a read of ordinary span may have a long window: any record that carries bases may
+            // land on the long list
+            n_long = s.out_bound;
+            max_lr = lr_bound;
+            max_lq = std::min(std::max(s.max_lq, 1), MAX_LONG_QUERY);
+        } else {
+            for (const auto &wr : s.wide)
+                if (wr.first + 2 * w > WAVE_MAX_WINDOW) {
+                    if (wr.second <= 16 * class_rows(NUM_CLASSES - 1)) n_long++;  // (longer reads are counted already)
+                    max_lq = std::max(max_lq, std::min(wr.second, MAX_LONG_QUERY));
+                    max_lr = std::max(max_lr, std::min<int64_t>(wr.first + 2 * w, lr_bound));
+                }
+            if (s.hist[LONG_LIST]) max_lr = lr_bound;
         }
-        s.bound[LONG_LIST] = n_long;
+        s.bound[LONG_LIST] = std::min(n_long, s.out_bound);
         s.long_max_lq = max_lq;
         s.long_max_lr = (int)max_lr;
-    }
-    uint32_t base = 0;
-    for (int c = 0; c < NUM_LISTS; c++) {
-        s.aln_base[c] = base;
-        base += s.bound[c];
     }
     return 0;
 }
@@ -745,8 +796,11 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
     s.tickets_used = 0;
     memset(s.prof_counts, 0, sizeof s.prof_counts);
     int rc;
+    // one result array for all lists: an alignment reports into the entry the gate hands it (Work::out)
     uint32_t total_bound = 0;
     for (int c = 0; c < NUM_LISTS; c++) total_bound += s.bound[c];
+    total_bound = std::min(total_bound, s.out_bound);
+    s.out_cap = total_bound;
     s.res_aln_off = ((size_t)n + 255) & ~(size_t)255;
     if ((rc = reserve(ctx, s.rs, (size_t)n)) || (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)std::max<uint32_t>(total_bound, 1))) ||
         (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)) ||
@@ -755,6 +809,45 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
     for (int c = 0; c < NUM_LISTS; c++) {
         if (!s.bound[c]) continue;
         if ((rc = reserve(ctx, s.work[c], sizeof(Work) * (size_t)s.bound[c])) || (rc = reserve(ctx, s.meta[c], sizeof(Meta) * (size_t)s.bound[c])))
+            return rc;
+    }
+    const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)16 << 30);
+    // snapshots only when the slot's previous run had many pass-2 candidates (plan_two_pass); FADEHIP_CKPT=0/1 pins it
+    s.use_ckpt = s.last_cand * 32 > std::max<int64_t>(s.last_aln, 1);
+    if (const char *kv = getenv("FADEHIP_CKPT")) s.use_ckpt = atoi(kv) != 0;
+    auto class_run = [&](int c) {
+        ClassRun cr;
+        cr.cls = c;
+        cr.work = (const Work *)s.work[c].p;
+        cr.meta = (const Meta *)s.meta[c].p;
+        cr.n_bound = (int)s.bound[c];
+        cr.count_dev = s.d_counters() + c;
+        cr.max_lr = c == LONG_LIST ? s.long_max_lr : std::max(s.wave_lr_bound, 1);
+        cr.q_nib = d_arr<uint8_t>(s, A_SEQ);
+        cr.r_nib = (const uint8_t *)ctx->genome.p;
+        cr.out = (fadehip_aln *)s.aln.p;
+        cr.rs = (uint8_t *)s.rs.p;
+        cr.floor_len = floor_len;
+        cr.gate = 1;
+        cr.budget = budget;
+        cr.timed = true;
+        return cr;
+    };
+    if (ctx->two_pass) {
+        // the scratch of every class of this run, sized once before the first launch (nothing is re-allocated between
+        // kernels already queued; the slot is idle here: run waited for its previous results)
+        size_t need_ckpt = 0, need_fwd = 0, need_trace = 0, need_cand = 0;
+        for (int c = 0; c < NUM_CLASSES; c++) {
+            if (!s.bound[c]) continue;
+            TwoPassPlan p;
+            if ((rc = plan_two_pass(ctx, s, class_run(c), p))) return rc;
+            need_ckpt = std::max(need_ckpt, p.ckpt_bytes);
+            need_fwd = std::max(need_fwd, p.fwd_bytes);
+            need_trace = std::max(need_trace, p.trace_bytes);
+            need_cand = std::max(need_cand, p.cand_bytes);
+        }
+        if ((rc = reserve_run(ctx, s.trash, s.ckpt, need_ckpt)) || (rc = reserve_run(ctx, s.trash, s.fwd, need_fwd)) ||
+            (rc = reserve_run(ctx, s.trash, s.trace, need_trace)) || (rc = reserve_run(ctx, s.trash, s.cand, need_cand)))
             return rc;
     }
     HIPCHK(ctx, hipMemsetAsync(s.zblock.p, 0, Slot::ZB_BYTES, st));  // every counter of the run in one fill
@@ -786,14 +879,15 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
         g.meta[c] = (Meta *)s.meta[c].p;
         g.list_cap[c] = s.bound[c];
     }
+    g.out_cap = s.out_cap;
+    g.n_cigar_ops = (uint32_t)(s.L.bytes[A_CIG] / 4);
+    g.n_seq_bytes = (uint32_t)s.L.bytes[A_SEQ];
     g.stats = s.d_stats();
     g.counters = s.d_counters();
     g.counters64 = s.d_counters64();
     hipLaunchKernelGGL(gate_kernel, dim3((n + GATE_BLOCK - 1) / GATE_BLOCK), dim3(GATE_BLOCK), 0, st, g);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = record(ctx, s, &s.ev_gate1))) return rc;
-    const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)16 << 30);
-    const uint8_t *q_nib = d_arr<uint8_t>(s, A_SEQ);
     uint32_t exact[NUM_LISTS];
     for (int c = 0; c < NUM_LISTS; c++) exact[c] = s.bound[c];
     if (!ctx->two_pass) {
@@ -804,40 +898,14 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
     }
     for (int c = 0; c < NUM_CLASSES; c++) {
         if (!exact[c]) continue;
-        ClassRun cr;
-        cr.cls = c;
-        cr.work = (const Work *)s.work[c].p;
-        cr.meta = (const Meta *)s.meta[c].p;
+        ClassRun cr = class_run(c);
         cr.n_bound = (int)exact[c];
-        cr.count_dev = s.d_counters() + c;
-        cr.max_lr = std::max(s.wave_lr_bound, 1);
-        cr.q_nib = q_nib;
-        cr.r_nib = (const uint8_t *)ctx->genome.p;
-        cr.out = (fadehip_aln *)s.aln.p + s.aln_base[c];
-        cr.rs = (uint8_t *)s.rs.p;
-        cr.floor_len = floor_len;
-        cr.gate = 1;
-        cr.budget = budget;
-        cr.timed = true;
         rc = ctx->two_pass ? run_class_two_pass(ctx, s, st, cr) : run_class_single(ctx, s, st, cr);
         if (rc) return rc;
     }
     if (exact[LONG_LIST]) {
-        ClassRun cr;
-        cr.cls = LONG_LIST;
-        cr.work = (const Work *)s.work[LONG_LIST].p;
-        cr.meta = (const Meta *)s.meta[LONG_LIST].p;
+        ClassRun cr = class_run(LONG_LIST);
         cr.n_bound = (int)exact[LONG_LIST];
-        cr.count_dev = s.d_counters() + LONG_LIST;
-        cr.max_lr = s.long_max_lr;
-        cr.q_nib = q_nib;
-        cr.r_nib = (const uint8_t *)ctx->genome.p;
-        cr.out = (fadehip_aln *)s.aln.p + s.aln_base[LONG_LIST];
-        cr.rs = (uint8_t *)s.rs.p;
-        cr.floor_len = floor_len;
-        cr.gate = 1;
-        cr.budget = budget;
-        cr.timed = true;
         if ((rc = run_long(ctx, s, st, cr, std::max(s.long_max_lq, 1)))) return rc;
     }
     if ((rc = record(ctx, s, &s.ev_end))) return rc;
@@ -864,12 +932,15 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
         return 0;
     }
     HIPCHK(ctx, hipStreamSynchronize(st));
+    for (void *q : s.trash) (void)hipFree(q);  // scratch outgrown while this run was enqueued
+    s.trash.clear();
     const uint32_t errbits = s.h_counters()[2 * NUM_LISTS];
     if (errbits) {
         s.state = 0;
+        if (errbits & 64u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a record whose cigar_off / seq_off are not non-decreasing within the arrays, or l_seq < 0");
         if (errbits & 8u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped record whose seq_packed slice is shorter than its l_seq");
         if (errbits & 16u) return set_err(ctx, FADEHIP_E_INVALID, "batch has a record whose cigar.alignedLength exceeds ref_span_bound=%lld", (long long)s.span_bound);
-        if (errbits & 32u) return set_err(ctx, FADEHIP_E_STATE, "internal: a work list outgrew the bound its launches were sized from");
+        if (errbits & 32u) return set_err(ctx, FADEHIP_E_INVALID, "batch has more records to re-align than its bounds said (n_with_seq / l_seq_min / l_seq_max too small?)");
         return set_err(ctx, FADEHIP_E_INVALID, "batch has a mapped soft-clipped read whose tid is not a contig of the uploaded genome");
     }
     for (int c = 0; c < NUM_CLASSES; c++)  // what pass 2 served: sizes the next run's persistent launch
@@ -879,14 +950,8 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
             for (int b = 0; b < NUM_BUCKETS; b++) octs += (int)((bn[b] + 7) / 8);
             s.p2_last_octs[c] = octs;
         }
-    // live entries of each list; several lists leave holes between their segments of the result block: close them
-    fadehip_aln *aln = (fadehip_aln *)(s.res.p + s.res_aln_off);
-    uint32_t at = 0;
-    for (int c = 0; c < NUM_LISTS; c++) {
-        const uint32_t cnt = std::min(s.h_counters()[c], s.bound[c]);
-        if (cnt && s.aln_base[c] != at) memmove(aln + at, aln + s.aln_base[c], sizeof(fadehip_aln) * (size_t)cnt);
-        at += cnt;
-    }
+    // all lists report into one result array: its live entries are the ones the gate handed out
+    const uint32_t at = std::min(s.h_counters()[2 * NUM_LISTS + 3], s.out_cap);
     s.n_aln = (int)at;
     s.n_oversize = (int)s.h_counters()[2 * NUM_LISTS + 2];
     for (int k = 0; k < 8; k++) {
@@ -897,12 +962,14 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
     const PlanOut *po = s.h_plan();
     s.n_cand = (int64_t)po->cand_total;
     s.n_rerun = (int64_t)po->rerun_total;
+    s.last_cand = s.n_cand;
+    s.last_aln = (int64_t)at;
     s.prof_counts[0] = at;
     s.prof_counts[1] = (int64_t)s.h_counters64()[0 * C64_STRIDE];
     // algorithmic bytes of the dominant kernel: SURVEY §8(d)'s packed query + packed window + 16 B
     // descriptor + 64 B result slot per alignment
     s.prof_counts[3] = (int64_t)s.h_counters64()[1 * C64_STRIDE] + (int64_t)at * 80;
-    s.prof_counts[4] = ctx->two_pass ? (int64_t)s.h_counters64()[2 * C64_STRIDE] : (int64_t)(s.h_counters64()[0 * C64_STRIDE] / 2);
+    s.prof_counts[4] = ctx->two_pass ? (s.use_ckpt ? (int64_t)s.h_counters64()[2 * C64_STRIDE] : 0) : (int64_t)(s.h_counters64()[0 * C64_STRIDE] / 2);
     s.prof_counts[5] = s.n_cand;
     if (ctx->debug)
         fprintf(stderr, "[fadehip] slot %d: %d reads, %u alignments, %lld candidates traced, %lld re-run, trace need %lld B\n", slot, n, at,
@@ -1017,7 +1084,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         set_err(ctx, FADEHIP_E_HIP, "hipMemcpyToSymbol failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(FADEHIP_E_HIP);
     }
-    static_assert(sizeof(uint32_t) * (2 * NUM_LISTS + 3) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
+    static_assert(sizeof(uint32_t) * (2 * NUM_LISTS + 4) <= Slot::ZB_C64 - Slot::ZB_COUNTERS, "gate counters overflow their slice");
     static_assert(Slot::ZB_SEL + Slot::ZB_SEL_STRIDE * NUM_CLASSES <= Slot::ZB_STATS, "selection counters overlap the stats");
     static_assert(sizeof(uint32_t) * NUM_BUCKETS <= Slot::ZB_SEL_STRIDE, "selection counters overflow their slice");
     static_assert(sizeof(PlanOut) <= 128, "PlanOut overflows its slice");
@@ -1034,6 +1101,8 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     for (int k = 0; k < FADEHIP_NUM_SLOTS; k++) {
         Slot &s = ctx->slots[k];
         for (DevBuf *b : {&s.in[0], &s.in[1], &s.rs, &s.fwd, &s.aln, &s.zblock, &s.trace, &s.ckpt, &s.cand, &s.lrows}) release(*b);
+        for (void *q : s.trash) (void)hipFree(q);
+        s.trash.clear();
         for (int c = 0; c < NUM_LISTS; c++) {
             release(s.work[c]);
             release(s.meta[c]);
@@ -1091,6 +1160,9 @@ int fadehip_batch_bind(void *base, int32_t n_reads, int64_t n_cigar_ops, int64_t
     b->seq_packed = (const uint8_t *)(p + L.off[A_SEQ]);
     b->n_skipped = 0;
     b->ref_span_bound = 0;
+    b->n_with_seq = 0;
+    b->l_seq_min = b->l_seq_max = 0;
+    b->reserved = 0;
     return 0;
 }
 
@@ -1129,7 +1201,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         w.lr = (uint32_t)lr;
         w.idx = (uint32_t)k;
         w.flags = 0;
-        w.pad = 0;
+        w.out = 0;
         lists[cls].push_back(w);
         max_lr[cls] = std::max(max_lr[cls], (int)lr);
     }
@@ -1159,6 +1231,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         size_t base = 0;
         for (int c = 0; c < NUM_LISTS; c++) {
             if (lists[c].empty()) continue;
+            for (size_t k = 0; k < lists[c].size(); k++) lists[c][k].out = (uint32_t)(base + k);  // one result array, list after list
             HIPCHK(ctx, hipMemcpyAsync((Work *)d_work.p + base, lists[c].data(), lists[c].size() * sizeof(Work), hipMemcpyHostToDevice, st));
             base += lists[c].size();
         }
@@ -1171,6 +1244,9 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
         s.tickets_used = 0;
         HIPCHK(ctx, hipMemsetAsync(s.zblock.p, 0, Slot::ZB_BYTES, st));
         for (int c = 0; c < NUM_CLASSES; c++) s.sel_fresh[c] = true;
+        // level 1 wants a CIGAR for every pair: whatever the forced-diagonal shortcut leaves goes to pass 2, with snapshots
+        s.use_ckpt = true;
+        if (const char *kv = getenv("FADEHIP_CKPT")) s.use_ckpt = atoi(kv) != 0;
         for (int c = 0; c < NUM_LISTS; c++) {
             if (lists[c].empty()) continue;
             // the lists come from the host here: their counts go where the gate leaves them at level 2
@@ -1185,7 +1261,7 @@ int fadehip_sw_batch(fadehip_ctx *ctx, int32_t n, const uint8_t *q, const int64_
             cr.max_lr = max_lr[c];
             cr.q_nib = (const uint8_t *)d_qn.p;
             cr.r_nib = (const uint8_t *)d_rn.p;
-            cr.out = (fadehip_aln *)d_aln.p + base;
+            cr.out = (fadehip_aln *)d_aln.p;
             cr.rs = nullptr;
             cr.floor_len = 0;
             cr.gate = 0;
@@ -1293,6 +1369,8 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
     nx.n_skipped = b->n_skipped;
     nx.buf = 1 - s.cur;
     memset(nx.hist, 0, sizeof nx.hist);
+    nx.out_bound = 0;
+    nx.wide.clear();
     nx.max_lq = 0;
     nx.span_bound = b->ref_span_bound;
     nx.h_base = nullptr;
@@ -1302,33 +1380,51 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
         return set_err(ctx, FADEHIP_E_INVALID, "batch has NULL arrays");
     const size_t n_cig = b->cigar_off[n], n_seq = b->seq_off[n];
     if ((uint64_t)n_seq * 2 >= ((uint64_t)1 << 32)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "packed sequence bytes per batch must stay below 2^31");
-    // One pass over the records: the kernels index with these offsets (they must be non-decreasing and end where the
-    // arrays end, lengths non-negative), and the launches of the run are sized from the read-length histogram.  Without
-    // the caller's ref_span_bound the CIGARs are scanned too (then only records that pass anno.d:61 count).
-    const bool scan = b->ref_span_bound <= 0;
+    // What the launches of the run are sized from: records that carry bases per read-length class, the longest read, the
+    // longest cigar.alignedLength.  A caller that packed the block knows them (ABI 3: n_with_seq, l_seq_min / l_seq_max,
+    // ref_span_bound) and upload then touches no record: the offsets the kernels index with are checked by the gate
+    // kernel before it reads through them.  Otherwise one pass over the records finds them (and checks the offsets
+    // here, as ABI 2 did).  The CIGARs are scanned when the caller gave no span bound, or one so long that a window may
+    // exceed what the wave kernels stage (then the few reads concerned are remembered for plan_run).
+    const bool hinted = b->n_with_seq > 0 && b->ref_span_bound > 0 && b->ref_span_bound <= WIDE_MIN_SPAN &&
+                        b->l_seq_min > 0 && b->l_seq_max >= b->l_seq_min;
     uint32_t hist[NUM_LISTS] = {0};
     int max_lq = 0;
     int64_t span = b->ref_span_bound;
-    uint8_t cls_of[33];  // class of a read of 16 k - 15 .. 16 k bases
-    for (int k = 0; k <= 32; k++) cls_of[k] = (uint8_t)list_of_len(std::max(16 * k, 1));
-    for (int i = 0; i < n; i++) {
-        const uint32_t c0 = b->cigar_off[i], c1 = b->cigar_off[i + 1];
-        const int lq = b->l_seq[i];
-        if (c0 > c1 || c1 > n_cig || b->seq_off[i] > b->seq_off[i + 1] || b->seq_off[i + 1] > n_seq || lq < 0)
-            return set_err(ctx, FADEHIP_E_INVALID, "record %d: cigar_off / seq_off must be non-decreasing and l_seq >= 0", i);
-        if (scan) {
-            if (b->flag[i] & 4u) continue;
-            const CigarSummary cs = summarize_cigar(b->cigar_ops, c0, c1);
-            if (cs.n_soft == 0) continue;
-            span = std::max(span, cs.aligned);
+    nx.wide.clear();
+    if (hinted) {
+        if (b->n_with_seq > n) return set_err(ctx, FADEHIP_E_INVALID, "n_with_seq %d exceeds n_reads %d", b->n_with_seq, n);
+        const int c_lo = list_of_len(std::min(b->l_seq_min, MAX_LONG_QUERY)), c_hi = list_of_len(std::min(b->l_seq_max, MAX_LONG_QUERY));
+        for (int c = c_lo; c <= c_hi; c++) hist[c] = (uint32_t)b->n_with_seq;  // any of them may be of any length in between
+        max_lq = std::min(b->l_seq_max, MAX_LONG_QUERY);
+        nx.out_bound = (uint32_t)b->n_with_seq;
+    } else {
+        const bool scan = b->ref_span_bound <= 0, scan_wide = scan || b->ref_span_bound > WIDE_MIN_SPAN;
+        uint8_t cls_of[33];  // class of a read of 16 k - 15 .. 16 k bases
+        for (int k = 0; k <= 32; k++) cls_of[k] = (uint8_t)list_of_len(std::max(16 * k, 1));
+        uint32_t n_out = 0;
+        for (int i = 0; i < n; i++) {
+            const uint32_t c0 = b->cigar_off[i], c1 = b->cigar_off[i + 1];
+            const int lq = b->l_seq[i];
+            if (c0 > c1 || c1 > n_cig || b->seq_off[i] > b->seq_off[i + 1] || b->seq_off[i + 1] > n_seq || lq < 0)
+                return set_err(ctx, FADEHIP_E_INVALID, "record %d: cigar_off / seq_off must be non-decreasing and l_seq >= 0", i);
+            if (b->seq_off[i + 1] == b->seq_off[i]) continue;  // no bases: the record cannot be re-aligned (anno.d:61 settled it)
+            if (scan_wide) {
+                if (b->flag[i] & 4u) continue;
+                const CigarSummary cs = summarize_cigar(b->cigar_ops, c0, c1);
+                if (cs.n_soft == 0) continue;
+                if (scan) span = std::max(span, cs.aligned);
+                if (cs.aligned > WIDE_MIN_SPAN) nx.wide.emplace_back(cs.aligned, lq);
+            }
+            const int c = lq > 512 ? (lq <= MAX_LONG_QUERY ? LONG_LIST : -1) : (int)cls_of[(std::max(lq, 1) + 15) >> 4];
+            if (c >= 0) { hist[c]++; n_out++; }
+            max_lq = std::max(max_lq, std::min(lq, MAX_LONG_QUERY));
         }
-        const int c = lq > 512 ? (lq <= MAX_LONG_QUERY ? LONG_LIST : -1) : (int)cls_of[(std::max(lq, 1) + 15) >> 4];
-        if (c >= 0) hist[c]++;
-        max_lq = std::max(max_lq, std::min(lq, MAX_LONG_QUERY));
+        nx.out_bound = n_out;
     }
     memcpy(nx.hist, hist, sizeof hist);
     nx.max_lq = max_lq;
-    nx.span_bound = span;
+    nx.span_bound = std::max<int64_t>(span, 1);
     const Layout L = batch_layout(n, (int64_t)n_cig, (int64_t)n_seq);
     const void *src[N_ARR] = {b->tid, b->pos, b->l_seq, b->cigar_off, b->seq_off, b->flag, b->has_sa, b->cigar_ops, b->seq_packed};
     const uint8_t *base = (const uint8_t *)b->tid;
@@ -1370,6 +1466,8 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         memcpy(s.hist, nx.hist, sizeof s.hist);
         s.max_lq = nx.max_lq;
         s.span_bound = nx.span_bound;
+        s.out_bound = nx.out_bound;
+        s.wide = nx.wide;
         s.n_reads = nx.n_reads;
         s.n_skipped = nx.n_skipped;
         s.have_batch = true;

@@ -71,7 +71,7 @@ struct Work {           // 32 bytes
     uint32_t lq, lr;
     uint32_t idx;       // level 1: pair index; level 2: read index
     uint32_t flags;     // bit0: reverse-complement the query while loading (analysis.d:40)
-    uint32_t pad;
+    uint32_t out;       // entry of the run's result array this alignment reports into (one array for all lists)
 };
 struct Meta {           // level-2 side data per work item, 32 bytes
     int64_t win_start;
@@ -162,15 +162,19 @@ struct GateArgs {
     int32_t wave_lr_bound;       // longest window the wave kernels' launches were sized for (LDS, snapshots): the host's bound
     int32_t long_lr_bound, long_lq_bound;  // the same for the long list's row and trace buffers
     uint32_t list_cap[NUM_LISTS];  // entries reserved per work list (from the host's count of the batch's read lengths)
+    uint32_t out_cap;            // entries of the run's result array (all lists report into one array)
+    uint32_t n_cigar_ops, n_seq_bytes;  // lengths of cigar_ops / seq_packed: the offsets are checked against them HERE
     uint8_t *rs;
     Work *work[NUM_LISTS];
     Meta *meta[NUM_LISTS];
-    uint32_t *counters;  // NL = NUM_LISTS: [0..NL) item counts, [NL..2NL) max lr, [2NL] error bits, [2NL+1] max lq of the long list, [2NL+2] oversize reads
+    uint32_t *counters;  // NL = NUM_LISTS: [0..NL) item counts, [NL..2NL) max lr, [2NL] error bits, [2NL+1] max lq of the long list, [2NL+2] oversize reads, [2NL+3] result entries handed out
     unsigned long long *counters64;  // [k * C64_STRIDE]: k = 0 DP cells, 1 packed sequence bytes read (query + window), 2 checkpoint bytes
     unsigned long long *stats;       // stats.d:45-54: [0] read_count, [1] clipped, [2] sup (the artifact counters come from traceback_kernel)
 };
 
-constexpr int GATE_BLOCK = 256;  // small blocks find room next to another slot's score pass; a block orders its items by window length
+// A block orders its items by window length (an octet sweeps its longest window).  With every record of a batch sent,
+// one in ten is an item: 1024 records give a block ~100 items to order (256 gave it ~25: 2 % more columns per octet)
+constexpr int GATE_BLOCK = 1024;
 __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // per-thread contribution to the batch counters; reduced per wave before touching memory
@@ -180,7 +184,13 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     Work w;
     Meta m;
     if (i < a.n_reads) {
-        const uint32_t c0 = a.cigar_off[i], c1 = a.cigar_off[i + 1];
+        uint32_t c0 = a.cigar_off[i], c1 = a.cigar_off[i + 1];
+        const uint32_t so0 = a.seq_off[i], so1 = a.seq_off[i + 1];
+        const int32_t lq = a.l_seq[i];
+        // the caller's offsets are checked before anything is read through them (upload no longer walks the records
+        // when the caller passes its bounds): a record that fails is skipped and the batch is failed at results
+        bool bad_rec = c0 > c1 || c1 > a.n_cigar_ops || so0 > so1 || so1 > a.n_seq_bytes || lq < 0;
+        if (bad_rec) { errbits |= 64u; c1 = c0; }
         // anno.d:61: count S ops; util.d:37-62 parse_clips; dhtslib alignedLength (M,D,N,=,X)
         int n_soft = 0;
         uint32_t clipL = 0, clipR = 0;
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         const uint32_t flag = a.flag[i];
         uint8_t rs = 0;
         bool want = false;
-        if (!((flag & 4u) || n_soft == 0)) {          // anno.d:61-65
+        if (!((flag & 4u) || n_soft == 0) && !bad_rec) {          // anno.d:61-65
             if (clipL != 0 || clipR != 0) rs |= 1;    // anno.d:69-70
             if (a.has_sa[i]) rs |= 32;                // anno.d:73-74
             // analysis.d:34: only clips strictly longer than the floor are re-aligned
@@ -208,12 +218,11 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         a.rs[i] = rs;
         st_bits = 4u | (rs & 1u) | ((rs >> 4) & 2u);  // bit2 read, bit0 clipped, bit1 sup
         const int32_t tid = a.tid[i];
-        const int32_t lq = a.l_seq[i];
         if (want && (tid < 0 || tid >= a.n_contigs)) {
             errbits |= 1u;  // mapped record without a valid contig
             want = false;
         }
-        if (want && lq > 0 && a.seq_off[i + 1] - a.seq_off[i] < (uint32_t)(lq + 1) / 2u) {
+        if (want && lq > 0 && so1 - so0 < (uint32_t)(lq + 1) / 2u) {
             errbits |= 8u;  // a record that must be re-aligned came without its bases
             want = false;
         }
@@ -240,12 +249,12 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
                     ck_bytes = cls == LONG_LIST ? 0ull : (unsigned long long)lq * (unsigned long long)(lr >> CK_SHIFT) * 4ull;  // H + E-hat, int16 each
                     lr_for_max = (uint32_t)lr;
                     w.r_base = a.contig_base[tid] + (uint64_t)start;
-                    w.q_base = a.seq_off[i] * 2u;
+                    w.q_base = so0 * 2u;
                     w.lq = (uint32_t)lq;
                     w.lr = (uint32_t)lr;
                     w.idx = (uint32_t)i;
                     w.flags = 1u;
-                    w.pad = 0;
+                    w.out = 0;
                     m.win_start = start;
                     m.clip_left = (int32_t)clipL;
                     m.clip_right = (int32_t)clipR;
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     // block-aggregated append: slots are first reserved in LDS, then one global atomic per block and
     // class (per-lane or even per-wave atomics on one address serialise at ~12 ns each and dominated
     // this kernel)
-    __shared__ uint32_t s_cnt[NUM_LISTS], s_base[NUM_LISTS], s_maxlr[NUM_LISTS], s_err, s_items, s_maxlq;
+    __shared__ uint32_t s_cnt[NUM_LISTS], s_base[NUM_LISTS], s_maxlr[NUM_LISTS], s_err, s_items, s_maxlq, s_out_base;
     __shared__ unsigned long long s_cells, s_bytes, s_ck;
     __shared__ uint32_t s_key[GATE_BLOCK], s_rank[GATE_BLOCK], s_stat[3];
     if (threadIdx.x < NUM_LISTS) { s_cnt[threadIdx.x] = 0; s_maxlr[threadIdx.x] = 0; }
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
         atomicMax(&a.counters[NUM_LISTS + threadIdx.x], s_maxlr[threadIdx.x]);
     }
     if (threadIdx.x == 0) {
+        if (s_items) s_out_base = atomicAdd(&a.counters[2 * NUM_LISTS + 3], s_items);  // the block's entries of the result array
         if (s_cells) {
             atomicAdd(&a.counters64[0 * C64_STRIDE], s_cells);
             atomicAdd(&a.counters64[1 * C64_STRIDE], s_bytes);
@@ -328,7 +338,8 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(GateArgs a) {
     __syncthreads();
     if (cls >= 0) {
         const uint32_t slot = s_base[cls] + s_rank[compact];
-        if (slot < a.list_cap[cls]) {
+        w.out = s_out_base + compact;
+        if (slot < a.list_cap[cls] && w.out < a.out_cap) {
             a.work[cls][slot] = w;
             a.meta[cls][slot] = m;
         } else atomicOr(&a.counters[2 * NUM_LISTS], 32u);  // more items than the host's bound: never written, reported at collect
@@ -357,6 +368,7 @@ struct SelArgs {
     int32_t match;          // score of a matching pair; 0 switches the forced-diagonal shortcut off
     int32_t mismatch;
     int32_t enabled;        // 0: the launch only scores (single-pass A/B kernels never get here)
+    int32_t no_ckpt;        // 1: this launch leaves no snapshots: every candidate is traced from step 0
 };
 
 struct SwArgs {
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
     const bool have = item < a.n_items;
     Work w;
     if (have) w = a.work[item];
-    else { w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.pad = 0; }
+    else { w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.out = 0; }
     const int lq = (int)w.lq, lr = (int)w.lr;
 
     // steps this wave needs: longest window of its 4 groups + 15 lanes of skew, in blocks of 4
@@ -542,7 +554,7 @@ struct TbArgs {
     const uint32_t *trace;
     uint64_t quad_stride;
     ScoreTab sc;
-    fadehip_aln *out;       // [n_items] at this launch's base
+    fadehip_aln *out;       // the run's result array; an alignment reports into entry Work::out
     uint8_t *rs;            // level 2: per-read status, OR-ed with the artifact bits
     unsigned long long *stats;  // level 2: stats.d:45-54 [3] art_sup, [4] art, [6] aln_l, [7] aln_r are added here
     int32_t floor_len;
@@ -726,7 +738,7 @@ __device__ __forceinline__ uint32_t traceback_path(const TbArgs &a, const int sr
         o.clip_left = m.clip_left;
         o.clip_right = m.clip_right;
         o.aligned_len = m.aligned_len;
-        a.out[src] = o;
+        a.out[w.out] = o;
         return 0u;
     }
     if (left_range && !(state == 0 && h == 0)) return 8u;  // the path continues before step T0: trace again from further back
@@ -765,6 +777,14 @@ __device__ __forceinline__ uint32_t traceback_path(const TbArgs &a, const int sr
         n++;
     }
     o.sw.n_ops = n;
+    if (a.early_out && n > 10) {
+        // more than 10 ops: analysis.d:69-70 rejects the result whatever the ops are.  Reported like an alignment that was
+        // not traced, exactly as the score pass's forced-diagonal shortcut reports such a path (select_one)
+        o.sw.beg_query = o.sw.beg_ref = -1;
+        o.sw.n_ops = 0;
+#pragma unroll
+        for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+    }
 
     if (a.meta) {
         const Meta m = a.meta[src];
@@ -796,7 +816,7 @@ __device__ __forceinline__ uint32_t traceback_path(const TbArgs &a, const int sr
         o.win_len = (int32_t)w.lr;
         o.clip_left = o.clip_right = o.aligned_len = 0;
     }
-    a.out[src] = o;
+    a.out[w.out] = o;
     return art_ret;
 }
 
@@ -857,7 +877,7 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
                 o.sw.beg_ref = -1;
                 o.sw.n_ops = 0;
                 for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
-                a.out[item] = o;
+                a.out[w.out] = o;
             }
         }
         // Forced-diagonal shortcut.  Walk back along the end cell's diagonal d_0 = (end_q, end_r), d_1, ... with
@@ -873,17 +893,20 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
             const int lq = (int)w.lq;
             const bool n_eq_n = rule(rules, FADEHIP_RULE_N_MATCHES_N), eq_by_char = rule(rules, FADEHIP_RULE_EQ_BY_CHAR);
             const bool pad = rule(rules, FADEHIP_RULE_PAD_SOFTCLIP);
-            // Up to four runs of = / X are kept, in registers (r0 = the run nearest the start of the alignment): a forced
-            // diagonal with more mismatching stretches than that goes to pass 2 like a gapped path.  Nothing here is
-            // indexed dynamically, so the score pass needs no scratch memory.
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            // Up to nine runs of = / X are kept, in registers (r0 = the run nearest the start of the alignment): with the
+            // two S pads that is every CIGAR analysis.d:69 can still accept (<= 10 ops), and a level-2 result with more ops
+            // than that is rejected whatever they are, so it is reported as "not traced" right here.  Only gapped paths (and,
+            // at level 1 / trace_all, forced diagonals of more than nine runs) go to pass 2.  Nothing here is indexed
+            // dynamically, so the score pass needs no scratch memory.
+            constexpr int MAX_RUNS = 9;
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0;
             int n_runs = 0, cur_op = -1;
             uint32_t cur_len = 0;
             int P = f.score, L = 0;
             bool ok = false, give_up = false;
             const int kmax = min(f.end_q, f.end_r) + 1;  // cells of the diagonal inside the matrix
             auto push_run = [&](uint32_t v) {
-                r3 = r2; r2 = r1; r1 = r0; r0 = v;
+                r8 = r7; r7 = r6; r6 = r5; r5 = r4; r4 = r3; r3 = r2; r2 = r1; r1 = r0; r0 = v;
                 n_runs++;
             };
             // 32 cells per round trip: the loads of four 8-cell pieces are issued together
@@ -930,9 +953,13 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
                     }
                 }
             }
+            bool too_many = false;  // a forced diagonal whose CIGAR has more than 10 ops: analysis.d:69-70 rejects it
             if (ok) {
                 push_run((cur_len << 4) | (uint32_t)cur_op);
-                if (n_runs > 4) ok = false;
+                const int lead0 = f.end_q - L + 1, tail0 = lq - 1 - f.end_q;
+                const int n_all = n_runs + ((pad && lead0 > 0) ? 1 : 0) + ((pad && tail0 > 0) ? 1 : 0);
+                too_many = n_all > 10 && a.meta && a.gate && !a.trace_all;
+                if (n_runs > MAX_RUNS && !too_many) ok = false;
             }
             if (ok) {
                 cand = false;
@@ -942,31 +969,48 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
                 o.sw.score = f.score;
                 o.sw.end_query = f.end_q;
                 o.sw.end_ref = f.end_r;
+#pragma unroll
+                for (int k = 0; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+                if (too_many) {  // reported like an alignment that was not traced (as traceback_path does for such a path)
+                    o.sw.beg_query = o.sw.beg_ref = -1;
+                    o.sw.n_ops = 0;
+                    const Meta m = a.meta[item];
+                    o.win_start = m.win_start;
+                    o.win_len = (int32_t)w.lr;
+                    o.clip_left = m.clip_left;
+                    o.clip_right = m.clip_right;
+                    o.aligned_len = m.aligned_len;
+                    a.out[w.out] = o;
+                } else {
                 o.sw.beg_query = f.end_q - L + 1;
                 o.sw.beg_ref = f.end_r - L + 1;
                 const int lead = o.sw.beg_query, tail = lq - 1 - f.end_q;
-                // [lead S] r0 .. r(n_runs-1) [tail S], assembled by shifting (no dynamic index)
-                uint32_t e0 = r0, e1 = r1, e2 = r2, e3 = r3, e4 = 0, e5 = 0;
-                int n = n_runs;
-                const uint32_t tail_op = ((uint32_t)tail << 4) | 4u;
-                if (pad && tail > 0) {
-                    if (n == 1) e1 = tail_op;
-                    else if (n == 2) e2 = tail_op;
-                    else if (n == 3) e3 = tail_op;
-                    else e4 = tail_op;
-                    n++;
-                }
-                if (pad && lead > 0) {
-                    e5 = e4; e4 = e3; e3 = e2; e2 = e1; e1 = e0;
-                    e0 = ((uint32_t)lead << 4) | 4u;
-                    n++;
-                }
-                o.sw.ops[0] = e0; o.sw.ops[1] = e1; o.sw.ops[2] = e2; o.sw.ops[3] = e3; o.sw.ops[4] = e4; o.sw.ops[5] = e5;
+                // [lead S] r0 .. r(n_runs-1) [tail S]: the ops go straight to the result entry in memory (a dynamic index
+                // into memory costs an address, into registers it would cost scratch); the rest of the record follows below
+                uint32_t *const gops = a.out[w.out].sw.ops;
+                int n = 0;
+                const uint32_t lead_op = ((uint32_t)lead << 4) | 4u, tail_op = ((uint32_t)tail << 4) | 4u;
+                if (pad && lead > 0) gops[n++] = lead_op;
+                if (n_runs > 0) gops[n + 0] = r0;
+                if (n_runs > 1) gops[n + 1] = r1;
+                if (n_runs > 2) gops[n + 2] = r2;
+                if (n_runs > 3) gops[n + 3] = r3;
+                if (n_runs > 4) gops[n + 4] = r4;
+                if (n_runs > 5) gops[n + 5] = r5;
+                if (n_runs > 6) gops[n + 6] = r6;
+                if (n_runs > 7) gops[n + 7] = r7;
+                if (n_runs > 8) gops[n + 8] = r8;
+                n += n_runs;
+                if (pad && tail > 0) gops[n++] = tail_op;
 #pragma unroll
-                for (int k = 6; k < FADEHIP_MAX_OPS; k++) o.sw.ops[k] = 0;
+                for (int k = 2; k < FADEHIP_MAX_OPS; k++)
+                    if (k >= n) gops[k] = 0;
+                if (n < 2) gops[1] = 0;
                 o.sw.n_ops = n;
-                const uint32_t first_op = e0;
-                const uint32_t last_op = n == 1 ? e0 : n == 2 ? e1 : n == 3 ? e2 : n == 4 ? e3 : n == 5 ? e4 : e5;
+                const uint32_t last_run = n_runs == 1 ? r0 : n_runs == 2 ? r1 : n_runs == 3 ? r2 : n_runs == 4 ? r3 : n_runs == 5 ? r4 :
+                                          n_runs == 6 ? r5 : n_runs == 7 ? r6 : n_runs == 8 ? r7 : r8;
+                const uint32_t first_op = (pad && lead > 0) ? lead_op : r0;
+                const uint32_t last_op = (pad && tail > 0) ? tail_op : last_run;
                 if (a.meta) {
                     const Meta m = a.meta[item];
                     o.win_start = m.win_start;
@@ -995,7 +1039,22 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
                     o.win_len = (int32_t)w.lr;
                     o.clip_left = o.clip_right = o.aligned_len = 0;
                 }
-                a.out[item] = o;
+                // everything but the ops (already in place)
+                fadehip_aln *const dst = &a.out[w.out];
+                dst->read_idx = o.read_idx;
+                dst->art = o.art;
+                dst->win_start = o.win_start;
+                dst->win_len = o.win_len;
+                dst->clip_left = o.clip_left;
+                dst->clip_right = o.clip_right;
+                dst->aligned_len = o.aligned_len;
+                dst->sw.score = o.sw.score;
+                dst->sw.end_query = o.sw.end_query;
+                dst->sw.end_ref = o.sw.end_ref;
+                dst->sw.beg_query = o.sw.beg_query;
+                dst->sw.beg_ref = o.sw.beg_ref;
+                dst->sw.n_ops = o.sw.n_ops;
+                }
             }
         }
         if (cand) {
@@ -1006,7 +1065,7 @@ __device__ __forceinline__ uint32_t select_one(const SelArgs &a, const int item,
             const int span = span_cols + span_cols / R + 2;
             const int t_end = f.end_r + f.end_q / R;
             int c0 = t_end + 1 - span;
-            c0 = c0 < CK_COLS ? 0 : (c0 & ~(CK_COLS - 1));
+            c0 = (c0 < CK_COLS || a.no_ckpt) ? 0 : (c0 & ~(CK_COLS - 1));
             const int steps = t_end + 1 - c0;
             b = 0;
             while (steps > bucket_cols(b)) b++;
@@ -1177,7 +1236,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     const int itemA = oct * 8 + g * 2, itemB = itemA + 1;
     Work wa, wb;
     wa.r_base = wb.r_base = 0; wa.q_base = wb.q_base = 0; wa.lq = wb.lq = 0; wa.lr = wb.lr = 0;
-    wa.idx = wb.idx = 0; wa.flags = wb.flags = 0; wa.pad = wb.pad = 0;
+    wa.idx = wb.idx = 0; wa.flags = wb.flags = 0; wa.out = wb.out = 0;
     int stepsA = 0, stepsB = 0;  // MODE 2: sweep steps to run for each half
     const uint64_t trace_off = (uint64_t)(P2 ? (int)blockIdx.x : oct) * a.quad_stride;
     if constexpr (P2) {
@@ -1209,35 +1268,67 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     const int n_blocks = (maxst + 3) >> 2;
 
     // ---- stage both windows: 16 bits per column = (7 classA + classB) * 16, the byte offset into wtab
+    // Eight columns per lane and trip: the two aligned dwords that hold them (load_nib8) instead of eight byte loads,
+    // and one 16-byte LDS store (ref_stride is a multiple of 16 and n_cols of 4; the last store may run up to 4
+    // columns into the slack the host adds to ref_stride).
     uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
     const int n_cols = n_blocks * 4;
-    for (int k = lig; k < n_cols; k += 16) {
-        uint32_t ca = PAD_CLASS, cb = PAD_CLASS;
-        if (k < lrA) ca = lut4(CLASS_LUT, nib_at(a.r_nib, wa.r_base + (uint64_t)k));
-        if (k < lrB) cb = lut4(CLASS_LUT, nib_at(a.r_nib, wb.r_base + (uint64_t)k));
-        lref[k] = (uint16_t)((7u * ca + cb) * 16u);
+    for (int k0 = lig * 8; k0 < n_cols; k0 += 128) {
+        Nib8 na, nb;
+        na.word = nb.word = 0; na.byte0 = nb.byte0 = 0;
+        const uint64_t ra0 = wa.r_base + (uint64_t)k0, rb0 = wb.r_base + (uint64_t)k0;
+        if (k0 < lrA) na = load_nib8(a.r_nib, ra0);
+        if (k0 < lrB) nb = load_nib8(a.r_nib, rb0);
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t ca = PAD_CLASS, cb = PAD_CLASS;
+            if (k0 + j < lrA) ca = lut4(CLASS_LUT, nib8_at(na, ra0 + (uint32_t)j));
+            if (k0 + j < lrB) cb = lut4(CLASS_LUT, nib8_at(nb, rb0 + (uint32_t)j));
+            const uint32_t e = (7u * ca + cb) * 16u;
+            if (j & 1) o[j >> 1] |= e << 16;
+            else o[j >> 1] = e;
+        }
+        *reinterpret_cast<uint4 *>(lref + k0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    // query classes per row (A | B << 16); `special` = some real row is N or a wildcard (class >= 4)
+    // query classes per row (A | B << 16); `special` = some real row is N or a wildcard (class >= 4).  A lane's R rows
+    // are R consecutive bases of the (reverse-complemented) query: eight per pair of aligned dwords.
     uint32_t qcls[R];
     bool special = false;
+    {
+        constexpr int NCH = (R + 7) / 8;
+        const int row0 = lig * R;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int row = lig * R + r;
-        uint32_t qa = PAD_CLASS, qb = PAD_CLASS;
-        if (row < lqA) {
-            uint32_t code;
-            if (wa.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)wa.q_base + (uint32_t)(lqA - 1 - row)));
-            else code = nib_at(a.q_nib, (uint64_t)wa.q_base + (uint32_t)row);
-            qa = lut4(CLASS_LUT, code);
+        for (int ch = 0; ch < NCH; ch++) {
+            // rows row0 + 8 ch .. + 7 are query bases (rc: lq - 1 - row, descending) of A and of B
+            const int rlo = row0 + 8 * ch;
+            const int nA = max(0, min(8, min(R - 8 * ch, lqA - rlo))), nB = max(0, min(8, min(R - 8 * ch, lqB - rlo)));
+            const bool rcA = wa.flags & 1u, rcB = wb.flags & 1u;
+            // first (lowest) nibble index of the piece
+            const uint64_t qa0 = rcA ? (uint64_t)wa.q_base + (uint32_t)(lqA - rlo - nA) : (uint64_t)wa.q_base + (uint32_t)rlo;
+            const uint64_t qb0 = rcB ? (uint64_t)wb.q_base + (uint32_t)(lqB - rlo - nB) : (uint64_t)wb.q_base + (uint32_t)rlo;
+            Nib8 na, nb;
+            na.word = nb.word = 0; na.byte0 = nb.byte0 = 0;
+            if (nA > 0) na = load_nib8(a.q_nib, qa0);
+            if (nB > 0) nb = load_nib8(a.q_nib, qb0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = 8 * ch + j;
+                if (r < R) {
+                    uint32_t qa = PAD_CLASS, qb = PAD_CLASS;
+                    if (j < nA) {
+                        const uint32_t raw = nib8_at(na, rcA ? qa0 + (uint32_t)(nA - 1 - j) : qa0 + (uint32_t)j);
+                        qa = lut4(CLASS_LUT, rcA ? lut4(COMP_LUT, raw) : raw);
+                    }
+                    if (j < nB) {
+                        const uint32_t raw = nib8_at(nb, rcB ? qb0 + (uint32_t)(nB - 1 - j) : qb0 + (uint32_t)j);
+                        qb = lut4(CLASS_LUT, rcB ? lut4(COMP_LUT, raw) : raw);
+                    }
+                    special |= qa == 4u || qa == 5u || qb == 4u || qb == 5u;
+                    qcls[r] = qa | (qb << 16);
+                }
+            }
         }
-        if (row < lqB) {
-            uint32_t code;
-            if (wb.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)(lqB - 1 - row)));
-            else code = nib_at(a.q_nib, (uint64_t)wb.q_base + (uint32_t)row);
-            qb = lut4(CLASS_LUT, code);
-        }
-        special |= (row < lqA && qa >= 4u) || (row < lqB && qb >= 4u);
-        qcls[r] = qa | (qb << 16);
     }
 
     // End-cell tracking.  MODE 0: a 32-bit key (H, 0xffff - t) per row and alignment.  MODE 1: one packed 16-bit
@@ -1652,7 +1743,7 @@ __global__ __launch_bounds__(64) void sw_long_kernel(LongArgs a) {
     if (a.count_dev) n_live = min(n_live, max(0, (int)*a.count_dev - (int)a.item_base));
     const bool have = item < n_live;
     Work w;
-    w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.pad = 0;
+    w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.out = 0;
     if (have) w = a.work[item];
     const int lq = (int)w.lq, lr = (int)w.lr;
     const uint32_t n = (uint32_t)a.n_items;

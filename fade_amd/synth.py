@@ -208,3 +208,19 @@ def take(batch, idx):
     if "qname" in batch:
         out["qname"] = [batch["qname"][i] for i in idx]
     return out
+
+
+def concat(batches):
+    """One batch out of several (records in order)."""
+    out = {}
+    for k in ("tid", "pos", "flag", "has_sa", "l_seq", "cigar_ops", "seq_packed", "qual"):
+        out[k] = np.concatenate([b[k] for b in batches])
+    for off, data in (("cigar_off", "cigar_ops"), ("seq_off", "seq_packed"), ("qual_off", "qual")):
+        parts, base = [np.zeros(1, dtype=np.int64)], 0
+        for b in batches:
+            parts.append(np.asarray(b[off], dtype=np.int64)[1:] + base)
+            base += len(b[data])
+        out[off] = np.concatenate(parts).astype(batches[0][off].dtype)
+    if all("qname" in b for b in batches):
+        out["qname"] = [q for b in batches for q in b["qname"]]
+    return out

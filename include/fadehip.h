@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FADEHIP_ABI_VERSION 2
+#define FADEHIP_ABI_VERSION 3
 #define FADEHIP_MAX_OPS 16   /* ops reported per alignment (FADE rejects > 10, analysis.d:69) */
 #define FADEHIP_MAX_QUERY 512 /* longest query of the wave kernels (8 alignments per wavefront) */
 #define FADEHIP_MAX_LONG_QUERY 32768 /* longer queries, up to this, take a thread-per-alignment kernel (slow path) */
@@ -153,6 +153,16 @@ typedef struct {
      * itself (about 1 ms per 10^5 records on one host thread).  A bound that turns out too small fails the batch at
      * collect (FADEHIP_E_INVALID), it is never trusted for memory safety. */
     int32_t ref_span_bound;
+    /* ABI 3.  What a caller that fills its own block knows for free and the library otherwise finds with one pass over
+     * the records (about 1 ms per 10^6 records on one host thread): the number of records that carry bases (a non-empty
+     * seq_packed slice — only those can be re-aligned) and the shortest / longest l_seq among THOSE.  With
+     * n_with_seq > 0 (and ref_span_bound > 0) fadehip_annotate_upload does no per-record host work: the launches and
+     * result buffers of the run are sized from these bounds, and cigar_off / seq_off / l_seq are validated by the gate
+     * kernel before anything is dereferenced through them.  A bound that turns out too small fails the batch at results
+     * (FADEHIP_E_INVALID); it is never trusted for memory safety.  0 = unknown. */
+    int32_t n_with_seq;
+    int32_t l_seq_min, l_seq_max;
+    int32_t reserved;
 } fadehip_read_batch;
 
 /* One pinned block for the nine arrays of a batch, so that upload is ONE hipMemcpyAsync at PCIe speed: allocate
@@ -165,8 +175,8 @@ int fadehip_batch_bind(void *base, int32_t n_reads, int64_t n_cigar_ops, int64_t
 /* One entry per read that was re-aligned (clip longer than min-length), in no particular order.
  * sw.score / end_query / end_ref are always set.  Unless params.trace_all, the traceback (beg_*, ops)
  * is only completed when the result can still be an artifact call; otherwise sw.n_ops == 0, beg_* == -1
- * (score or end cell already fail analysis.d:74-80 / 98-104, or the path was abandoned once it had
- * more than 10 ops, which analysis.d:69-70 rejects). */
+ * (score or end cell already fail analysis.d:74-80 / 98-104, or the CIGAR has more than 10 ops, which
+ * analysis.d:69-70 rejects whatever they are). */
 typedef struct {
     int32_t read_idx;
     int32_t art;         /* bit0 art_left, bit1 art_right (analysis.d:82,106) */

@@ -14,8 +14,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH2="python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu"
-BENCH1="python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu --slots 1"
+BENCH2="python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu --no-e2e"
+BENCH1="python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu --no-e2e --slots 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- $BENCH2 > $OUT/stats2.log 2>&1 || exit 1
 grep '^{' $OUT/stats2.log > $OUT/bench_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH1 > $OUT/stats.log 2>&1 || exit 1

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libfadehip.so lacks %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert L.fadehip_abi_version() == _lib.ABI_VERSION == 2
+    assert L.fadehip_abi_version() == _lib.ABI_VERSION == 3
     hdr = open(os.path.join(ROOT, "include", "fadehip.h")).read()
     assert "#define FADEHIP_ABI_VERSION %d" % _lib.ABI_VERSION in hdr and "#define FADEHIP_NUM_SLOTS %d" % _lib.NUM_SLOTS in hdr
     p = _lib.Params()
@@ -52,7 +52,7 @@ def test_batch_block_layout():
     assert spans[0][0] == base and spans[-1][1] <= base + total
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
         assert a1 <= b0 and b0 % 256 == 0
-    assert b.n_reads == n and b.n_skipped == 0 and b.ref_span_bound == 0
+    assert b.n_reads == n and b.n_skipped == 0 and b.ref_span_bound == 0 and b.n_with_seq == 0 and b.l_seq_max == 0
     assert L.fadehip_batch_bind(base + 8, n, n_cig, n_seq, ctypes.byref(b)) != 0  # misaligned block
 
 
@@ -60,7 +60,7 @@ def test_struct_layouts_match_header():
     from fade_amd import _lib
     assert ctypes.sizeof(_lib.SwResult) == 24 + 4 * 16
     assert ctypes.sizeof(_lib.Aln) == 32 + ctypes.sizeof(_lib.SwResult)
-    assert ctypes.sizeof(_lib.ReadBatch) == 8 + 9 * 8 + 8 and ctypes.sizeof(_lib.Params) == 40
+    assert ctypes.sizeof(_lib.ReadBatch) == 8 + 9 * 8 + 8 + 16 and ctypes.sizeof(_lib.Params) == 40
     assert ctypes.sizeof(_lib.AnnoView) == 16 + 8 + 64 + 8 and ctypes.sizeof(_lib.AnnoOut) == 16 + 8 + 64 + 8
     assert _lib.ALN_DTYPE.fields["sw"][1] == 32
 
@@ -160,6 +160,23 @@ def test_compact_sequences_keeps_exactly_the_records_the_gate_reads():
     assert 0 < kept < len(b["pos"]) // 2 and cs[-1] == len(c["seq_packed"])
 
 
+def test_with_bounds_describes_the_records_that_carry_bases():
+    """Context.with_bounds (the ABI-3 hints a packing thread passes): every record stays, only the ones the gate can
+    align keep their bases, and the bounds are those records' count, read lengths and longest alignedLength."""
+    from fade_amd import synth
+    from fade_amd.api import Context
+    g = synth.Genome(1, 200_000, 3)
+    b = synth.make_reads(g, 4000, 11, read_len=101, window=100, p_sc=0.25)
+    c = Context.with_bounds(b)
+    assert len(c["pos"]) == len(b["pos"]) and c["n_skipped"] == 0
+    co = b["cigar_off"].astype(np.int64)
+    need = np.array([bool(((b["cigar_ops"][co[i]:co[i + 1]] & 15) == 4).any()) and not (int(b["flag"][i]) & 4)
+                     for i in range(len(b["pos"]))])
+    assert c["n_with_seq"] == int(need.sum()) > 0 and c["l_seq_min"] == c["l_seq_max"] == 101
+    al = [sum(int(o) >> 4 for o in b["cigar_ops"][co[i]:co[i + 1]] if (int(o) & 15) in (0, 2, 3, 7, 8)) for i in np.nonzero(need)[0]]
+    assert c["ref_span_bound"] == max(al)
+
+
 def test_corrupt_bam_and_bgzf_inputs_are_rejected_under_sanitizers():
     """host/hts_lite.hpp against truncated / crafted records and blocks, built with ASan + UBSan
     (fade_amd/csrc/host/selftest/hts_selftest.cpp): aux fields that overrun the record, 'B' arrays with huge counts,
@@ -197,4 +214,4 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"),
                            str(src), "-o", str(exe), "-L", lib_dir, "-lfadehip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=60).stdout.decode().split()
-    assert out == ["2", str(len(names)), "127", "120"]
+    assert out == ["3", str(len(names)), "127", "120"]

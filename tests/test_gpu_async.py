@@ -218,3 +218,110 @@ def test_prefetching_uploads_pipeline(ctx):
         got[seq] = ctx.annotate_collect(seq % n_slots)
     for k in range(10):
         assert np.array_equal(got[k][0], ref[k][0]) and list(got[k][2]) == list(ref[k][2]) and _key(got[k][1]) == _key(ref[k][1]), k
+
+
+@pytest.mark.parametrize("name", ["C2", "C5"])
+def test_every_record_sent_with_the_callers_bounds_equals_full_batch(ctx, name):
+    """ABI 3: every record of the batch is sent (the device's gate does anno.d:61-65 for all of them), the records it can
+    never align without their bases, and upload sizes the run from the caller's bounds without walking the records."""
+    cfg, g, b = synth.make_config(name, 40_000, contig_len=500_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    rs0, aln0, st0 = ctx.annotate(b, cfg["floor_len"], cfg["window"])
+    allrec = ctx.with_bounds(b)
+    assert len(allrec["pos"]) == len(rs0) and 0 < allrec["n_with_seq"] < 0.4 * len(rs0)
+    assert len(allrec["seq_packed"]) < 0.4 * len(b["seq_packed"])
+    for form in ("dict", "pinned"):
+        batch = ctx.pinned_batch(allrec) if form == "pinned" else allrec
+        ctx.annotate_upload(1, batch)
+        ctx.annotate_run(1, cfg["floor_len"], cfg["window"])
+        rs1, aln1, st1 = ctx.annotate_collect(1)
+        assert np.array_equal(rs1, rs0), form
+        assert list(st1) == list(st0), form
+        assert _key(aln1) == _key(aln0), form
+    # reads of several lengths under one pair of bounds (three row classes)
+    parts = []
+    for k, L in enumerate((76, 150, 210)):
+        c2 = dict(cfg, read_len=L)
+        parts.append(synth.make_reads(g, 6000, 50 + k, **c2))
+    mixed = synth.concat(parts)
+    rs2, aln2, st2 = ctx.annotate(mixed, cfg["floor_len"], cfg["window"])
+    mb = ctx.with_bounds(mixed)
+    assert (mb["l_seq_min"], mb["l_seq_max"]) == (76, 210)
+    rs3, aln3, st3 = ctx.annotate(mb, cfg["floor_len"], cfg["window"], slot=2)
+    assert np.array_equal(rs2, rs3) and list(st2) == list(st3) and _key(aln2) == _key(aln3)
+
+
+def test_bounds_too_small_or_bad_offsets_fail_the_batch_not_the_device(ctx):
+    """The caller's bounds are never trusted for memory safety: the gate kernel checks list capacities and every
+    offset before it reads through it; the batch fails at results and the context stays usable."""
+    cfg, g, b = synth.make_config("C2", 20_000, contig_len=300_000)
+    ctx.genome_upload(g.names, g.ascii_contigs())
+    good = ctx.with_bounds(b)
+    rs0, aln0, st0 = ctx.annotate(good, cfg["floor_len"], cfg["window"])
+    few = dict(good, n_with_seq=good["n_with_seq"] // 3)
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(few, cfg["floor_len"], cfg["window"])
+    assert e.value.code == -1 and "bounds" in str(e.value)
+    short = dict(good, l_seq_max=64, l_seq_min=64)  # the reads have 150 bases: another row class than announced
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(short, cfg["floor_len"], cfg["window"])
+    assert e.value.code == -1
+    bad = dict(good)
+    so = good["seq_off"].copy()
+    so[1000] = so[-1] + 7_000_000  # points far beyond seq_packed
+    bad["seq_off"] = so
+    with pytest.raises(fade_amd.FadeHipError) as e:
+        ctx.annotate(bad, cfg["floor_len"], cfg["window"])
+    assert e.value.code == -1 and "seq_off" in str(e.value)
+    bad = dict(good)
+    co = good["cigar_off"].copy()
+    co[500] = co[499] - 1 if co[499] > 0 else 5  # decreasing
+    bad["cigar_off"] = co
+    with pytest.raises(fade_amd.FadeHipError):
+        ctx.annotate(bad, cfg["floor_len"], cfg["window"])
+    rs1, aln1, st1 = ctx.annotate(good, cfg["floor_len"], cfg["window"])
+    assert np.array_equal(rs0, rs1) and _key(aln0) == _key(aln1)
+
+
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_snapshots_on_and_off_give_the_same_bytes(monkeypatch, name):
+    """The score pass leaves wave snapshots only when the slot's previous run had many pass-2 candidates (otherwise a
+    candidate is traced from step 0).  Either way, and across the switch, the results are the same bytes — with the
+    forced-diagonal shortcut (few candidates) and without it (every candidate through pass 2)."""
+    cfg, g, b = synth.make_config(name, 24_000, contig_len=400_000)
+    outs = []
+    for shortcut in (True, False):
+        if not shortcut:
+            monkeypatch.setenv("FADEHIP_NO_SHORTCUT", "1")
+        for ck in ("0", "1", None):
+            if ck is None:
+                monkeypatch.delenv("FADEHIP_CKPT", raising=False)
+            else:
+                monkeypatch.setenv("FADEHIP_CKPT", ck)
+            c = fade_amd.Context(device=0)
+            try:
+                c.genome_upload(g.names, g.ascii_contigs())
+                for rep in range(3 if ck is None else 1):  # adaptive: the first run decides for the second
+                    rs, aln, st = c.annotate(b, cfg["floor_len"], cfg["window"])
+                    prof = c.last_profile(0)
+                    outs.append((rs.tobytes(), _key(aln), list(st)))
+                    if ck == "0":
+                        assert prof["snapshot_bytes"] == 0
+                    if ck == "1":
+                        assert prof["snapshot_bytes"] > 0
+                    if ck is None:
+                        # the first run of a slot leaves none; many candidates (no shortcut: all of them go through pass 2)
+                        # switch the snapshots on from the second run, few (C2 with the shortcut) leave them off
+                        frac = prof["candidates"] / max(prof["alignments"], 1)
+                        if rep == 0:
+                            assert prof["snapshot_bytes"] == 0
+                        else:
+                            assert (prof["snapshot_bytes"] > 0) == (frac > 1 / 32), (rep, shortcut, frac)
+                        if not shortcut:
+                            assert frac > 1 / 32
+                        elif name == "C2":
+                            assert frac < 1 / 32
+            finally:
+                c.close()
+    for o in outs[1:]:
+        assert o == outs[0]

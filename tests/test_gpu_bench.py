@@ -23,7 +23,7 @@ def _bench(args, env=None):
 
 
 def test_bench_spawns_its_ranks_and_reduces_over_them():
-    small = ["--steps", "2", "--warmup", "1", "--batch-reads", "20000", "--no-cpu"]
+    small = ["--steps", "2", "--warmup", "1", "--batch-reads", "20000", "--no-cpu", "--no-e2e"]
     one = _bench(["--gpus", "1"] + small)
     two = _bench(["--gpus", "2"] + small, env={"FADE_BENCH_BACKEND": "gloo", "MASTER_PORT": "29611"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
@@ -47,7 +47,7 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
     must not spawn again.  Two ranks on the one GPU (gloo for the collective)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--batch-reads", "20000", "--no-cpu"]
+           "--batch-reads", "20000", "--no-cpu", "--no-e2e"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, FADE_BENCH_BACKEND="gloo"))
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
