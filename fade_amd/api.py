@@ -264,6 +264,24 @@ class Context:
         self.annotate_run(slot, floor_len, window)
         return self.annotate_collect(slot)
 
+    # ---- BGZF compression of an output stream (util.d:65-76, anno.d:47-49)
+    def bgzf_deflate_submit(self, lane, data):
+        """data: bytes / uint8 array (kept alive until bgzf_deflate_wait)."""
+        arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        self._keep[("bgzf", lane)] = arr
+        self._chk(self._L.fadehip_bgzf_deflate_submit(self._h, lane, arr.ctypes.data, arr.nbytes))
+
+    def bgzf_deflate_wait(self, lane):
+        """The BGZF members of the submitted bytes (no end-of-file marker), as bytes."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.fadehip_bgzf_deflate_wait(self._h, lane, C.byref(ptr), C.byref(n)))
+        self._keep.pop(("bgzf", lane), None)
+        return C.string_at(ptr.value, n.value)
+
+    def bgzf_deflate(self, data, lane=0):
+        self.bgzf_deflate_submit(lane, data)
+        return self.bgzf_deflate_wait(lane)
+
     def sync(self):
         self._chk(self._L.fadehip_sync(self._h))
 

@@ -7,6 +7,7 @@
 // bounds, the real counts stay on the device, persistent waves draw the traced re-computation's work from a table a
 // planning kernel builds — and results / collect waits for the slot.
 #include "fadehip_kernels.hpp"
+#include "bgzf_deflate.hpp"
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <cstdarg>
@@ -141,6 +142,18 @@ struct Slot {
     std::vector<void *> trash;        // scratch buffers outgrown while a run was being enqueued (freed after the slot's sync)
 };
 
+// One BGZF compression in flight (fadehip_bgzf_deflate_submit / _wait): its own stream, so that the copies of one lane
+// run beside the kernels of the other.
+struct BgzfLane {
+    hipStream_t stream = nullptr;
+    DevBuf src, slots, meta, member_off, packed;  // meta: out_size [n] | out_crc [n] | ticket | total (u64)
+    PinBuf out;
+    uint64_t *h_total = nullptr;  // pinned
+    size_t n_bytes = 0;
+    uint32_t n_blocks = 0;
+    int state = 0;  // 0 idle, 1 submitted
+};
+
 }  // namespace
 
 struct fadehip_ctx {
@@ -168,6 +181,8 @@ struct fadehip_ctx {
     int p2_waves_fixed = 0;    // FADEHIP_P2_WAVES: waves of the persistent pass-2 launch (0: adaptive, see run_class_two_pass)
     int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
     bool debug = false;
+    BgzfLane bgzf[FADEHIP_BGZF_LANES];
+    bool bgzf_ready = false;           // the compressor's LDS size has been declared to the runtime
     std::map<uint64_t, int> resident;  // (class, mode, LDS bytes) -> waves of that kernel the device holds at once
     std::mutex resident_mu;
 };
@@ -1117,6 +1132,12 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (BgzfLane &l : ctx->bgzf) {
+        for (DevBuf *b : {&l.src, &l.slots, &l.meta, &l.member_off, &l.packed}) release(*b);
+        release(l.out);
+        if (l.h_total) (void)hipHostFree(l.h_total);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
     release(ctx->genome);
     for (DevBuf *b : {&ctx->l1_q, &ctx->l1_r, &ctx->l1_qn, &ctx->l1_rn, &ctx->l1_bad, &ctx->l1_work, &ctx->l1_aln}) release(*b);
     release(ctx->contig_len);
@@ -1571,6 +1592,76 @@ int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t co
     }
     HIPCHK(ctx, hipEventElapsedTime(&t, s.ev[s.ev_gate0], s.ev[s.ev_end]));
     ms[3] = t;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- BGZF compression
+int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, size_t n_bytes) {
+    if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
+    if (lane < 0 || lane >= FADEHIP_BGZF_LANES) return set_err(ctx, FADEHIP_E_INVALID, "bgzf lane %d out of range", lane);
+    if (!src || n_bytes == 0 || n_bytes > ((size_t)1 << 31)) return set_err(ctx, FADEHIP_E_INVALID, "bgzf: 1 .. 2^31 bytes per call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    BgzfLane &l = ctx->bgzf[lane];
+    if (!l.stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
+    }
+    if (!ctx->bgzf_ready) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)bgzf::bgzf_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bgzf::LDS_BYTES));
+        ctx->bgzf_ready = true;
+    }
+    if (l.state == 1) HIPCHK(ctx, hipStreamSynchronize(l.stream));  // never waited for: its buffers are still in use
+    l.state = 0;
+    const uint32_t nb = (uint32_t)((n_bytes + bgzf::BLOCK - 1) / bgzf::BLOCK);
+    int rc;
+    if ((rc = reserve(ctx, l.src, n_bytes + 64)) || (rc = reserve(ctx, l.slots, (size_t)nb * bgzf::SLOT)) ||
+        (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 64)) || (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) ||
+        (rc = reserve(ctx, l.packed, (size_t)nb * bgzf::SLOT)))
+        return rc;
+    uint32_t *d_size = (uint32_t *)l.meta.p, *d_crc = d_size + nb, *d_ticket = d_crc + nb;
+    uint64_t *d_total = (uint64_t *)(((uintptr_t)(d_ticket + 2) + 7) & ~(uintptr_t)7);
+    HIPCHK(ctx, hipMemcpyAsync(l.src.p, src, n_bytes, hipMemcpyHostToDevice, l.stream));
+    HIPCHK(ctx, hipMemsetAsync(d_ticket, 0, 8, l.stream));
+    bgzf::DeflateArgs a;
+    a.src = (const uint8_t *)l.src.p;
+    a.n_bytes = n_bytes;
+    a.n_blocks = nb;
+    a.slots = (uint8_t *)l.slots.p;
+    a.out_size = d_size;
+    a.out_crc = d_crc;
+    a.ticket = d_ticket;
+    const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(ctx->cu_count, 1));
+    hipLaunchKernelGGL(bgzf::bgzf_deflate_kernel, dim3(grid), dim3(bgzf::WG), bgzf::LDS_BYTES, l.stream, a);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(bgzf::bgzf_scan_kernel, dim3(1), dim3(1024), 0, l.stream, (const uint32_t *)d_size, nb, (uint64_t *)l.member_off.p, d_total);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(bgzf::bgzf_pack_kernel, dim3(nb), dim3(256), 0, l.stream, (const uint8_t *)l.slots.p, (const uint32_t *)d_size,
+                       (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, (uint8_t *)l.packed.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(l.h_total, d_total, 8, hipMemcpyDeviceToHost, l.stream));
+    l.n_bytes = n_bytes;
+    l.n_blocks = nb;
+    l.state = 1;
+    return 0;
+}
+
+int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, size_t *out_bytes) {
+    if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
+    if (lane < 0 || lane >= FADEHIP_BGZF_LANES) return set_err(ctx, FADEHIP_E_INVALID, "bgzf lane %d out of range", lane);
+    if (!out || !out_bytes) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
+    BgzfLane &l = ctx->bgzf[lane];
+    if (l.state != 1) return set_err(ctx, FADEHIP_E_STATE, "bgzf lane %d has nothing submitted", lane);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(l.stream));
+    const uint64_t total = *l.h_total;
+    l.state = 0;
+    if (total == 0 || total > (uint64_t)l.n_blocks * bgzf::SLOT) return set_err(ctx, FADEHIP_E_STATE, "internal: bgzf members add up to %llu bytes", (unsigned long long)total);
+    int rc = reserve_pinned(ctx, l.out, (size_t)total);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(l.out.p, l.packed.p, (size_t)total, hipMemcpyDeviceToHost, l.stream));
+    HIPCHK(ctx, hipStreamSynchronize(l.stream));
+    *out = l.out.p;
+    *out_bytes = (size_t)total;
     return 0;
 }
 

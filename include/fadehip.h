@@ -244,6 +244,22 @@ int fadehip_sync(fadehip_ctx *ctx);
  * pass 2 (int16 H and E-hat per query row every 32 sweep steps), counts[5] candidates traced by pass 2. */
 int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[6]);
 
+/* ------------------------------------------------------ BGZF compression of the output stream -- */
+/* What htslib's bgzf_write + zlib do behind SAMWriter(..., SAMWriterTypes.BAM) (util.d:65-76) for the write at
+ * anno.d:47-49: the uncompressed BAM byte stream cut into blocks of FADEHIP_BGZF_BLOCK bytes, each compressed into one
+ * BGZF member (SAM spec 4.1: gzip header with the BC subfield, one final dynamic-Huffman or stored DEFLATE block,
+ * CRC32, ISIZE).  On the device: one workgroup per block with the block in LDS (hash matching, minimum-redundancy
+ * codes, bit packing, CRC-32), then the members packed into one contiguous byte stream — what goes to the file, minus
+ * the end-of-file marker, which the caller appends once.  Any inflater reads it (zlib, htslib, samtools).
+ *   submit : H2D of src[0, n_bytes) (host memory; pinned memory from fadehip_host_alloc copies at PCIe speed), the
+ *            kernels; returns at once.  src must stay unchanged until wait returns.
+ *   wait   : the members' bytes in a pinned buffer of the lane, valid until the lane's next submit.
+ * Two lanes, each with its own stream: one compresses while the other's result is copied back. */
+#define FADEHIP_BGZF_BLOCK 0xff00
+#define FADEHIP_BGZF_LANES 2
+int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, size_t n_bytes);
+int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, size_t *out_bytes);
+
 /* Sum counters over the ranks' devices with one ncclAllReduce (RCCL) — single process, one ctx
  * per device.  counters is [n_ctx][count] in, every row holds the sum on return. */
 int fadehip_stats_allreduce(fadehip_ctx *const *ctxs, int n_ctx, int64_t *counters, int count);

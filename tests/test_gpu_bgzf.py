@@ -1,0 +1,138 @@
+"""BGZF compression on the device (include/fadehip.h fadehip_bgzf_deflate_*; fade_amd/csrc/bgzf_deflate.hpp) — what
+htslib's bgzf_write + zlib do for the write at anno.d:47-49 (util.d:65-76, SAMWriterTypes.BAM).
+Three properties, on every payload: (1) standard DEFLATE in BGZF members — Python's gzip / zlib inflate them, which also
+checks each member's CRC32 and ISIZE; (2) the inflated bytes are the input, byte for byte; (3) on BAM payloads the stream
+is no larger than zlib level 6's (htslib's default) over the same 0xff00-byte blocks."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import fade_amd
+from fade_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = _lib.BGZF_BLOCK
+EOF_MARK = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def members(buf):
+    """[(payload, crc, isize)] of a BGZF byte stream, checking the framing (SAM spec 4.1)."""
+    out, at = [], 0
+    while at < len(buf):
+        assert buf[at:at + 4] == b"\x1f\x8b\x08\x04" and buf[at + 10:at + 16] == b"\x06\x00BC\x02\x00", at
+        bsize = struct.unpack_from("<H", buf, at + 16)[0] + 1
+        crc, isize = struct.unpack_from("<II", buf, at + bsize - 8)
+        out.append((buf[at + 18:at + bsize - 8], crc, isize))
+        at += bsize
+    assert at == len(buf)
+    return out
+
+
+def zlib6_size(data):
+    total = 0
+    for o in range(0, len(data), BLOCK):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        total += len(c.compress(data[o:o + BLOCK]) + c.flush()) + 26
+    return total
+
+
+def bam_payload(n_reads, seed, runny):
+    """An uncompressed BAM record stream: 100-150 base reads, qualities uniform in [20, 40] or binned with runs (the law of
+    tests/test_bgzf_codec.py::test_block_writer_with_layout_hints), an NM tag."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for i in range(n_reads):
+        lq = int(rng.integers(100, 151))
+        name = b"read%d\0" % i
+        seq = rng.integers(0, 4, lq + (lq & 1))
+        nt = np.array([1, 2, 4, 8], dtype=np.uint8)[seq]
+        packed = ((nt[0::2] << 4) | nt[1::2]).astype(np.uint8).tobytes()
+        if runny:
+            change = rng.random(lq) < 0.08
+            vals = rng.choice([2, 11, 25, 37], lq, p=[0.05, 0.1, 0.15, 0.7])
+            q, cur = np.empty(lq, np.uint8), 37
+            for k in range(lq):
+                if change[k]:
+                    cur = int(vals[k])
+                q[k] = cur
+            qual = q.tobytes()
+        else:
+            qual = rng.integers(20, 41, lq, dtype=np.uint8).tobytes()
+        body = struct.pack("<iiBBHHHiiii", 0, int(rng.integers(0, 900000)), len(name), 60, 4681, 1, 0, lq, -1, -1, 0) + name + \
+            struct.pack("<I", lq << 4) + packed + qual + b"NMC" + bytes([int(rng.integers(0, 4))])
+        parts.append(struct.pack("<I", len(body)) + body)
+    return b"".join(parts)
+
+
+@pytest.fixture(scope="module")
+def payloads():
+    rng = np.random.default_rng(1)
+    text = b"".join(b"the quick brown fox jumps over the lazy dog %d\n" % int(x) for x in rng.integers(0, 1000, 9000))
+    return {
+        "bam, uniform qualities": bam_payload(3000, 2, False),
+        "bam, run-heavy qualities": bam_payload(3000, 3, True),
+        "random": rng.integers(0, 256, 3 * BLOCK + 17, dtype=np.uint8).tobytes(),
+        "zeros": bytes(2 * BLOCK + 5),
+        "text": text,
+        "short period": bytes((i % 7) * 31 & 255 for i in range(BLOCK)),
+        "one block exactly": rng.integers(0, 4, BLOCK, dtype=np.uint8).tobytes(),
+        "one block and a byte": rng.integers(0, 4, BLOCK + 1, dtype=np.uint8).tobytes(),
+    }
+
+
+def test_members_inflate_to_the_input_and_are_no_larger_than_zlib6(ctx, payloads):
+    for name, data in payloads.items():
+        out = ctx.bgzf_deflate(data)
+        ms = members(out)
+        assert len(ms) == (len(data) + BLOCK - 1) // BLOCK, name
+        at = 0
+        for payload, crc, isize in ms:  # each member on its own: raw DEFLATE, CRC32 and ISIZE of its block
+            raw = zlib.decompress(payload, -15)
+            assert raw == data[at:at + isize] and zlib.crc32(raw) == crc and isize == min(BLOCK, len(data) - at), (name, at)
+            at += isize
+        assert gzip.decompress(out + EOF_MARK) == data, name  # and as the file a BAM reader sees
+        if name.startswith("bam"):
+            assert len(out) <= zlib6_size(data), (name, len(out), zlib6_size(data))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 258, 259, 1000, 4099])
+def test_tiny_streams(ctx, n):
+    rng = np.random.default_rng(n)
+    for data in (rng.integers(0, 256, n, dtype=np.uint8).tobytes(), bytes(n), bytes([65 + (i % 3) for i in range(n)])):
+        out = ctx.bgzf_deflate(data)
+        assert gzip.decompress(out + EOF_MARK) == data
+        assert len(members(out)) == 1
+
+
+def test_two_lanes_in_flight_and_repeated_use(ctx):
+    """Two submissions in flight (each lane has its own stream and buffers), lanes reused with other sizes."""
+    rng = np.random.default_rng(9)
+    datas = [bam_payload(int(k), 20 + i, i % 2 == 1) for i, k in enumerate((1500, 400, 2500, 50, 1200))]
+    ref = [ctx.bgzf_deflate(d) for d in datas]
+    for d, r in zip(datas, ref):
+        assert gzip.decompress(r + EOF_MARK) == d
+    got = [None] * len(datas)
+    for k in range(len(datas) + 2):
+        lane = k % 2
+        if k >= 2:
+            got[k - 2] = ctx.bgzf_deflate_wait(lane)
+        if k < len(datas):
+            ctx.bgzf_deflate_submit(lane, datas[k])
+    assert got == ref  # (the compressor is deterministic)
+
+
+def test_large_stream_at_rate(ctx):
+    """64 MB of BAM payload: round trip, and the device rate printed (-s shows it)."""
+    import time
+    base = bam_payload(20000, 77, False)
+    data = base * (64 * 1024 * 1024 // len(base))
+    ctx.bgzf_deflate(data[:BLOCK * 8])
+    t0 = time.perf_counter()
+    out = ctx.bgzf_deflate(data)
+    dt = time.perf_counter() - t0
+    print("bgzf deflate: %.1f MB in %.1f ms = %.2f GB/s (host memory pageable), ratio %.4f" % (len(data) / 1e6, dt * 1e3, len(data) / dt / 1e9, len(out) / len(data)))
+    assert gzip.decompress(out + EOF_MARK) == data
