@@ -21,51 +21,81 @@ namespace bgzf {
 constexpr int NUM_LITLEN = 286, NUM_DIST = 30, NUM_CL = 19;
 constexpr int MAX_LITLEN_BITS = 15, MAX_CL_BITS = 7;
 
+// Arrays are reached through accessors (get / set) so that the same code runs on plain memory (host, MemArr) and on
+// arrays spread over the lanes of a wavefront (device: WaveArr in bgzf_deflate.hpp, v_readlane / v_writelane — a
+// dependent LDS round trip costs ~130 clocks, a lane access ~10, and these loops are chains of dependent accesses).
+struct MemArr {
+    uint32_t *p;
+    FADE_HD uint32_t get(int i) const { return p[i]; }
+    FADE_HD void set(int i, uint32_t v) { p[i] = v; }
+};
+template <class T>
+struct MemArrT {
+    T *p;
+    FADE_HD uint32_t get(int i) const { return (uint32_t)p[i]; }
+    FADE_HD void set(int i, uint32_t v) { p[i] = (T)v; }
+};
+
 // ---- minimum-redundancy code lengths in place (Moffat & Katajainen 1995).  A[0..m) = frequencies in ASCENDING order
-// (all > 0) on entry, code lengths (descending) on return.  m >= 2.
-FADE_HD void mr_code_lengths(uint32_t *A, int m) {
-    if (m == 1) { A[0] = 1; return; }
-    A[0] += A[1];
+// (all > 0) on entry, code lengths (descending) on return.
+template <class Arr>
+FADE_HD void mr_code_lengths_t(Arr &A, int m) {
+    if (m == 1) { A.set(0, 1); return; }
+    A.set(0, A.get(0) + A.get(1));
     int root = 0, leaf = 2;
     for (int next = 1; next < m - 1; next++) {
-        if (leaf >= m || A[root] < A[leaf]) { A[next] = A[root]; A[root++] = (uint32_t)next; }
-        else A[next] = A[leaf++];
-        if (leaf >= m || (root < next && A[root] < A[leaf])) { A[next] += A[root]; A[root++] = (uint32_t)next; }
-        else A[next] += A[leaf++];
+        uint32_t v;
+        if (leaf >= m || A.get(root) < A.get(leaf)) { v = A.get(root); A.set(root++, (uint32_t)next); }
+        else v = A.get(leaf++);
+        if (leaf >= m || (root < next && A.get(root) < A.get(leaf))) { v += A.get(root); A.set(root++, (uint32_t)next); }
+        else v += A.get(leaf++);
+        A.set(next, v);
     }
-    A[m - 2] = 0;
-    for (int next = m - 3; next >= 0; next--) A[next] = A[A[next]] + 1;
+    A.set(m - 2, 0);
+    for (int next = m - 3; next >= 0; next--) A.set(next, A.get((int)A.get(next)) + 1);
     int avbl = 1, used = 0, depth = 0;
     root = m - 2;
     int next = m - 1;
     while (avbl > 0) {
-        while (root >= 0 && (int)A[root] == depth) { used++; root--; }
-        while (avbl > used) { A[next--] = (uint32_t)depth; avbl--; }
+        while (root >= 0 && (int)A.get(root) == depth) { used++; root--; }
+        while (avbl > used) { A.set(next--, (uint32_t)depth); avbl--; }
         avbl = 2 * used;
         depth++;
         used = 0;
     }
 }
+FADE_HD void mr_code_lengths(uint32_t *A, int m) {
+    MemArr a{A};
+    mr_code_lengths_t(a, m);
+}
 
 // ---- length limit.  A[0..m) = optimal lengths of the symbols in ascending order of frequency (so lengths descend).
 // Counts per length with everything beyond max_bits folded into max_bits; while the Kraft sum exceeds 1, one code of
 // max_bits is taken away and the deepest shorter code becomes two codes one bit longer (the number of codes stays, the
-// sum drops by 2^-max_bits); then the lengths are handed out again, longest to the rarest.  bl[0..32] is scratch.
-FADE_HD void limit_code_lengths(uint32_t *A, int m, int max_bits, uint32_t *bl) {
-    if (m < 2 || (int)A[0] <= max_bits) return;
-    for (int b = 0; b <= max_bits; b++) bl[b] = 0;
-    for (int i = 0; i < m; i++) bl[(int)A[i] > max_bits ? max_bits : (int)A[i]]++;
+// sum drops by 2^-max_bits); then the lengths are handed out again, longest to the rarest.  bl[0..max_bits] is scratch.
+template <class Arr, class Bl>
+FADE_HD void limit_code_lengths_t(Arr &A, int m, int max_bits, Bl &bl) {
+    if (m < 2 || (int)A.get(0) <= max_bits) return;
+    for (int b = 0; b <= max_bits; b++) bl.set(b, 0);
+    for (int i = 0; i < m; i++) {
+        const int l = (int)A.get(i) > max_bits ? max_bits : (int)A.get(i);
+        bl.set(l, bl.get(l) + 1);
+    }
     uint32_t total = 0;
-    for (int b = max_bits; b > 0; b--) total += bl[b] << (max_bits - b);
+    for (int b = max_bits; b > 0; b--) total += bl.get(b) << (max_bits - b);
     while (total != (1u << max_bits)) {
-        bl[max_bits]--;
+        bl.set(max_bits, bl.get(max_bits) - 1);
         for (int b = max_bits - 1; b > 0; b--)
-            if (bl[b]) { bl[b]--; bl[b + 1] += 2; break; }
+            if (bl.get(b)) { bl.set(b, bl.get(b) - 1); bl.set(b + 1, bl.get(b + 1) + 2); break; }
         total--;
     }
     int i = 0;
     for (int bits = max_bits; bits >= 1; bits--)
-        for (uint32_t k = 0; k < bl[bits]; k++) A[i++] = (uint32_t)bits;
+        for (uint32_t k = 0; k < bl.get(bits); k++) A.set(i++, (uint32_t)bits);
+}
+FADE_HD void limit_code_lengths(uint32_t *A, int m, int max_bits, uint32_t *bl) {
+    MemArr a{A}, b{bl};
+    limit_code_lengths_t(a, m, max_bits, b);
 }
 
 FADE_HD uint32_t bit_reverse(uint32_t v, int n) {  // the low n bits of v, reversed
@@ -120,87 +150,116 @@ FADE_HD Sym dist_symbol(uint32_t dist) {  // 1..32768
     return s;
 }
 
-// ---- a little bit writer over 32-bit words the caller zeroed (single lane / single thread use)
-struct BitW {
+// ---- bit sink over 32-bit words: whole words are stored, never read back (single lane / single thread use)
+struct WordSink {
     uint32_t *w;
-    uint32_t pos;  // bits written
+    uint64_t acc = 0;
+    int cnt = 0;
+    uint32_t wi = 0;
     FADE_HD void put(uint32_t v, int n) {  // n <= 16
-        if (!n) return;
-        const uint32_t at = pos >> 5, sh = pos & 31u;
-        w[at] |= v << sh;
-        if (sh + (uint32_t)n > 32u) w[at + 1] |= v >> (32u - sh);
-        pos += (uint32_t)n;
+        acc |= (uint64_t)v << cnt;
+        cnt += n;
+        if (cnt >= 32) {
+            w[wi++] = (uint32_t)acc;
+            acc >>= 32;
+            cnt -= 32;
+        }
+    }
+    FADE_HD uint32_t finish() {  // bits written; the last, partial word is stored too
+        if (cnt) w[wi] = (uint32_t)acc;
+        return 32u * wi + (uint32_t)cnt;
     }
 };
 
-// ---- the dynamic-block header: BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, the code-length code and the run-length
-// coded lengths of the two alphabets (RFC 1951 §3.2.7).  ll[0..286) / dl[0..30) are the code lengths; cl_sym / cl_ext
-// (room for 320 entries) and the small arrays are scratch.  Returns the number of header bits written to bw.
-FADE_HD uint32_t write_dynamic_header(BitW &bw, const uint8_t *ll, const uint8_t *dl, uint8_t *cl_sym, uint8_t *cl_ext,
-                                      uint32_t *sortbuf /* >= 2 * 19 + 8 */) {
-    int hlit = NUM_LITLEN, hdist = NUM_DIST;
-    while (hlit > 257 && ll[hlit - 1] == 0) hlit--;
-    while (hdist > 1 && dl[hdist - 1] == 0) hdist--;
+// ---- run-length coding of the hlit + hdist code lengths (RFC 1951 §3.2.7): 16 = repeat the previous length 3-6 times,
+// 17 = 3-10 zeros, 18 = 11-138 zeros.  emit(symbol, extra) is called per code-length symbol, in order.
+template <class LL, class DL, class F>
+FADE_HD void cl_rle(const LL &ll, const DL &dl, int hlit, int hdist, F &&emit) {
     const int n = hlit + hdist;
-    auto at = [&](int k) -> int { return k < hlit ? ll[k] : dl[k - hlit]; };
-    // run-length code the n lengths: 16 = repeat previous 3-6, 17 = 3-10 zeros, 18 = 11-138 zeros
-    int nt = 0;
-    uint32_t freq[NUM_CL];
-    for (int k = 0; k < NUM_CL; k++) freq[k] = 0;
-    for (int i = 0; i < n;) {
-        const int v = at(i);
+    int i = 0;
+    while (i < n) {
+        const int v = i < hlit ? (int)ll.get(i) : (int)dl.get(i - hlit);
         int run = 1;
-        while (i + run < n && at(i + run) == v) run++;
+        while (i + run < n && ((i + run) < hlit ? (int)ll.get(i + run) : (int)dl.get(i + run - hlit)) == v) run++;
         int left = run;
         if (v == 0) {
-            while (left >= 11) { const int r = left > 138 ? 138 : left; cl_sym[nt] = 18; cl_ext[nt++] = (uint8_t)(r - 11); freq[18]++; left -= r; }
-            if (left >= 3) { cl_sym[nt] = 17; cl_ext[nt++] = (uint8_t)(left - 3); freq[17]++; left = 0; }
-            while (left-- > 0) { cl_sym[nt] = 0; cl_ext[nt++] = 0; freq[0]++; }
+            while (left >= 11) { const int r = left > 138 ? 138 : left; emit(18, r - 11); left -= r; }
+            if (left >= 3) { emit(17, left - 3); left = 0; }
+            while (left-- > 0) emit(0, 0);
         } else {
-            cl_sym[nt] = (uint8_t)v; cl_ext[nt++] = 0; freq[v]++; left--;
-            while (left >= 3) { const int r = left > 6 ? 6 : left; cl_sym[nt] = 16; cl_ext[nt++] = (uint8_t)(r - 3); freq[16]++; left -= r; }
-            while (left-- > 0) { cl_sym[nt] = (uint8_t)v; cl_ext[nt++] = 0; freq[v]++; }
+            emit(v, 0);
+            left--;
+            while (left >= 3) { const int r = left > 6 ? 6 : left; emit(16, r - 3); left -= r; }
+            while (left-- > 0) emit(v, 0);
         }
         i += run;
     }
-    // code lengths of the code-length alphabet (limit 7): sort the used symbols by (frequency, symbol)
-    uint32_t *sf = sortbuf, *ss = sortbuf + NUM_CL, *bl = sortbuf + 2 * NUM_CL;
-    int m = 0;
-    for (int s = 0; s < NUM_CL; s++)
-        if (freq[s]) {
-            int j = m++;
-            while (j > 0 && sf[j - 1] > freq[s]) { sf[j] = sf[j - 1]; ss[j] = ss[j - 1]; j--; }
-            sf[j] = freq[s];
-            ss[j] = (uint32_t)s;
-        }
-    uint8_t cll[NUM_CL];
-    uint16_t clc[NUM_CL];
-    for (int s = 0; s < NUM_CL; s++) cll[s] = 0;
-    if (m == 1) cll[ss[0]] = 1;
-    else {
-        mr_code_lengths(sf, m);
-        limit_code_lengths(sf, m, MAX_CL_BITS, bl);
-        for (int k = 0; k < m; k++) cll[ss[k]] = (uint8_t)sf[k];
-    }
-    canonical_codes(cll, NUM_CL, MAX_CL_BITS, clc);
+}
+
+FADE_HD int cl_order(int k) {  // the order in which the code-length code lengths are sent
     const uint8_t order[NUM_CL] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    int hclen = NUM_CL;
-    while (hclen > 4 && cll[order[hclen - 1]] == 0) hclen--;
-    const uint32_t p0 = bw.pos;
-    bw.put(1, 1);  // BFINAL
-    bw.put(2, 2);  // BTYPE = dynamic
-    bw.put((uint32_t)(hlit - 257), 5);
-    bw.put((uint32_t)(hdist - 1), 5);
-    bw.put((uint32_t)(hclen - 4), 4);
-    for (int k = 0; k < hclen; k++) bw.put(cll[order[k]], 3);
-    for (int k = 0; k < nt; k++) {
-        const int s = cl_sym[k];
-        bw.put(clc[s], cll[s]);
-        if (s == 16) bw.put(cl_ext[k], 2);
-        else if (s == 17) bw.put(cl_ext[k], 3);
-        else if (s == 18) bw.put(cl_ext[k], 7);
+    return order[k];
+}
+
+// ---- the dynamic-block header: BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, the code-length code and the run-length
+// coded lengths of the two alphabets (RFC 1951 §3.2.7).  ll (286) / dl (30) hold the code lengths; freq, sf, ss, cll,
+// clc (19 entries each) and bl (8) are scratch arrays.  The run-length coding is done twice (count, then emit) instead of
+// being stored.
+template <class Sink, class LL, class DL, class A>
+FADE_HD void write_dynamic_header_t(Sink &out, const LL &ll, const DL &dl, A &freq, A &sf, A &ss, A &cll, A &clc, A &bl) {
+    int hlit = NUM_LITLEN, hdist = NUM_DIST;
+    while (hlit > 257 && ll.get(hlit - 1) == 0) hlit--;
+    while (hdist > 1 && dl.get(hdist - 1) == 0) hdist--;
+    for (int s = 0; s < NUM_CL; s++) { freq.set(s, 0); cll.set(s, 0); }
+    cl_rle(ll, dl, hlit, hdist, [&](int s, int) { freq.set(s, freq.get(s) + 1); });
+    // code lengths of the code-length alphabet (limit 7): the used symbols sorted by (frequency, symbol)
+    int m = 0;
+    for (int s = 0; s < NUM_CL; s++) {
+        const uint32_t f = freq.get(s);
+        if (f) {
+            int j = m++;
+            while (j > 0 && sf.get(j - 1) > f) { sf.set(j, sf.get(j - 1)); ss.set(j, ss.get(j - 1)); j--; }
+            sf.set(j, f);
+            ss.set(j, (uint32_t)s);
+        }
     }
-    return bw.pos - p0;
+    if (m == 1) cll.set((int)ss.get(0), 1);
+    else {
+        mr_code_lengths_t(sf, m);
+        limit_code_lengths_t(sf, m, MAX_CL_BITS, bl);
+        for (int k = 0; k < m; k++) cll.set((int)ss.get(k), sf.get(k));
+    }
+    // canonical codes of the 19 symbols: bl = count per length, then sf = next code per length
+    for (int b = 0; b <= MAX_CL_BITS; b++) bl.set(b, 0);
+    for (int s = 0; s < NUM_CL; s++)
+        if (cll.get(s)) bl.set((int)cll.get(s), bl.get((int)cll.get(s)) + 1);
+    uint32_t c = 0;
+    sf.set(0, 0);
+    for (int b = 1; b <= MAX_CL_BITS; b++) {
+        c = (c + (b > 1 ? bl.get(b - 1) : 0u)) << 1;
+        sf.set(b, c);
+    }
+    for (int s = 0; s < NUM_CL; s++) {
+        const int l = (int)cll.get(s);
+        if (l) {
+            clc.set(s, bit_reverse(sf.get(l), l));
+            sf.set(l, sf.get(l) + 1);
+        }
+    }
+    int hclen = NUM_CL;
+    while (hclen > 4 && cll.get(cl_order(hclen - 1)) == 0) hclen--;
+    out.put(1, 1);  // BFINAL
+    out.put(2, 2);  // BTYPE = dynamic
+    out.put((uint32_t)(hlit - 257), 5);
+    out.put((uint32_t)(hdist - 1), 5);
+    out.put((uint32_t)(hclen - 4), 4);
+    for (int k = 0; k < hclen; k++) out.put(cll.get(cl_order(k)), 3);
+    cl_rle(ll, dl, hlit, hdist, [&](int s, int e) {
+        out.put(clc.get(s), (int)cll.get(s));
+        if (s == 16) out.put((uint32_t)e, 2);
+        else if (s == 17) out.put((uint32_t)e, 3);
+        else if (s == 18) out.put((uint32_t)e, 7);
+    });
 }
 
 // ---- CRC-32 (the gzip polynomial, reflected) arithmetic for combining the CRCs of pieces: crc(A || B) =

@@ -1615,7 +1615,7 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     const uint32_t nb = (uint32_t)((n_bytes + bgzf::BLOCK - 1) / bgzf::BLOCK);
     int rc;
     if ((rc = reserve(ctx, l.src, n_bytes + 64)) || (rc = reserve(ctx, l.slots, (size_t)nb * bgzf::SLOT)) ||
-        (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 64)) || (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) ||
+        (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 256)) || (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) ||
         (rc = reserve(ctx, l.packed, (size_t)nb * bgzf::SLOT)))
         return rc;
     uint32_t *d_size = (uint32_t *)l.meta.p, *d_crc = d_size + nb, *d_ticket = d_crc + nb;
@@ -1630,6 +1630,11 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     a.out_size = d_size;
     a.out_crc = d_crc;
     a.ticket = d_ticket;
+    a.prof = nullptr;
+    if (getenv("FADEHIP_BGZF_PROF")) {  // shader clocks per phase, printed by wait (development aid)
+        a.prof = (unsigned long long *)(d_total + 1);
+        HIPCHK(ctx, hipMemsetAsync(a.prof, 0, 64, l.stream));
+    }
     const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(ctx->cu_count, 1));
     hipLaunchKernelGGL(bgzf::bgzf_deflate_kernel, dim3(grid), dim3(bgzf::WG), bgzf::LDS_BYTES, l.stream, a);
     HIPCHK(ctx, hipGetLastError());
@@ -1655,6 +1660,19 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
     HIPCHK(ctx, hipStreamSynchronize(l.stream));
     const uint64_t total = *l.h_total;
     l.state = 0;
+    if (getenv("FADEHIP_BGZF_PROF")) {
+        unsigned long long pr[8];
+        uint32_t *d_ticket = (uint32_t *)l.meta.p + 2 * (size_t)l.n_blocks;
+        uint64_t *d_total = (uint64_t *)(((uintptr_t)(d_ticket + 2) + 7) & ~(uintptr_t)7);
+        if (hipMemcpy(pr, d_total + 1, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *nm[7] = {"load", "A match+parse", "B hist", "B codes", "C header+count", "D emit", "CRC"};
+            unsigned long long sum = 0;
+            for (int k = 0; k < 7; k++) sum += pr[k];
+            fprintf(stderr, "[fadehip bgzf] %u blocks, shader clocks per block:", l.n_blocks);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.0f (%.0f%%)", nm[k], (double)pr[k] / l.n_blocks, 100.0 * (double)pr[k] / (double)std::max<unsigned long long>(sum, 1));
+            fprintf(stderr, "\n");
+        }
+    }
     if (total == 0 || total > (uint64_t)l.n_blocks * bgzf::SLOT) return set_err(ctx, FADEHIP_E_STATE, "internal: bgzf members add up to %llu bytes", (unsigned long long)total);
     int rc = reserve_pinned(ctx, l.out, (size_t)total);
     if (rc) return rc;

@@ -166,6 +166,34 @@ struct BlockPool {
     }
 };
 
+// the writer's BGZF blocks compressed on the device (fadehip_bgzf_deflate_*): two lanes, each with a pinned staging buffer
+struct DeviceBgzf : BgzfDevice {
+    fadehip_ctx *ctx;
+    struct Lane { void *p = nullptr; size_t cap = 0; } lane_[FADEHIP_BGZF_LANES];
+    explicit DeviceBgzf(fadehip_ctx *c) : ctx(c) {}
+    ~DeviceBgzf() override {
+        for (auto &l : lane_)
+            if (l.p) fadehip_host_free(ctx, l.p);
+    }
+    int lanes() const override { return FADEHIP_BGZF_LANES; }
+    uint8_t *stage(int lane, size_t bytes) override {
+        Lane &l = lane_[lane];
+        if (bytes > l.cap) {
+            if (l.p) fadehip_host_free(ctx, l.p);
+            l.p = nullptr;
+            l.cap = bytes + bytes / 4 + (1u << 20);
+            if (fadehip_host_alloc(ctx, l.cap, &l.p)) throw std::runtime_error(std::string("pinned allocation: ") + fadehip_last_error(ctx));
+        }
+        return (uint8_t *)l.p;
+    }
+    void submit(int lane, size_t bytes) override {
+        if (fadehip_bgzf_deflate_submit(ctx, lane, lane_[lane].p, bytes)) throw std::runtime_error(std::string("device BGZF: ") + fadehip_last_error(ctx));
+    }
+    void wait(int lane, const uint8_t **out, size_t *n) override {
+        if (fadehip_bgzf_deflate_wait(ctx, lane, out, n)) throw std::runtime_error(std::string("device BGZF: ") + fadehip_last_error(ctx));
+    }
+};
+
 struct Chunk {
     RecordBlock blk;             // the records, framed in place (BAM: in the inflated bytes; SAM: parsed into the same layout)
     Writer::BlockOut bout;       // ... and what annotate adds to them
@@ -611,7 +639,10 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         fa.seqs.shrink_to_fit();
         // nothing is written to stdout before the GPU path is known to be usable
         const OutFmt fmt = o.bam ? OutFmt::BAM : o.ubam ? OutFmt::UBAM : OutFmt::SAM;  // util.d:65-76
-        Writer writer(stdout, fmt, hdr, &pool);
+        // BAM output: the BGZF blocks are compressed on the device (FADE_BGZF_DEVICE=0 keeps them on the host pool)
+        std::unique_ptr<DeviceBgzf> dev_codec;
+        if (fmt == OutFmt::BAM && !(getenv("FADE_BGZF_DEVICE") && atoi(getenv("FADE_BGZF_DEVICE")) == 0)) dev_codec.reset(new DeviceBgzf(ctxs[0]));
+        Writer writer(stdout, fmt, hdr, &pool, dev_codec.get());
 
         StageThreads wstage;  // declared after the writer it uses: joined before the writer goes away
         wstage.unblock = [&] {

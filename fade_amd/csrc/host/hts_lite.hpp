@@ -1453,9 +1453,21 @@ private:
     std::thread th_;
 };
 
+// A BGZF compressor on a device (the `fade` driver hands the writer one: fadehip_bgzf_deflate_* of include/fadehip.h).
+// This layer knows nothing of HIP; without a device codec the blocks are compressed on the pool (deflate_fast.hpp / zlib).
+// Lanes alternate: while one lane's bytes are compressed on the device, the next flush is staged into the other's buffer.
+struct BgzfDevice {
+    virtual ~BgzfDevice() {}
+    virtual int lanes() const = 0;
+    virtual uint8_t *stage(int lane, size_t bytes) = 0;  // a pinned buffer of at least `bytes` for the lane's next submit
+    virtual void submit(int lane, size_t bytes) = 0;     // compress stage(lane)[0, bytes) into BGZF members; returns at once
+    virtual void wait(int lane, const uint8_t **out, size_t *n) = 0;  // the members' bytes, valid until the lane's next submit
+};
+
 class Writer {
 public:
-    Writer(FILE *f, OutFmt fmt, const Header &h, Pool *pool) : f_(f), fmt_(fmt), hdr_(h), pool_(pool), io_(f) {
+    Writer(FILE *f, OutFmt fmt, const Header &h, Pool *pool, BgzfDevice *dev = nullptr)
+        : f_(f), fmt_(fmt), hdr_(h), pool_(pool), dev_(fmt == OutFmt::BAM ? dev : nullptr), io_(f) {
         if (fmt_ == OutFmt::SAM) {
             std::vector<std::string> one(1, hdr_.text);
             io_.put(std::move(one));
@@ -1549,7 +1561,7 @@ public:
         // what the compressor is told about the bytes (FastDeflate::Hint): a record's packed bases hold no repeats worth
         // probing for, its qualities rarely (runs), its tags and the next record's fixed fields do
         const size_t h0 = hints_.size();
-        const bool hinted = fmt_ == OutFmt::BAM && off[n] < 0xffffffffull;
+        const bool hinted = fmt_ == OutFmt::BAM && !dev_ && off[n] < 0xffffffffull;
         if (hinted) hints_.resize(h0 + 3 * n);
         const size_t nt = (size_t)pool_->size() * 4;
         pool_->parallel_for(nt, [&](size_t t) {
@@ -1580,6 +1592,8 @@ public:
         closed_ = true;
         if (fmt_ != OutFmt::SAM) {
             flush_blocks(true);
+            if (dev_)
+                for (int k = 0; k < dev_->lanes(); k++) collect_lane((int)((dev_seq_ + (size_t)k) % (size_t)dev_->lanes()));  // oldest first
             std::vector<std::vector<uint8_t>> eof(1, std::vector<uint8_t>(BGZF_EOF, BGZF_EOF + sizeof BGZF_EOF));
             io_.put(std::move(eof));
         }
@@ -1588,7 +1602,42 @@ public:
     }
 
 private:
+    // the members a device lane has finished go to the output thread (copied on the pool: the lane's buffer is reused)
+    void collect_lane(int lane) {
+        if (dev_busy_.empty() || !dev_busy_[(size_t)lane]) return;
+        const uint8_t *out = nullptr;
+        size_t n = 0;
+        dev_->wait(lane, &out, &n);
+        dev_busy_[(size_t)lane] = false;
+        const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)pool_->size(), n / (4u << 20) + 1));
+        std::vector<std::vector<uint8_t>> outs(nt);
+        pool_->parallel_for(nt, [&](size_t t) {
+            const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            outs[t].assign(out + lo, out + hi);
+        }, CPU_COPY);
+        io_.put(std::move(outs));
+    }
+    void flush_blocks_device(bool all) {
+        const size_t B = 0xff00;
+        size_t used = all ? raw_.size() : raw_.size() / B * B;
+        if (!used) return;
+        if (dev_busy_.empty()) dev_busy_.assign((size_t)dev_->lanes(), false);
+        const int lane = (int)(dev_seq_ % (size_t)dev_->lanes());
+        collect_lane(lane);  // (the submission before last: its bytes leave before the lane's buffers are reused)
+        uint8_t *st = dev_->stage(lane, used);
+        const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)pool_->size() * 2, used / (1u << 20) + 1));
+        pool_->parallel_for(nt, [&](size_t t) {
+            const size_t lo = used * t / nt, hi = used * (t + 1) / nt;
+            memcpy(st + lo, raw_.data() + lo, hi - lo);
+        }, CPU_COPY);
+        dev_->submit(lane, used);
+        dev_busy_[(size_t)lane] = true;
+        dev_seq_++;
+        raw_.drop_front(used);
+        hints_.clear();
+    }
     void flush_blocks(bool all) {
+        if (dev_) return flush_blocks_device(all);
         const size_t B = 0xff00;
         size_t nblk = raw_.size() / B;
         if (all && raw_.size() % B) nblk++;
@@ -1628,6 +1677,9 @@ private:
     OutFmt fmt_;
     Header hdr_;
     Pool *pool_;
+    BgzfDevice *dev_;
+    std::vector<bool> dev_busy_;
+    size_t dev_seq_ = 0;  // flushes handed to the device so far
     RawBuf raw_;
     std::vector<FastDeflate::Hint> hints_;  // layout hints for the bytes in raw_ (positions relative to its start, sorted)
     bool closed_ = false;

@@ -179,10 +179,18 @@ std::vector<uint8_t> model_deflate(const uint8_t *src, int n, bool lazy) {
     canonical_codes(dl, NUM_DIST, MAX_LITLEN_BITS, dc);
     // ---- header
     std::vector<uint32_t> words((size_t)BLOCK / 2 + 4096, 0);
-    BitW bw{words.data(), 0};
-    uint8_t cl_sym[NUM_LITLEN + NUM_DIST + 8], cl_ext[NUM_LITLEN + NUM_DIST + 8];
-    uint32_t sortbuf[64];
-    const uint32_t hdr_bits = write_dynamic_header(bw, ll, dl, cl_sym, cl_ext, sortbuf);
+    uint32_t hdr_bits;
+    {
+        std::vector<uint32_t> hw(256, 0);
+        WordSink sink;
+        sink.w = hw.data();
+        uint32_t f19[32], sf[32], ss[32], cll[32], clc[32], bl[32];
+        MemArr a_f{f19}, a_sf{sf}, a_ss{ss}, a_cll{cll}, a_clc{clc}, a_bl{bl};
+        MemArrT<uint8_t> a_ll{ll}, a_dl{dl};
+        write_dynamic_header_t(sink, a_ll, a_dl, a_f, a_sf, a_ss, a_cll, a_clc, a_bl);
+        hdr_bits = sink.finish();
+        for (size_t k = 0; k < hw.size(); k++) words[k] = hw[k];
+    }
     // ---- phase D: 256 ranges of 8 bitmap words (256 positions) each
     auto token_bits = [&](int w, int b, uint64_t *bits, int *nb) {
         const int p = 32 * w + b;
