@@ -28,7 +28,9 @@ namespace fadehip {
 namespace bgzf {
 
 constexpr int BLOCK = 0xff00;  // input bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
-constexpr int WG = 1024;
+constexpr int WG = 512;   // 8 waves: hasher, six extenders, parser.  Measured: 768 threads (ten extenders, 168 VGPRs, 11 spilled) and
+                          // 1024 (fourteen, 128 VGPRs, 41 spilled) are slower: the serial roles set the pace, and spills sit in their fences
+constexpr int DIST_T0 = 320;  // threads DIST_T0 .. + 29 serve the distance alphabet where the first 286 serve literals / lengths
 constexpr int N_WAVES = WG / 64;
 constexpr int HASH_BITS = 12, WAYS = 4;
 constexpr int MAX_MATCHES = 8192;
@@ -39,8 +41,9 @@ constexpr int SLOT = 65536;                  // bytes of a block's output slot (
 constexpr int MAX_PAYLOAD = 65536 - 26;
 
 // LDS layout (bytes)
+constexpr int R1 = 8, R2 = 24;  // slots of phase A's candidate ring (64 x 8 bytes each) and length ring (64 x 4)
 constexpr int L_DATA = 0, L_HEAD = 65536, L_MATCH = L_HEAD + 32768, L_TOK = L_MATCH + 32768, L_MAT = L_TOK + 8192,
-              L_MISC = L_MAT + 8192, LDS_BYTES = L_MISC + 6144;
+              L_MISC = L_MAT + 8192, L_CRING = L_MISC + 6144, L_LRING = L_CRING + R1 * 512, LDS_BYTES = L_LRING + R2 * 256;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup must fit the CU's LDS");
 // ... of the head region once the matches are found
 constexpr int H_MPRE = 0, H_H8 = 8192, H_AL = H_H8 + 8 * 320 * 4, H_SL = H_AL + 320 * 4, H_AD = H_SL + 320 * 4, H_SD = H_AD + 64 * 4,
@@ -48,7 +51,7 @@ constexpr int H_MPRE = 0, H_H8 = 8192, H_AL = H_H8 + 8 * 320 * 4, H_SL = H_AL + 
 static_assert(H_END <= 32768, "phase B temporaries must fit the hash region");
 
 struct Misc {  // the small arrays of a block
-    uint32_t turn1, turn2, carry, mcount, full, blk, m_l, m_d, hdr_bits, total_bits, stored, pad[5];
+    uint32_t abort, dbg[3], carry, mcount, full, blk, m_l, m_d, hdr_bits, total_bits, stored, pad[3];
     uint32_t freq_l[320], freq_d[64];
     uint8_t ll[320], dl[64];
     uint16_t lc[320], dc[64];
@@ -58,6 +61,11 @@ struct Misc {  // the small arrays of a block
     uint32_t sortbuf[64];
     uint32_t wtmp[N_WAVES];
     uint32_t crc_part[N_WAVES];
+    // phase A's rings (see there): sequence / free numbers per slot, the extenders' ticket
+    uint32_t cand_seq[R1], cand_free[R1], lens_seq[R2], lens_free[R2], ext_ticket;
+    // the header's run-length tokens (symbol | extra << 8) and the code-length alphabet
+    uint16_t cltok[320];
+    uint32_t cl_freq[NUM_CL + 1], cl_len[NUM_CL + 1], cl_code[NUM_CL + 1], cl_n, cl_hlit, cl_hdist, cl_hclen;
 };
 static_assert(sizeof(Misc) <= 6144, "Misc outgrew its slice");
 
@@ -76,10 +84,44 @@ __device__ __forceinline__ uint32_t lds_load32u(const uint8_t *base, uint32_t p)
     const uint32_t *w = reinterpret_cast<const uint32_t *>(base) + (p >> 2);
     return __builtin_amdgcn_alignbyte(w[1], w[0], p & 3u);
 }
+__device__ __forceinline__ uint64_t lds_load64u(const uint8_t *base, uint32_t p) {  // 8 bytes at any offset
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base) + (p >> 2);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, p & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, p & 3u) << 32);
+}
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
 
-__device__ __forceinline__ void spin_until(uint32_t *turn, uint32_t v) {
-    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
+// Waits for *turn == v.  Every wait of the pipeline is bounded: a wait that outlasts SPIN_LIMIT polls (a hundred times
+// the longest legitimate one) raises the block's abort flag, which ends every other wait and every role's loop too, so
+// that the workgroup always drains; the block is then reported as failed (out_size = ~0) instead of hanging the device.
+constexpr uint32_t SPIN_LIMIT = 1u << 18;
+// (Every value the loop branches on goes through v_readfirstlane: the waits are wave-uniform by construction, and the
+// compiler must know it — with per-lane exit conditions it nests the roles' loops around exec masks, and a back edge of
+// that nest re-used a stale ticket: two extenders on one piece.)
+__device__ __forceinline__ bool spin_until(uint32_t *turn, uint32_t v, uint32_t *abort_flag, uint32_t who) {
+    uint32_t polls = 0;
+    for (;;) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (x == v) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 255u) == 0) {
+            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+            if (polls >= SPIN_LIMIT) {
+                abort_flag[1] = x;  // (dbg: what it saw ...
+                abort_flag[2] = v;  //  ... and wanted)
+                abort_flag[3] = (uint32_t)(threadIdx.x >> 6);
+                __hip_atomic_store(abort_flag, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return false;
+            }
+        }
+    }
+}
+// the next ticket of a wave-shared counter, as a wave-uniform value (kept out of line: inlined into the extenders' loop the
+// claim was hoisted around the loop's exec-mask bookkeeping and a back edge re-used a stale ticket)
+__device__ __noinline__ int claim_ticket(uint32_t *counter) {
+    uint32_t tk = 0;
+    if ((threadIdx.x & 63) == 0) tk = atomicAdd(counter, 1u);
+    return __builtin_amdgcn_readlane((int)tk, 0);
 }
 __device__ __forceinline__ void publish(uint32_t *turn, uint32_t v) {
     __hip_atomic_store(turn, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -175,6 +217,199 @@ __device__ __forceinline__ void token_bits(const uint8_t *data, uint32_t mw, uin
     }
 }
 
+// ---- phase A's three roles (inlined: out of line they measured a third slower)
+struct RoleArgs {
+    uint8_t *data;
+    uint16_t *head;
+    uint32_t *match, *tokw, *matw;
+    Misc *ms;
+    uint2 *cand_ring;
+    uint32_t *lens_ring;
+    int n, n_pieces, lane;
+    unsigned long long *prof;  // optional: [60 + 2 role] clocks waited, [61 + 2 role] clocks in the role (summed over waves)
+};
+__device__ __forceinline__ void role_hasher(const RoleArgs r) {
+    uint8_t *const data = r.data; uint16_t *const head = r.head; Misc *const ms = r.ms; uint2 *const cand_ring = r.cand_ring;
+    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
+        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+        const bool ok = spin_until(turn, v, ab, who);
+        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
+        return ok;
+    };
+    bool live = true;  // (wave-uniform; an aborted role runs its loop out without waiting or working)
+    for (int piece = 0; piece < n_pieces && live; piece++) {
+        const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
+        const bool valid = (int)p + MIN_MATCH <= n;
+        const uint32_t v = valid ? lds_load32u(data, p) : 0u;
+        uint2 *bucket = reinterpret_cast<uint2 *>(head) + hash4(v);
+        const int slot = piece % R1;
+        live = timed_spin(&ms->cand_free[slot], (uint32_t)piece, &ms->abort, 0x10000000u | (uint32_t)piece);
+        uint2 bk = make_uint2(0, 0);
+        if (valid) {
+            bk = *bucket;
+            *bucket = make_uint2((p + 1u) | (bk.x << 16), (bk.x >> 16) | (bk.y << 16));  // newest first; the oldest of the four leaves
+        }
+        cand_ring[slot * 64 + lane] = bk;
+        if (lane == 0) publish(&ms->cand_seq[slot], (uint32_t)piece + 1u);
+    }
+    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 0], t_wait); atomicAdd(&r.prof[61 + 2 * 0], __builtin_readcyclecounter() - t_role0); }
+}
+__device__ __forceinline__ void role_extender(const RoleArgs r) {
+    uint8_t *const data = r.data; Misc *const ms = r.ms; uint2 *const cand_ring = r.cand_ring; uint32_t *const lens_ring = r.lens_ring;
+    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
+        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+        const bool ok = spin_until(turn, v, ab, who);
+        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
+        return ok;
+    };
+    bool live = true;
+    for (int piece = claim_ticket(&ms->ext_ticket); piece < n_pieces; piece = claim_ticket(&ms->ext_ticket)) {
+        if (!live) continue;  // (aborted: the tickets are drawn to the end, nothing else is done)
+        const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
+        const bool valid = (int)p + MIN_MATCH <= n;
+        const uint32_t v = valid ? lds_load32u(data, p) : 0u;
+        const int slot = piece % R1;
+        live = timed_spin(&ms->cand_seq[slot], (uint32_t)piece + 1u, &ms->abort, 0x20000000u | (uint32_t)piece);
+        if (!live) continue;
+        const uint2 bk = cand_ring[slot * 64 + lane];
+        if (lane == 0) publish(&ms->cand_free[slot], (uint32_t)(piece + R1));
+        uint32_t len = 0, dist = 0;
+        // a position that an earlier match already covers can start no token: its matches are never looked at (the
+        // parse starts at `carry`, which only grows), so they need not be found either
+        const uint32_t covered_to = __hip_atomic_load(&ms->carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid && p >= covered_to) {
+            const uint32_t maxlen = (uint32_t)min(MAX_MATCH, n - (int)p);
+            // up to five candidates: the nearest of the distances 1 .. 8 whose four bytes agree, and the bucket's four
+            // positions; their loads are issued together and they are extended side by side (one LDS round trip per
+            // four bytes of the LONGEST match, not per candidate)
+            uint32_t cp[5];
+            uint32_t alive = 0;
+            {
+                uint32_t vd[8];
+#pragma unroll
+                for (uint32_t d = 1; d <= 8u; d++) vd[d - 1] = lds_load32u(data, p >= d ? p - d : p);
+                uint32_t dsmall = 0;
+#pragma unroll
+                for (uint32_t d = 8; d >= 1u; d--)
+                    if (p >= d && vd[d - 1] == v) dsmall = d;
+                cp[0] = p - dsmall;
+                if (dsmall) alive |= 1u;
+            }
+            const uint32_t c4[4] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16};
+            uint32_t cv[4];
+#pragma unroll
+            for (int w = 0; w < WAYS; w++) {
+                cp[1 + w] = c4[w] ? c4[w] - 1u : 0u;
+                cv[w] = lds_load32u(data, cp[1 + w]);
+            }
+#pragma unroll
+            for (int w = 0; w < WAYS; w++)
+                if (c4[w] && p - cp[1 + w] <= 32768u && cv[w] == v) alive |= 2u << w;
+            uint32_t cl[5] = {0, 0, 0, 0, 0};
+            uint32_t off = 4;
+            while (alive && off < maxlen) {  // eight bytes per round trip
+                const uint64_t pw = lds_load64u(data, p + off);
+                uint64_t x[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) x[k] = lds_load64u(data, cp[k] + off) ^ pw;
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    if (((alive >> k) & 1u) && x[k]) {
+                        cl[k] = off + ((uint32_t)__builtin_ctzll(x[k]) >> 3);
+                        alive &= ~(1u << k);
+                    }
+                off += 8;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                uint32_t l = ((alive >> k) & 1u) ? maxlen : cl[k];  // still equal where the limit was reached
+                if (l > maxlen) l = maxlen;
+                if (l > len) { len = l; dist = p - cp[k]; }
+            }
+        }
+        if (len < (uint32_t)MIN_MATCH) len = 0;
+        const int lslot = piece % R2;
+        live = timed_spin(&ms->lens_free[lslot], (uint32_t)piece, &ms->abort, 0x30000000u | (uint32_t)piece);
+        if (!live) continue;
+        lens_ring[lslot * 64 + lane] = len | (dist << 16);
+        if (lane == 0) publish(&ms->lens_seq[lslot], (uint32_t)piece + 1u);
+    }
+    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 1], t_wait); atomicAdd(&r.prof[61 + 2 * 1], __builtin_readcyclecounter() - t_role0); }
+}
+__device__ __forceinline__ void role_parser(const RoleArgs r) {
+    uint32_t *const match = r.match, *const tokw = r.tokw, *const matw = r.matw; Misc *const ms = r.ms; uint32_t *const lens_ring = r.lens_ring;
+    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
+        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+        const bool ok = spin_until(turn, v, ab, who);
+        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
+        return ok;
+    };
+    // The parser sets the block's pace (every piece passes through this one wave, carry in hand), so its round trips are
+    // taken off the chain: the next piece's (length, distance) words are fetched while this piece is parsed, the neighbour's
+    // length comes by DPP (wave_shl:1) instead of through the LDS crossbar, and a match's slot in the list is an mbcnt.
+    int carry = 0;
+    uint32_t mcount = 0, full = 0;
+    bool live = n_pieces > 0 && timed_spin(&ms->lens_seq[0], 1u, &ms->abort, 0x40000000u);
+    uint32_t lx = live ? lens_ring[lane] : 0u;
+    for (int piece = 0; piece < n_pieces && live; piece++) {
+        const int lslot = piece % R2;
+        const uint32_t len = lx & 0xffffu, dist = lx >> 16;
+        if (lane == 0) publish(&ms->lens_free[lslot], (uint32_t)(piece + R2));  // (this piece's words are in registers: its slot goes back)
+        // the next piece's words are fetched while this one is parsed
+        uint32_t lx_next = 0;
+        const int nslot = (piece + 1) % R2;
+        if (piece + 1 < n_pieces) {
+            live = timed_spin(&ms->lens_seq[nslot], (uint32_t)piece + 2u, &ms->abort, 0x40000000u | (uint32_t)(piece + 1));
+            if (live) lx_next = lens_ring[nslot * 64 + lane];
+        }
+        // a match yields to a longer one at the next position
+        const uint32_t len_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const bool yield = len && lane < 63 && len_next > len;
+        const int cb = piece * 64, nv = min(64, n - cb);
+        uint64_t has = __ballot(len != 0 && !yield);
+        if (full || mcount + (uint32_t)__popcll(has) > (uint32_t)MAX_MATCHES) { full = 1; has = 0; }  // the match list is full: literals from here on
+        const uint64_t vmask = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
+        // greedy: from `cur`, the next match start at or after it is taken and covers its length; what no match covers is a literal
+        uint64_t matmask = 0, covered = 0;
+        int cur = max(carry - cb, 0);
+        const int cur0 = cur;
+        while (cur < nv) {
+            const uint64_t rem = has & (~0ull << cur);
+            if (!rem) break;
+            const int j = (int)__builtin_ctzll(rem);
+            const int e = j + (int)__builtin_amdgcn_readlane((int)len, j);  // first position after the match
+            matmask |= 1ull << j;
+            covered |= (e >= 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((j == 63) ? ~0ull : ((1ull << (j + 1)) - 1ull));
+            cur = e;
+        }
+        const uint64_t tokmask = vmask & ~covered & (cur0 >= 64 ? 0ull : (~0ull << cur0));
+        if (cur < nv) cur = nv;
+        if (cb + cur > carry) carry = cb + cur;
+        if ((matmask >> lane) & 1ull) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(matmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matmask, 0u));
+            match[mcount + before] = dist | ((len - 3u) << 16);
+        }
+        mcount += (uint32_t)__popcll(matmask);
+        if (lane == 0) {
+            *reinterpret_cast<uint2 *>(tokw + 2 * piece) = make_uint2((uint32_t)tokmask, (uint32_t)(tokmask >> 32));
+            *reinterpret_cast<uint2 *>(matw + 2 * piece) = make_uint2((uint32_t)matmask, (uint32_t)(matmask >> 32));
+            __hip_atomic_store(&ms->carry, (uint32_t)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        lx = lx_next;
+    }
+    if (lane == 0) ms->mcount = mcount;
+    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 2], t_wait); atomicAdd(&r.prof[61 + 2 * 2], __builtin_readcyclecounter() - t_role0); }
+}
+
 __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     uint8_t *const data = lds + L_DATA;
@@ -183,6 +418,8 @@ __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
     uint32_t *const tokw = reinterpret_cast<uint32_t *>(lds + L_TOK);
     uint32_t *const matw = reinterpret_cast<uint32_t *>(lds + L_MAT);
     Misc *const ms = reinterpret_cast<Misc *>(lds + L_MISC);
+    uint2 *const cand_ring = reinterpret_cast<uint2 *>(lds + L_CRING);
+    uint32_t *const lens_ring = reinterpret_cast<uint32_t *>(lds + L_LRING);
     uint32_t *const mpre = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_MPRE);
     uint32_t *const h8 = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_H8);
     uint32_t *const A_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AL), *const S_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SL);
@@ -223,121 +460,47 @@ __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
             for (int k = tid; k < 32768 / 16; k += WG) z[k] = make_uint4(0, 0, 0, 0);
             uint4 *zb = reinterpret_cast<uint4 *>(lds + L_TOK);
             for (int k = tid; k < 16384 / 16; k += WG) zb[k] = make_uint4(0, 0, 0, 0);
-            if (tid == 0) { ms->turn1 = 0; ms->turn2 = 0; ms->carry = 0; ms->mcount = 0; ms->full = 0; ms->stored = 0; }
+            if (tid == 0) { ms->carry = 0; ms->mcount = 0; ms->stored = 0; ms->ext_ticket = 0; ms->abort = 0; }
+            if (tid < R1) { ms->cand_seq[tid] = 0; ms->cand_free[tid] = (uint32_t)tid; }
+            if (tid < R2) { ms->lens_seq[tid] = 0; ms->lens_free[tid] = (uint32_t)tid; }
         }
         __syncthreads();
         stamp(0);
 
-        // ---- A: matches and the parse, 64 positions per wave and turn
+        // ---- A: matches and the parse, as a pipeline of wave roles over pieces of 64 positions.  The two steps that must
+        // see the pieces in order never hand a turn from wave to wave (a hand-over costs ~900 clocks, 2,040 of them a block):
+        //   wave 0, the hasher, walks the pieces through the hash heads (a bucket's read, then its write, in LDS order) and
+        //           leaves each position's four candidates in a small ring;
+        //   waves 1 .. 14, the extenders, claim pieces by ticket, take the candidates (the slot goes back at once), extend
+        //           them and leave (length, distance) in a second ring;
+        //   wave 15, the parser, takes the pieces in order, carry and match count in registers.
+        // Slots carry sequence numbers: a ring slot s is written for piece k only when `free` says k, read only when `seq`
+        // says k + 1.  Every wait is for a lower-numbered piece's step, so the waits cannot form a cycle.
         const int n_pieces = (n + 63) >> 6;
-        for (int piece = wave; piece < n_pieces; piece += N_WAVES) {
-            const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
-            const bool valid = (int)p + MIN_MATCH <= n;
-            const uint32_t v = valid ? lds_load32u(data, p) : 0u;
-            const uint32_t h = hash4(v);
-            uint2 *bucket = reinterpret_cast<uint2 *>(head) + h;
-            spin_until(&ms->turn1, (uint32_t)piece);
-            uint2 bk = make_uint2(0, 0);
-            if (valid) {
-                bk = *bucket;
-                *bucket = make_uint2((p + 1u) | (bk.x << 16), (bk.x >> 16) | (bk.y << 16));  // newest first; the oldest of the four leaves
-            }
-            if (lane == 0) publish(&ms->turn1, (uint32_t)piece + 1u);
-            uint32_t len = 0, dist = 0;
-            // a position that an earlier match already covers can start no token: its matches are never looked at (the
-            // parse below starts at `carry`, which only grows), so they need not be found either
-            const uint32_t covered_to = __hip_atomic_load(&ms->carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (valid && p >= covered_to) {
-                const uint32_t maxlen = (uint32_t)min(MAX_MATCH, n - (int)p);
-                // up to five candidates: the nearest of the distances 1 .. 8 whose four bytes agree, and the bucket's four
-                // positions; their loads are issued together and they are extended side by side (one LDS round trip per
-                // four bytes of the LONGEST match, not per candidate)
-                uint32_t cp[5];
-                uint32_t alive = 0;
-                {
-                    uint32_t vd[8];
-#pragma unroll
-                    for (uint32_t d = 1; d <= 8u; d++) vd[d - 1] = lds_load32u(data, p >= d ? p - d : p);
-                    uint32_t dsmall = 0;
-#pragma unroll
-                    for (uint32_t d = 8; d >= 1u; d--)
-                        if (p >= d && vd[d - 1] == v) dsmall = d;
-                    cp[0] = p - dsmall;
-                    if (dsmall) alive |= 1u;
-                }
-                const uint32_t c4[4] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16};
-                uint32_t cv[4];
-#pragma unroll
-                for (int w = 0; w < WAYS; w++) {
-                    cp[1 + w] = c4[w] ? c4[w] - 1u : 0u;
-                    cv[w] = lds_load32u(data, cp[1 + w]);
-                }
-#pragma unroll
-                for (int w = 0; w < WAYS; w++)
-                    if (c4[w] && p - cp[1 + w] <= 32768u && cv[w] == v) alive |= 2u << w;
-                uint32_t cl[5] = {0, 0, 0, 0, 0};
-                uint32_t off = 4;
-                while (alive && off < maxlen) {
-                    const uint32_t pw = lds_load32u(data, p + off);
-                    uint32_t x[5];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) x[k] = lds_load32u(data, cp[k] + off) ^ pw;
-#pragma unroll
-                    for (int k = 0; k < 5; k++)
-                        if (((alive >> k) & 1u) && x[k]) {
-                            cl[k] = off + ((uint32_t)__builtin_ctz(x[k]) >> 3);
-                            alive &= ~(1u << k);
-                        }
-                    off += 4;
-                }
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    uint32_t l = ((alive >> k) & 1u) ? maxlen : cl[k];  // still equal where the limit was reached
-                    if (l > maxlen) l = maxlen;
-                    if (l > len) { len = l; dist = p - cp[k]; }
-                }
-            }
-            if (len < (uint32_t)MIN_MATCH) len = 0;
-            // a match yields to a longer one at the next position
-            const uint32_t len_next = (uint32_t)__shfl_down((int)len, 1, 64);
-            const bool yield = len && lane < 63 && len_next > len;
-            // -- the parse of this piece, in turn
-            spin_until(&ms->turn2, (uint32_t)piece);
-            const int cb = piece * 64, nv = min(64, n - cb);
-            int carry = (int)ms->carry;
-            uint32_t mcount = ms->mcount, full = ms->full;
-            uint64_t has = __ballot(len != 0 && !yield);
-            if (full || mcount + (uint32_t)__popcll(has) > (uint32_t)MAX_MATCHES) { full = 1; has = 0; }  // the match list is full: literals from here on
-            const uint64_t vmask = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
-            uint64_t tokmask = 0, matmask = 0;
-            int cur = max(carry - cb, 0);
-            while (cur < nv) {
-                const uint64_t rem = has & (~0ull << cur);
-                if (!rem) {
-                    tokmask |= vmask & (~0ull << cur);
-                    cur = nv;
-                    break;
-                }
-                const int j = (int)__builtin_ctzll(rem);
-                tokmask |= (j == 63 ? ~0ull : ((1ull << (j + 1)) - 1ull)) & (~0ull << cur);
-                matmask |= 1ull << j;
-                cur = j + (int)__builtin_amdgcn_readlane((int)len, j);
-            }
-            if (cb + cur > carry) carry = cb + cur;
-            if ((matmask >> lane) & 1ull)
-                match[mcount + (uint32_t)__popcll(matmask & ((1ull << lane) - 1ull))] = dist | ((len - 3u) << 16);
-            if (lane == 0) {
-                tokw[2 * piece] = (uint32_t)tokmask;
-                tokw[2 * piece + 1] = (uint32_t)(tokmask >> 32);
-                matw[2 * piece] = (uint32_t)matmask;
-                matw[2 * piece + 1] = (uint32_t)(matmask >> 32);
-                __hip_atomic_store(&ms->carry, (uint32_t)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ms->mcount = mcount + (uint32_t)__popcll(matmask);
-                ms->full = full;
-                publish(&ms->turn2, (uint32_t)piece + 1u);
-            }
+        {
+            RoleArgs ra;
+            ra.data = data; ra.head = head; ra.match = match; ra.tokw = tokw; ra.matw = matw; ra.ms = ms;
+            ra.cand_ring = cand_ring; ra.lens_ring = lens_ring; ra.n = n; ra.n_pieces = n_pieces; ra.lane = lane; ra.prof = a.prof;
+            if (wave == 0) role_hasher(ra);
+            else if (wave < N_WAVES - 1) role_extender(ra);
+            else role_parser(ra);
         }
         __syncthreads();
+        if (ms->abort) {  // (uniform) a wait of the pipeline timed out: the block is reported, not compressed
+            if (tid == 0) {
+                a.out_size[blk] = 0xffffffffu;
+                a.out_crc[blk] = ms->abort;
+                if (a.prof) {  // the rings as they stand (FADEHIP_BGZF_PROF): [8..) of the profile words
+                    unsigned long long *d = a.prof + 8;
+                    int q = 0;
+                    d[q++] = ms->abort; d[q++] = ms->ext_ticket; d[q++] = ms->carry; d[q++] = (unsigned long long)n | ((unsigned long long)ms->dbg[0] << 32);
+                    d[70] = ms->dbg[1]; d[71] = ms->dbg[2];
+                    for (int k = 0; k < R1; k++) { d[q++] = ms->cand_seq[k]; d[q++] = ms->cand_free[k]; }
+                    for (int k = 0; k < R2; k++) { d[q++] = ms->lens_seq[k]; d[q++] = ms->lens_free[k]; }
+                }
+            }
+            continue;
+        }
         stamp(1);
 
         // ---- B: match-index prefix, histograms
@@ -416,8 +579,8 @@ __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
                 S_l[r] = (uint32_t)tid;
                 atomicAdd(&ms->m_l, 1u);
             }
-        } else if (tid >= 512 && tid < 512 + NUM_DIST) {
-            const int sd = tid - 512;
+        } else if (tid >= DIST_T0 && tid < DIST_T0 + NUM_DIST) {
+            const int sd = tid - DIST_T0;
             const uint32_t f = ms->freq_d[sd];
             if (f) {
                 uint32_t r = 0;
@@ -433,31 +596,24 @@ __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
         if (tid < 320) ms->ll[tid] = 0;
         if (tid < 64) ms->dl[tid] = 0;
         __syncthreads();
-        // minimum-redundancy lengths: wave 0 the literal / length alphabet, wave 1 the distances, arrays in lane registers
-        if (wave == 0) {
-            WaveArr<5> A;
-#pragma unroll
-            for (int k = 0; k < 5; k++) A.r[k] = A_l[64 * k + lane];
+        // minimum-redundancy lengths: a lane per alphabet (a chain of ~3 m dependent LDS accesses: the one serial stretch of
+        // the block that no reformulation here made shorter — lane arrays read by v_readlane measured slower than LDS)
+        if (tid == 0) {
             const int m = (int)ms->m_l;
-            mr_code_lengths_t(A, m);
-#pragma unroll
-            for (int k = 0; k < 5; k++) A_l[64 * k + lane] = A.r[k];
-            if (lane == 0 && A_l[0] > (uint32_t)MAX_LITLEN_BITS) limit_code_lengths(A_l, m, MAX_LITLEN_BITS, ms->sortbuf);  // (rare)
-        } else if (wave == 1) {
-            WaveArr<1> A;
-            A.r[0] = A_d[lane];
+            mr_code_lengths(A_l, m);
+            limit_code_lengths(A_l, m, MAX_LITLEN_BITS, ms->sortbuf);
+        } else if (tid == 64) {
             const int m = (int)ms->m_d;
-            mr_code_lengths_t(A, m);
-            A_d[lane] = A.r[0];
-            if (lane == 0 && A_d[0] > (uint32_t)MAX_LITLEN_BITS) limit_code_lengths(A_d, m, MAX_LITLEN_BITS, ms->sortbuf + 32);
+            mr_code_lengths(A_d, m);
+            limit_code_lengths(A_d, m, MAX_LITLEN_BITS, ms->sortbuf + 32);
         }
         __syncthreads();
         if ((uint32_t)tid < ms->m_l) {
             ms->ll[S_l[tid]] = (uint8_t)A_l[tid];
             atomicAdd(&ms->bl_l[A_l[tid]], 1u);
-        } else if (tid >= 512 && (uint32_t)(tid - 512) < ms->m_d) {
-            ms->dl[S_d[tid - 512]] = (uint8_t)A_d[tid - 512];
-            atomicAdd(&ms->bl_d[A_d[tid - 512]], 1u);
+        } else if (tid >= DIST_T0 && (uint32_t)(tid - DIST_T0) < ms->m_d) {
+            ms->dl[S_d[tid - DIST_T0]] = (uint8_t)A_d[tid - DIST_T0];
+            atomicAdd(&ms->bl_d[A_d[tid - DIST_T0]], 1u);
         }
         __syncthreads();
         if (tid == 0 || tid == 64) {  // first code of each length (RFC 1951 §3.2.2)
@@ -486,20 +642,122 @@ __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
         __syncthreads();
         stamp(3);
 
-        // ---- C + D: the header (wave 0, lane arrays) beside the bit counts of the 1024 position ranges
-        if (wave == 0) {
-            WaveArr<5> LL;
-            WaveArr<1> DL, fr, sf, ss, cll, clc, bl;
-#pragma unroll
-            for (int k = 0; k < 5; k++) LL.r[k] = ms->ll[64 * k + lane];
-            DL.r[0] = ms->dl[lane];
-            fr.r[0] = sf.r[0] = ss.r[0] = cll.r[0] = clc.r[0] = bl.r[0] = 0;
-            LdsSink sink;
-            sink.w = ms->hdr;
-            write_dynamic_header_t(sink, LL, DL, fr, sf, ss, cll, clc, bl);
-            const uint32_t hb = sink.finish();
-            if (lane == 0) ms->hdr_bits = hb;
+        // ---- C: the dynamic-block header (RFC 1951 §3.2.7), in parallel: the hlit + hdist code lengths are cut into runs,
+        // every run start expands its run into code-length symbols (16 / 17 / 18 and plain lengths, the same sequence the
+        // serial cl_rle of bgzf_huff.hpp emits), a scan places them, the 19-symbol code is made by one lane, and every
+        // symbol's bits are OR-ed into the header words at scanned offsets.
+        if (tid == 0) { ms->cl_hlit = 257; ms->cl_hdist = 1; ms->cl_n = 0; }
+        if (tid < NUM_CL + 1) { ms->cl_freq[tid] = 0; ms->cl_len[tid] = 0; ms->cl_code[tid] = 0; }
+        for (int k = tid; k < 160; k += WG) ms->hdr[k] = 0;
+        __syncthreads();
+        if (tid < NUM_LITLEN && ms->ll[tid]) atomicMax(&ms->cl_hlit, (uint32_t)tid + 1u);
+        if (tid >= DIST_T0 && tid < DIST_T0 + NUM_DIST && ms->dl[tid - DIST_T0]) atomicMax(&ms->cl_hdist, (uint32_t)(tid - DIST_T0) + 1u);
+        __syncthreads();
+        {
+            const int hlit = (int)ms->cl_hlit, hdist = (int)ms->cl_hdist, nseq = hlit + hdist;
+            auto at = [&](int k) -> int { return k < hlit ? (int)ms->ll[k] : (int)ms->dl[k - hlit]; };
+            uint32_t ntok = 0;
+            int v = 0, run = 0;
+            if (tid < nseq) {
+                v = at(tid);
+                if (tid == 0 || at(tid - 1) != v) {  // a run starts here
+                    run = 1;
+                    while (tid + run < nseq && at(tid + run) == v) run++;
+                    if (v == 0) {
+                        const int full18 = run / 138, rem = run % 138;
+                        ntok = (uint32_t)full18 + (rem >= 3 ? 1u : (uint32_t)rem);
+                    } else {
+                        const int left = run - 1, full16 = left / 6, rem = left % 6;
+                        ntok = 1u + (uint32_t)full16 + (rem >= 3 ? 1u : (uint32_t)rem);
+                    }
+                }
+            }
+            uint32_t nt_all;
+            uint32_t at_tok = block_excl_scan(ntok, ms->wtmp, &nt_all);
+            if (run) {
+                auto emit = [&](int sym, int extra) {
+                    ms->cltok[at_tok++] = (uint16_t)(sym | (extra << 8));
+                    atomicAdd(&ms->cl_freq[sym], 1u);
+                };
+                int left = run;
+                if (v == 0) {
+                    while (left >= 11) { const int r = left > 138 ? 138 : left; emit(18, r - 11); left -= r; }
+                    if (left >= 3) { emit(17, left - 3); left = 0; }
+                    while (left-- > 0) emit(0, 0);
+                } else {
+                    emit(v, 0);
+                    left--;
+                    while (left >= 3) { const int r = left > 6 ? 6 : left; emit(16, r - 3); left -= r; }
+                    while (left-- > 0) emit(v, 0);
+                }
+            }
+            if (tid == 0) ms->cl_n = nt_all;
         }
+        __syncthreads();
+        if (tid == 0) {  // the code-length code: 19 symbols, 7 bits at most
+            uint32_t *sf = ms->sortbuf, *ss = ms->sortbuf + 20, *bl = ms->sortbuf + 40;
+            int m = 0;
+            for (int sy = 0; sy < NUM_CL; sy++) {
+                const uint32_t f = ms->cl_freq[sy];
+                if (f) {
+                    int j = m++;
+                    while (j > 0 && sf[j - 1] > f) { sf[j] = sf[j - 1]; ss[j] = ss[j - 1]; j--; }
+                    sf[j] = f;
+                    ss[j] = (uint32_t)sy;
+                }
+            }
+            if (m == 1) ms->cl_len[ss[0]] = 1;
+            else {
+                mr_code_lengths(sf, m);
+                limit_code_lengths(sf, m, MAX_CL_BITS, bl);
+                for (int k = 0; k < m; k++) ms->cl_len[ss[k]] = sf[k];
+            }
+            for (int bb = 0; bb <= MAX_CL_BITS; bb++) bl[bb] = 0;
+            for (int sy = 0; sy < NUM_CL; sy++)
+                if (ms->cl_len[sy]) bl[ms->cl_len[sy]]++;
+            uint32_t c = 0;
+            sf[0] = 0;
+            for (int bb = 1; bb <= MAX_CL_BITS; bb++) {
+                c = (c + (bb > 1 ? bl[bb - 1] : 0u)) << 1;
+                sf[bb] = c;
+            }
+            for (int sy = 0; sy < NUM_CL; sy++) {
+                const uint32_t l = ms->cl_len[sy];
+                if (l) ms->cl_code[sy] = __builtin_bitreverse32(sf[l]++) >> (32u - l);
+            }
+            int hclen = NUM_CL;
+            while (hclen > 4 && ms->cl_len[cl_order(hclen - 1)] == 0) hclen--;
+            ms->cl_hclen = (uint32_t)hclen;
+            // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then 3 bits per code-length code length
+            WordSink sink;
+            sink.w = ms->hdr;
+            sink.put(1, 1);
+            sink.put(2, 2);
+            sink.put(ms->cl_hlit - 257u, 5);
+            sink.put(ms->cl_hdist - 1u, 5);
+            sink.put((uint32_t)(hclen - 4), 4);
+            for (int k = 0; k < hclen; k++) sink.put(ms->cl_len[cl_order(k)], 3);
+            sink.finish();
+        }
+        __syncthreads();
+        {
+            const uint32_t nt_all = ms->cl_n, fixed_bits = 17u + 3u * ms->cl_hclen;
+            uint32_t bits = 0, val = 0;
+            if ((uint32_t)tid < nt_all) {
+                const uint32_t t = ms->cltok[tid], sy = t & 255u, ex = t >> 8;
+                const uint32_t l = ms->cl_len[sy], eb = sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u;
+                val = ms->cl_code[sy] | (ex << l);
+                bits = l + eb;
+            }
+            uint32_t cl_bits_all;
+            const uint32_t o = fixed_bits + block_excl_scan(bits, ms->wtmp, &cl_bits_all);
+            if (bits) {
+                atomicOr(&ms->hdr[o >> 5], val << (o & 31u));
+                if ((o & 31u) + bits > 32u) atomicOr(&ms->hdr[(o >> 5) + 1u], val >> (32u - (o & 31u)));
+            }
+            if (tid == 0) ms->hdr_bits = fixed_bits + cl_bits_all;
+        }
+        // ---- D: the bit counts of the 1024 position ranges
         uint32_t my_bits = 0;
 #pragma unroll
         for (int k = 0; k < WPT; k++) {
@@ -595,7 +853,8 @@ __global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
         }
         uint32_t part = 0;
         {
-            constexpr int PIECE = 65536 / WG;
+            constexpr int PIECE = ((65536 / WG + 3) / 4 + 1) * 4;  // bytes per thread, a multiple of 4, WG * PIECE >= BLOCK
+            static_assert(PIECE * WG >= BLOCK, "CRC pieces must cover the block");
             const int lo = PIECE * tid, hi = min(lo + PIECE, n);
             if (lo < hi) {
                 uint32_t c = 0xffffffffu;
@@ -628,14 +887,20 @@ __global__ __launch_bounds__(1024) void bgzf_scan_kernel(const uint32_t *out_siz
     __shared__ uint64_t part[1024];
     const int tid = threadIdx.x;
     const uint32_t per = (n_blocks + 1023u) / 1024u, lo = (uint32_t)tid * per, hi = min(lo + per, n_blocks);
+    __shared__ int failed;
+    if (tid == 0) failed = 0;
+    __syncthreads();
     uint64_t s = 0;
-    for (uint32_t k = lo; k < hi; k++) s += (uint64_t)out_size[k] + 26u;
+    for (uint32_t k = lo; k < hi; k++) {
+        if (out_size[k] > (uint32_t)MAX_PAYLOAD) failed = 1;  // a block the compressor gave up on (see spin_until)
+        s += (uint64_t)out_size[k] + 26u;
+    }
     part[tid] = s;
     __syncthreads();
     if (tid == 0) {
         uint64_t run = 0;
         for (int k = 0; k < 1024; k++) { const uint64_t c = part[k]; part[k] = run; run += c; }
-        *total = run;
+        *total = failed ? 0ull : run;  // 0: the host reports the failure instead of copying anything
     }
     __syncthreads();
     uint64_t at = part[tid];
@@ -648,6 +913,7 @@ __global__ __launch_bounds__(256) void bgzf_pack_kernel(const uint8_t *slots, co
     const uint32_t blk = blockIdx.x;
     if (blk >= n_blocks) return;
     const uint32_t sz = out_size[blk];
+    if (sz > (uint32_t)MAX_PAYLOAD) return;  // (a failed block: nothing is packed, the scan has zeroed the total)
     uint8_t *d = dst + member_off[blk];
     const uint8_t *s = slots + (uint64_t)blk * SLOT;
     const int tid = threadIdx.x;

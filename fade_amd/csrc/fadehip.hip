@@ -1615,7 +1615,7 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     const uint32_t nb = (uint32_t)((n_bytes + bgzf::BLOCK - 1) / bgzf::BLOCK);
     int rc;
     if ((rc = reserve(ctx, l.src, n_bytes + 64)) || (rc = reserve(ctx, l.slots, (size_t)nb * bgzf::SLOT)) ||
-        (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 256)) || (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) ||
+        (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 1024)) || (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) ||
         (rc = reserve(ctx, l.packed, (size_t)nb * bgzf::SLOT)))
         return rc;
     uint32_t *d_size = (uint32_t *)l.meta.p, *d_crc = d_size + nb, *d_ticket = d_crc + nb;
@@ -1633,7 +1633,7 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     a.prof = nullptr;
     if (getenv("FADEHIP_BGZF_PROF")) {  // shader clocks per phase, printed by wait (development aid)
         a.prof = (unsigned long long *)(d_total + 1);
-        HIPCHK(ctx, hipMemsetAsync(a.prof, 0, 64, l.stream));
+        HIPCHK(ctx, hipMemsetAsync(a.prof, 0, 64 + 8 * 72, l.stream));
     }
     const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(ctx->cu_count, 1));
     hipLaunchKernelGGL(bgzf::bgzf_deflate_kernel, dim3(grid), dim3(bgzf::WG), bgzf::LDS_BYTES, l.stream, a);
@@ -1661,19 +1661,36 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
     const uint64_t total = *l.h_total;
     l.state = 0;
     if (getenv("FADEHIP_BGZF_PROF")) {
-        unsigned long long pr[8];
+        unsigned long long pr[8 + 72];
         uint32_t *d_ticket = (uint32_t *)l.meta.p + 2 * (size_t)l.n_blocks;
         uint64_t *d_total = (uint64_t *)(((uintptr_t)(d_ticket + 2) + 7) & ~(uintptr_t)7);
-        if (hipMemcpy(pr, d_total + 1, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (hipMemcpy(pr, d_total + 1, sizeof pr, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (pr[8]) {
+                fprintf(stderr, "[fadehip bgzf] pipeline timeout: wait 0x%llx (saw %llu, wanted %llu, wave %llu) ticket %llu carry %llu n %llu | cand seq/free:", pr[8], pr[11] >> 32, pr[78], pr[79], pr[9], pr[10], pr[11] & 0xffffffffull);
+                for (int k = 0; k < 4; k++) fprintf(stderr, " %llu/%llu", pr[12 + 2 * k], pr[13 + 2 * k]);
+                fprintf(stderr, " | lens seq/free:");
+                for (int k = 0; k < 24; k++) fprintf(stderr, " %llu/%llu", pr[20 + 2 * k], pr[21 + 2 * k]);
+                fprintf(stderr, "\n");
+            }
             static const char *nm[7] = {"load", "A match+parse", "B hist", "B codes", "C header+count", "D emit", "CRC"};
             unsigned long long sum = 0;
             for (int k = 0; k < 7; k++) sum += pr[k];
             fprintf(stderr, "[fadehip bgzf] %u blocks, shader clocks per block:", l.n_blocks);
             for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.0f (%.0f%%)", nm[k], (double)pr[k] / l.n_blocks, 100.0 * (double)pr[k] / (double)std::max<unsigned long long>(sum, 1));
             fprintf(stderr, "\n");
+            fprintf(stderr, "[fadehip bgzf] phase A roles, clocks per block waited / in role: hasher %.0f / %.0f, extenders (sum) %.0f / %.0f, parser %.0f / %.0f\n",
+                    (double)pr[60] / l.n_blocks, (double)pr[61] / l.n_blocks, (double)pr[62] / l.n_blocks, (double)pr[63] / l.n_blocks, (double)pr[64] / l.n_blocks, (double)pr[65] / l.n_blocks);
         }
     }
-    if (total == 0 || total > (uint64_t)l.n_blocks * bgzf::SLOT) return set_err(ctx, FADEHIP_E_STATE, "internal: bgzf members add up to %llu bytes", (unsigned long long)total);
+    if (total == 0 || total > (uint64_t)l.n_blocks * bgzf::SLOT) {
+        // a block whose pipeline timed out reports size ~0 and, as its CRC, the wait that gave up (role << 28 | piece)
+        std::vector<uint32_t> meta(2 * (size_t)l.n_blocks);
+        unsigned bad = 0, why = 0;
+        if (hipMemcpy(meta.data(), l.meta.p, meta.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+            for (uint32_t k = 0; k < l.n_blocks; k++)
+                if (meta[k] == 0xffffffffu) { if (!bad) why = meta[l.n_blocks + k]; bad++; }
+        return set_err(ctx, FADEHIP_E_STATE, "internal: bgzf members add up to %llu bytes (%u blocks timed out, first wait 0x%08x)", (unsigned long long)total, bad, why);
+    }
     int rc = reserve_pinned(ctx, l.out, (size_t)total);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(l.out.p, l.packed.p, (size_t)total, hipMemcpyDeviceToHost, l.stream));

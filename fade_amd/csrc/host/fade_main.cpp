@@ -791,6 +791,15 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 fprintf(stderr, "[timing] BAM reader thread: wait for file bytes %.3f, scan %.3f, inflate (parallel) %.3f, frame %.3f, carry %.3f, "
                                 "layout check (parallel) %.3f\n", rp.wait_io, rp.scan, rp.inflate, rp.frame, rp.carry, rp.layout);
         }
+        // Everything is written and flushed.  What is left would be giving back, piece by piece, what the process exit gives
+        // back at once — the contexts' device buffers and streams, a gigabyte of pinned blocks, the pools' threads: 0.1 s of
+        // a 0.8 s run.  FADE_FAST_EXIT=0 takes the long way (leak checkers, tests of the destructors).
+        if (!(getenv("FADE_FAST_EXIT") && atoi(getenv("FADE_FAST_EXIT")) == 0)) {
+            if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (leaving by _exit)\n", since_process_start());
+            fflush(stdout);
+            fflush(stderr);
+            _exit(0);
+        }
     } catch (const std::exception &e) {
         fprintf(stderr, "[E::fade annotate] %s\n", e.what());
         return 1;
