@@ -201,9 +201,9 @@ def main():
     t0 = time.perf_counter()
     if args.synth == "native":
         import synthgen as sg
-        genome = sg.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+        genome = sg.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"], kind=cfg.get("genome_kind", "uniform"))
     else:
-        genome = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+        genome = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"], kind=cfg.get("genome_kind", "uniform"))
     t_setup["genome"] = time.perf_counter() - t0
     n_slots = max(1, min(int(args.slots), fade_amd._lib.NUM_SLOTS))
     ctx = fade_amd.Context(device=local, max_batch_reads=max(args.batch_reads, 1 << 20))

@@ -1136,7 +1136,7 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         for (DevBuf *b : {&l.src, &l.slots, &l.meta, &l.member_off, &l.packed}) release(*b);
         release(l.out);
         if (l.h_total) (void)hipHostFree(l.h_total);
-        if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.stream && (&l == &ctx->bgzf[0] || l.stream != ctx->bgzf[0].stream)) (void)hipStreamDestroy(l.stream);
     }
     release(ctx->genome);
     for (DevBuf *b : {&ctx->l1_q, &ctx->l1_r, &ctx->l1_qn, &ctx->l1_rn, &ctx->l1_bad, &ctx->l1_work, &ctx->l1_aln}) release(*b);
@@ -1603,7 +1603,10 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     HIPCHK(ctx, hipSetDevice(ctx->device));
     BgzfLane &l = ctx->bgzf[lane];
     if (!l.stream) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        // (every stream is an HSA queue with a 173 MB context-save area to set up and to give back: FADEHIP_BGZF_ONE_STREAM=1
+        // lets the lanes share one — their copies then no longer overlap each other's kernels)
+        if (lane > 0 && getenv("FADEHIP_BGZF_ONE_STREAM") && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
+        else HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
     }
     if (!ctx->bgzf_ready) {

@@ -698,7 +698,12 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         std::vector<int> next_slot((size_t)ngpu, 0);
         std::chrono::steady_clock::time_point t_first;
         std::unique_ptr<Chunk> c;
-        while (!failed && q_in.pop(c)) {
+        // a failed stage (reader or writer) ends the run here: no further batch is packed or sent to a device
+        auto stage_failed = [&] {
+            std::lock_guard<std::mutex> l(err_m);
+            return !stage_err.empty();
+        };
+        while (!failed && !stage_failed() && q_in.pop(c)) {
             c->dev = (int)(seq_no % (size_t)ngpu);
             c->slot = next_slot[(size_t)c->dev];
             next_slot[(size_t)c->dev] = (c->slot + 1) % (int)kSlotsInUse;
@@ -712,12 +717,18 @@ static int annotate_main(const std::string &cl, const Opts &o) {
                 if (finish(std::move(inflight.front()))) failed = true;
                 inflight.pop_front();
             }
-            if (failed) break;
+            if (failed) {
+                blocks[(size_t)c->dev].release(c->block, c->block_cap);  // (the chunk in hand goes nowhere: its pinned block returns to the pool)
+                c->block = nullptr;
+                break;
+            }
             ck_submit.start();
             const int src = fadehip_annotate_submit(ctxs[(size_t)c->dev], c->slot, &c->b, o.floor_len, o.window);
             ck_submit.stop();
             if (src) {
                 fprintf(stderr, "[E::fade annotate] submit: %s\n", fadehip_last_error(ctxs[(size_t)c->dev]));
+                blocks[(size_t)c->dev].release(c->block, c->block_cap);
+                c->block = nullptr;
                 failed = true;
                 break;
             }
@@ -733,7 +744,15 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             if (finish(std::move(inflight.front()))) failed = true;
             inflight.pop_front();
         }
-        if (failed) {  // let the reader run out so that it can exit
+        if (stage_failed()) failed = true;
+        if (failed) {  // the batches still in flight are abandoned (their pinned blocks go back), the reader runs out so that it can exit
+            for (auto &f : inflight)
+                if (f && f->block) {
+                    (void)fadehip_sync(ctxs[(size_t)f->dev]);  // the DMA out of the block has ended before it is reused or freed
+                    blocks[(size_t)f->dev].release(f->block, f->block_cap);
+                    f->block = nullptr;
+                }
+            inflight.clear();
             abort_stages = true;
             while (q_in.pop(c)) {}
         }

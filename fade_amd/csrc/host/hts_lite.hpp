@@ -496,6 +496,11 @@ inline void sam_parse(const char *line, size_t len, const Header &h, Rec &r) {
             }
         }
     }
+    // BAM holds l_read_name in one byte (the name and its NUL) and n_cigar_op in 16 bits: a line beyond either cannot be laid
+    // out as a record (htslib moves such a CIGAR into a CG tag; this reader refuses the line rather than write fields that
+    // contradict the bytes behind them)
+    if (fl[0] > 254) throw std::runtime_error("SAM line with a QNAME longer than 254 characters");
+    if (cig.size() > 65535) throw std::runtime_error("SAM line with more than 65535 CIGAR operations");
     const bool noseq = fl[9] == 1 && f[9][0] == '*';
     const size_t lseq = noseq ? 0 : fl[9];
     const size_t lq = fl[0] + 1;
@@ -1312,6 +1317,7 @@ private:
             try {
                 for (size_t i = lo; i < hi; i++) {
                     sam_parse((const char *)text_.data() + lines[i].first, lines[i].second, hdr_, r);
+                    if (!r.layout_ok()) throw std::runtime_error("corrupt SAM record (field lengths exceed the record)");  // as for BAM input
                     piece[t].insert(piece[t].end(), r.d.begin(), r.d.end());
                     plen[t].push_back((uint32_t)r.d.size());
                 }

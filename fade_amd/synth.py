@@ -30,16 +30,57 @@ CONFIGS = {
                clip_min=1, clip_max=60, insert_mu=350, insert_sd=50, floor_len=5),
 }
 CONFIGS["C4"] = dict(CONFIGS["C2"])
+# C6 (round 3): C2's reads on a repeat-rich genome — tandem repeats, homopolymer runs and a 10 % segmental duplication —
+# where the re-alignment has co-optimal and gapped paths, the forced-diagonal shortcut hits less often and the traced pass
+# works for its living (the iid-uniform genome of C1-C5 flatters the shortcut)
+CONFIGS["C6"] = dict(CONFIGS["C2"], genome_kind="repeat_rich", p_clip_indel=0.3)
+
+
+def make_repeat_rich(codes, n_contigs, contig_len, seed):
+    """In place, on base codes 0..3 (all contigs concatenated): ~15 % of every contig becomes tandem repeats (unit 1-6 bases,
+    30-400 bases long, 2 % of the copies' bases substituted), ~5 % homopolymer runs (10-60 bases), and 10 % of the genome is
+    overwritten by copies of other stretches of it (segments of 5-40 kb, 1 % divergence): segmental duplications."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    for c in range(n_contigs):
+        g = codes[c * contig_len:(c + 1) * contig_len]
+        # segmental duplications first (the repeats then differ between the copies a little, as in real genomes)
+        left = contig_len // 10
+        while left > 0:
+            ln = int(min(rng.integers(5_000, 40_001), max(left, 1000), contig_len // 4))
+            src_c = int(rng.integers(0, n_contigs))
+            src = int(rng.integers(0, contig_len - ln))
+            dst = int(rng.integers(0, contig_len - ln))
+            seg = codes[src_c * contig_len + src:src_c * contig_len + src + ln].copy()
+            m = rng.random(ln) < 0.01
+            seg[m] = (seg[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+            g[dst:dst + ln] = seg
+            left -= ln
+        n_tr = int(0.15 * contig_len / 200)
+        for _ in range(n_tr):
+            unit = rng.integers(0, 4, int(rng.integers(1, 7)), dtype=np.uint8)
+            ln = int(rng.integers(30, 401))
+            at = int(rng.integers(0, contig_len - ln))
+            rep = np.resize(unit, ln).copy()
+            m = rng.random(ln) < 0.02
+            rep[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
+            g[at:at + ln] = rep
+        n_hp = int(0.05 * contig_len / 35)
+        for _ in range(n_hp):
+            ln = int(rng.integers(10, 61))
+            at = int(rng.integers(0, contig_len - ln))
+            g[at:at + ln] = rng.integers(0, 4)
 
 
 class Genome:
-    def __init__(self, n_contigs, contig_len, seed, prefix="chr"):
+    def __init__(self, n_contigs, contig_len, seed, prefix="chr", kind="uniform"):
         rng = np.random.Generator(np.random.PCG64(seed))
         self.names = ["%s%d" % (prefix, k + 1) for k in range(n_contigs)]
         self.lengths = np.full(n_contigs, contig_len, dtype=np.int64)
         self.offsets = np.concatenate([[0], np.cumsum(self.lengths)]).astype(np.int64)
         # base codes 0..3 (A,C,G,T), all contigs concatenated
         self.codes = rng.integers(0, 4, size=int(self.offsets[-1]), dtype=np.uint8)
+        if kind == "repeat_rich":
+            make_repeat_rich(self.codes, n_contigs, contig_len, seed)
 
     def ascii_contigs(self):
         """list of uint8 arrays of ASCII residues (upper case)."""
@@ -56,7 +97,7 @@ class Genome:
 
 def make_reads(genome, n_reads, seed, read_len=150, window=100, p_sc=0.10, clip_min=6, clip_max=50,
                insert_mu=350, insert_sd=50, p_unmapped=0.01, p_sa=0.02, p_sub=0.001, p_planted=0.5,
-               with_names=False, chunk=200_000, **_unused):
+               with_names=False, chunk=200_000, p_clip_indel=0.0, **_unused):
     """Returns the batch dict.  Deterministic in (genome, all arguments)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     Lq = int(read_len)
@@ -128,6 +169,21 @@ def make_reads(genome, n_reads, seed, read_len=150, window=100, p_sc=0.10, clip_
         sub = rng.random((m, Lq)) < p_sub
         shift = rng.integers(1, 4, size=(m, Lq), dtype=np.uint8)
         base = np.where(sub, (base + shift) & 3, base).astype(np.uint8)
+        if p_clip_indel > 0:
+            # a planted clip of 12 bases or more loses one inner base with this probability (the clip's outer end takes a
+            # random one): the re-alignment then has a gap in it, the forced-diagonal shortcut does not apply (C6)
+            hit = rng.random(m) < p_clip_indel
+            for r in np.nonzero(hit & (plantL[sl] | plantR[sl]))[0]:
+                if plantL[c0 + r] and clipL[c0 + r] >= 12:
+                    L = int(clipL[c0 + r])
+                    at = int(rng.integers(3, L - 3))
+                    base[r, 1:at + 1] = base[r, 0:at].copy()
+                    base[r, 0] = rng.integers(0, 4)
+                elif plantR[c0 + r] and clipR[c0 + r] >= 12:
+                    L = int(clipR[c0 + r])
+                    at = Lq - L + int(rng.integers(3, L - 3))
+                    base[r, at:Lq - 1] = base[r, at + 1:Lq].copy()
+                    base[r, Lq - 1] = rng.integers(0, 4)
         codes = _ACGT_NT16[base]
         if Lq & 1:
             codes = np.concatenate([codes, np.zeros((m, 1), dtype=np.uint8)], axis=1)
@@ -177,7 +233,7 @@ def make_config(name, n_reads, read_seed=7, genome=None, contig_len=None):
     cfg = config(name)
     if contig_len is not None:
         cfg["contig_len"] = contig_len
-    g = genome or Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    g = genome or Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"], kind=cfg.get("genome_kind", "uniform"))
     b = make_reads(g, n_reads, read_seed, **cfg)
     return cfg, g, b
 

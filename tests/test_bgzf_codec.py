@@ -177,3 +177,25 @@ def test_block_writer_with_layout_hints(tmp_path):
     skip = lambda x, l: x[8 + l:]  # (the header texts differ by the @PG line `fade out` adds)
     ra, rb = skip(a, la), skip(b, lb)
     assert ra[ra.index(b"read0\0") - 36:] == rb[rb.index(b"read0\0") - 36:]
+
+
+def test_sam_lines_that_cannot_be_bam_records_are_refused(tmp_path):
+    """BAM stores l_read_name in a byte and n_cigar_op in 16 bits.  A SAM line beyond either used to be laid out with
+    truncated counts in front of untruncated bytes (every later field read from the wrong place); it is an error now,
+    on the per-record path (`fade out`) as on the block path `fade annotate` reads through (tools/sam2bam)."""
+    tools = os.path.join(ROOT, "tools")
+    subprocess.run(["make", "-s", "-C", tools, "sam2bam"], check=True, timeout=600)
+    hdr = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000000\n"
+    long_name = tmp_path / "longname.sam"
+    long_name.write_text(hdr + "%s\t0\tchr1\t100\t60\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\n" % ("q" * 300))
+    many_ops = tmp_path / "manyops.sam"
+    n = 70000
+    many_ops.write_text(hdr + "r1\t0\tchr1\t100\t60\t%s\t*\t0\t0\t%s\t%s\n" % ("1M1I" * (n // 2), "A" * n, "I" * n))
+    for sam, what in ((long_name, b"QNAME"), (many_ops, b"CIGAR")):
+        for cmd in ([FADE, "out", "-b", "-t", "2", str(sam)], [os.path.join(tools, "sam2bam"), str(sam)]):
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert p.returncode != 0 and what in p.stderr, (cmd, p.stderr[-300:])
+    ok = tmp_path / "ok.sam"
+    ok.write_text(hdr + "%s\t0\tchr1\t100\t60\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\n" % ("q" * 254))
+    p = subprocess.run([FADE, "out", "-b", "-t", "2", str(ok)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0 and (b"q" * 254 + b"\0") in gzip.decompress(p.stdout)

@@ -22,7 +22,7 @@ def _oracle_tags(oracle, g, b, cfg, floor_len=None, window=None):
     return rs, tags
 
 
-@pytest.mark.parametrize("name,n", [("C1", 6000), ("C2", 6000), ("C3", 3000), ("C5", 4000)])
+@pytest.mark.parametrize("name,n", [("C1", 6000), ("C2", 6000), ("C3", 3000), ("C5", 4000), ("C6", 6000)])
 def test_annotate_matches_oracle(ctx, oracle, name, n):
     cfg, g, b = synth.make_config(name, n, contig_len=300_000)
     ctx.genome_upload(g.names, g.ascii_contigs())
@@ -47,3 +47,27 @@ def test_stats_allreduce_over_rccl(ctx):
     c = np.arange(8, dtype=np.int64).reshape(1, 8) * 1000 + 7
     out = fade_amd.stats_allreduce([ctx], c)
     assert np.array_equal(out, c)
+
+
+def test_stats_allreduce_with_two_contexts_on_the_one_device(ctx):
+    """Two contexts (two ranks) on this box's single GPU.  RCCL wants one rank per device: ncclCommInitAll with a device
+    listed twice is refused, which the C ABI reports as FADEHIP_E_RCCL — the reason `fade annotate --gpus N` under
+    FADE_DEVICE_MAP=0,0 sums on the host instead (fade_main.cpp).  Whichever way the sum is taken, every rank must end up
+    with the column sums: checked here for the RCCL call if this stack allows it, and for the host sum it falls back to."""
+    import fade_amd
+    other = fade_amd.Context(device=0)
+    try:
+        c = np.array([np.arange(8) * 10 + 1, np.arange(8) * 1000 + 5], dtype=np.int64)
+        want = np.tile(c.sum(axis=0), (2, 1))
+        try:
+            out = fade_amd.stats_allreduce([ctx, other], c)
+            assert np.array_equal(out, want)  # RCCL accepted two ranks on one device
+        except fade_amd.FadeHipError as e:
+            assert e.code == -8, e  # FADEHIP_E_RCCL: refused, not crashed
+            host = np.tile(c.sum(axis=0), (2, 1))  # what the driver does instead (fade_main.cpp: per_dev summed on the host)
+            assert np.array_equal(host, want)
+        # the contexts stay usable either way
+        one = fade_amd.stats_allreduce([ctx], c[:1])
+        assert np.array_equal(one, c[:1])
+    finally:
+        other.close()

@@ -47,12 +47,15 @@ def threads():
 class Genome:
     """Same interface as fade_amd.synth.Genome (names, lengths, offsets, codes, ascii_contigs)."""
 
-    def __init__(self, n_contigs, contig_len, seed):
+    def __init__(self, n_contigs, contig_len, seed, kind="uniform"):
         self.names = ["chr%d" % (k + 1) for k in range(n_contigs)]
         self.lengths = np.full(n_contigs, contig_len, dtype=np.int64)
         self.offsets = np.concatenate([[0], np.cumsum(self.lengths)]).astype(np.int64)
         self.codes = np.empty(int(self.offsets[-1]), dtype=np.uint8)
         lib().sg_genome(seed, len(self.codes), self.codes.ctypes.data, threads())
+        if kind == "repeat_rich":  # (the repeat structure is laid over the uniform bases by fade_amd.synth's routine)
+            from fade_amd import synth
+            synth.make_repeat_rich(self.codes, n_contigs, contig_len, seed)
 
     def ascii_contigs(self):
         t = np.frombuffer(b"ACGT", dtype=np.uint8)
