@@ -30,7 +30,7 @@ EXPORTS = [
     "fadehip_genome_upload", "fadehip_annotate_upload", "fadehip_annotate_run", "fadehip_annotate_submit",
     "fadehip_annotate_results", "fadehip_annotate_collect",
     "fadehip_sync", "fadehip_last_run_profile", "fadehip_stats_allreduce",
-    "fadehip_bgzf_deflate_submit", "fadehip_bgzf_deflate_wait",
+    "fadehip_bgzf_deflate_submit", "fadehip_bgzf_deflate_wait", "fadehip_stats_allreduce_rank",
 ]
 BGZF_BLOCK = 0xff00
 BGZF_LANES = 2
@@ -121,6 +121,7 @@ def load():
     L.fadehip_last_run_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_float * 4), C.POINTER(i64 * 6)]
     L.fadehip_stats_allreduce.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int]
     L.fadehip_bgzf_deflate_submit.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.fadehip_stats_allreduce_rank.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, vp, C.c_int]
     L.fadehip_bgzf_deflate_wait.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here means the .so is stale against include/fadehip.h

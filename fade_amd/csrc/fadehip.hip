@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <new>
@@ -1741,6 +1742,54 @@ int fadehip_stats_allreduce(fadehip_ctx *const *ctxs, int n_ctx, int64_t *counte
         if (bufs[k]) (void)hipFree(bufs[k]);
         ncclCommDestroy(comms[k]);
     }
+    return rc;
+}
+
+int fadehip_stats_allreduce_rank(fadehip_ctx *ctx, int rank, int n_ranks, const char *id_path, int64_t *counters, int count) {
+    if (!ctx || !id_path || !counters || count <= 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return set_err(ctx, FADEHIP_E_INVALID, "bad arguments");
+    if (n_ranks == 1) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    if (rank == 0) {
+        ncclResult_t nr = ncclGetUniqueId(&id);
+        if (nr != ncclSuccess) return set_err(ctx, FADEHIP_E_RCCL, "ncclGetUniqueId failed: %s", ncclGetErrorString(nr));
+        const std::string tmp = std::string(id_path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return set_err(ctx, FADEHIP_E_INVALID, "cannot write %s", tmp.c_str()); }
+        fclose(f);
+        if (rename(tmp.c_str(), id_path) != 0) return set_err(ctx, FADEHIP_E_INVALID, "cannot rename %s", tmp.c_str());
+    } else {
+        bool got = false;
+        for (int tries = 0; tries < 60000 && !got; tries++) {
+            if (FILE *f = fopen(id_path, "rb")) {
+                got = fread(&id, 1, sizeof id, f) == sizeof id;
+                fclose(f);
+            }
+            if (!got) {
+                struct timespec ts = {0, 1000000};
+                nanosleep(&ts, nullptr);
+            }
+        }
+        if (!got) return set_err(ctx, FADEHIP_E_RCCL, "rank %d: no ncclUniqueId appeared in %s", rank, id_path);
+    }
+    ncclComm_t comm;
+    ncclResult_t nr = ncclCommInitRank(&comm, n_ranks, id, rank);
+    if (nr != ncclSuccess) return set_err(ctx, FADEHIP_E_RCCL, "ncclCommInitRank failed: %s", ncclGetErrorString(nr));
+    void *buf = nullptr;
+    int rc = 0;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&buf, sizeof(int64_t) * count) != hipSuccess ||
+        hipMemcpy(buf, counters, sizeof(int64_t) * count, hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_err(ctx, FADEHIP_E_HIP, "staging counters failed");
+    if (!rc) {
+        nr = ncclAllReduce(buf, buf, count, ncclInt64, ncclSum, comm, st);
+        if (nr != ncclSuccess) rc = set_err(ctx, FADEHIP_E_RCCL, "ncclAllReduce failed: %s", ncclGetErrorString(nr));
+    }
+    if (!rc && (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(counters, buf, sizeof(int64_t) * count, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = set_err(ctx, FADEHIP_E_HIP, "reading the reduced counters failed");
+    if (buf) (void)hipFree(buf);
+    ncclCommDestroy(comm);
+    if (st) (void)hipStreamDestroy(st);
     return rc;
 }
 

@@ -23,7 +23,13 @@
 #include <functional>
 #include <future>
 #include <sched.h>
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+extern char **environ;
 
 #ifndef FADE_VERSION
 #define FADE_VERSION "v0.5.0-mi355x"
@@ -493,15 +499,289 @@ static double since_process_start() {
     return up - (double)start / (double)sysconf(_SC_CLK_TCK);
 }
 
+// ------------------------------------------------------------------ lanes: one process per GPU
+// `fade annotate --gpus N` on a BAM file: N lanes, each a process of its own with its own reader, device and writer, on
+// disjoint BGZF virtual-offset ranges of the input; no lane sees another's records, the only exchange
+// is the final sum of the stats.d counters (RCCL when the lanes sit on distinct devices).  The parent never touches the
+// GPU: it cuts the file, starts the lanes, and puts their outputs together — BGZF blocks concatenate.
+struct LaneEnv {
+    bool on = false;
+    int k = 0, n = 1, device = 0, rccl = 0;
+    LaneRange range;
+    std::string cl, status_path, id_path;
+};
+static LaneEnv lane_env() {
+    LaneEnv e;
+    const char *l = getenv("FADE_LANE");
+    if (!l) return e;
+    unsigned long long a = 0, b = 0, c = 0, d = 0;
+    if (sscanf(l, "%d/%d:%d:%d:%llu:%llu:%llu:%llu", &e.k, &e.n, &e.device, &e.rccl, &a, &b, &c, &d) != 8) return e;
+    e.on = true;
+    e.range.on = true;
+    e.range.coff_start = a;
+    e.range.first_rec = b;
+    e.range.coff_end = c;
+    e.range.end_rec = d;
+    if (const char *v = getenv("FADE_LANE_CL")) e.cl = v;
+    if (const char *v = getenv("FADE_LANE_STATUS")) e.status_path = v;
+    if (const char *v = getenv("FADE_LANE_NCCL_ID")) e.id_path = v;
+    return e;
+}
+
+// a plausible BAM record at buf[o ..): the checks a splitter can make without the chain from the start of the file
+static bool plausible_record(const uint8_t *buf, size_t n, size_t o, int n_ref, size_t *next) {
+    if (o + 36 > n) return false;
+    uint32_t bs;
+    memcpy(&bs, buf + o, 4);
+    if (bs < 32 || bs > (1u << 24)) return false;
+    const RecView v(buf + o + 4, std::min<size_t>(bs, n - o - 4));
+    if (v.tid() < -1 || v.tid() >= n_ref || v.mtid() < -1 || v.mtid() >= n_ref || v.pos() < -1 || v.mpos() < -1) return false;
+    const size_t lq = (size_t)v.l_qname();
+    if (lq < 1 || v.l_seq() < 0) return false;
+    const size_t need = 32 + lq + 4 * (size_t)v.n_cigar() + ((size_t)v.l_seq() + 1) / 2 + (size_t)v.l_seq();
+    if (need > bs) return false;
+    if (o + 4 + 32 + lq <= n) {
+        const uint8_t *q = buf + o + 4 + 32;
+        if (q[lq - 1] != 0) return false;
+        for (size_t k = 0; k + 1 < lq; k++)
+            if (q[k] < 33 || q[k] > 126) return false;
+    }
+    *next = o + 4 + bs;
+    return true;
+}
+
+static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_back) {
+    *fall_back = true;  // until the lanes have been started, a single-lane run can still take over
+    const int n_lanes = o.gpus;
+    const std::string &path = o.pos[1];
+    struct stat sb;
+    if (path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return 1;
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    // the BGZF blocks of the file
+    std::vector<uint64_t> boff;
+    std::vector<uint32_t> bsz;
+    {
+        uint64_t at = 0;
+        uint8_t h[18];
+        while (pread(fileno(f), h, 18, (off_t)at) == 18) {
+            if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') return 1;  // not BGZF: one lane reads it
+            const uint32_t bs = (uint32_t)(h[16] | (h[17] << 8)) + 1u;
+            boff.push_back(at);
+            bsz.push_back(bs);
+            at += bs;
+        }
+    }
+    if (boff.size() < (size_t)(8 * n_lanes)) return 1;  // too small to be worth cutting
+    auto isize_of = [&](size_t b) -> uint32_t {
+        uint8_t t[4] = {0, 0, 0, 0};
+        if (pread(fileno(f), t, 4, (off_t)(boff[b] + bsz[b] - 4)) != 4) return 0;
+        return (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    };
+    auto inflate_blocks = [&](size_t b0, size_t nb, std::vector<uint8_t> &out, std::vector<size_t> &start) -> bool {
+        out.clear();
+        start.clear();
+        for (size_t b = b0; b < std::min(b0 + nb, boff.size()); b++) {
+            std::vector<uint8_t> comp(bsz[b]);
+            if (pread(fileno(f), comp.data(), comp.size(), (off_t)boff[b]) != (ssize_t)comp.size()) return false;
+            const size_t xlen = (size_t)comp[10] | ((size_t)comp[11] << 8), hl = 12 + xlen;
+            if (comp.size() < hl + 8) return false;
+            const uint32_t isz = isize_of(b);
+            if (isz > 65536) return false;
+            start.push_back(out.size());
+            const size_t base = out.size();
+            out.resize(base + isz);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            zs.next_in = comp.data() + hl;
+            zs.avail_in = (uInt)(comp.size() - hl - 8);
+            zs.next_out = out.data() + base;
+            zs.avail_out = isz;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.total_out != isz) return false;
+        }
+        start.push_back(out.size());
+        return true;
+    };
+    // header, number of references
+    int n_ref = 0;
+    size_t hdr_bytes = 0;
+    {
+        Pool small(1);
+        Reader rd(path, &small);
+        if (!rd.is_bam()) return 1;
+        n_ref = (int)rd.header().names.size();
+        hdr_bytes = rd.bam_header_bytes();
+    }
+    // lane starts: lane 0 behind the header; lane k at the first offset of block k * nblk / N from which a chain of
+    // plausible records runs through the next blocks.  The guess is checked for real by the lane before, whose own chain
+    // must end exactly there.
+    std::vector<LaneRange> lr((size_t)n_lanes);
+    {
+        size_t b = 0;
+        uint64_t cum = 0;
+        while (b < boff.size() && cum + isize_of(b) <= hdr_bytes) cum += isize_of(b++);
+        if (b >= boff.size()) return 1;
+        lr[0].on = true;
+        lr[0].coff_start = boff[b];
+        lr[0].first_rec = hdr_bytes - cum;
+    }
+    for (int k = 1; k < n_lanes; k++) {
+        bool found = false;
+        for (size_t b = boff.size() * (size_t)k / (size_t)n_lanes; b + 4 < boff.size() && !found; b++) {
+            std::vector<uint8_t> buf;
+            std::vector<size_t> st;
+            if (!inflate_blocks(b, 4, buf, st)) return 1;
+            for (size_t o0 = 0; o0 < st[1] && !found; o0++) {
+                size_t o = o0, nx = 0;
+                int cnt = 0;
+                while (plausible_record(buf.data(), buf.size(), o, n_ref, &nx) && nx <= buf.size()) { o = nx; cnt++; }
+                // the chain must run to the end of what was inflated (the last record may stick out) through at least 4 records
+                if (cnt >= 4 && (o == buf.size() || (o + 4 <= buf.size() && plausible_record(buf.data(), buf.size(), o, n_ref, &nx)) || buf.size() - o < 36)) {
+                    lr[(size_t)k].on = true;
+                    lr[(size_t)k].coff_start = boff[b];
+                    lr[(size_t)k].first_rec = o0;
+                    found = true;
+                }
+            }
+        }
+        if (!found) return 1;
+        lr[(size_t)k - 1].coff_end = lr[(size_t)k].coff_start;
+        lr[(size_t)k - 1].end_rec = lr[(size_t)k].first_rec;
+    }
+    // devices: 0 .. N-1, or FADE_DEVICE_MAP (tests put two lanes on one device; RCCL wants distinct devices)
+    std::vector<int> devmap((size_t)n_lanes);
+    for (int d = 0; d < n_lanes; d++) devmap[(size_t)d] = d;
+    bool distinct = true;
+    if (const char *dm = getenv("FADE_DEVICE_MAP")) {
+        int d = 0;
+        for (const char *q = dm; *q && d < n_lanes; d++) {
+            devmap[(size_t)d] = atoi(q);
+            q = strchr(q, ',');
+            if (!q) break;
+            q++;
+        }
+        for (int a = 0; a < n_lanes; a++)
+            for (int b2 = a + 1; b2 < n_lanes; b2++)
+                if (devmap[(size_t)a] == devmap[(size_t)b2]) distinct = false;
+    }
+    const int threads_each = std::max(1, (o.threads > 0 ? o.threads : default_threads()) / n_lanes);
+    const char *tmpd = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+    char stem[512];
+    snprintf(stem, sizeof stem, "%s/fade_lanes_%d", tmpd, (int)getpid());
+    std::vector<std::string> outp((size_t)n_lanes), stp((size_t)n_lanes);
+    std::vector<pid_t> pids((size_t)n_lanes, -1);
+    const std::string idp = std::string(stem) + ".ncclid";
+    auto cleanup = [&] {
+        for (int k = 0; k < n_lanes; k++) { unlink(outp[(size_t)k].c_str()); unlink(stp[(size_t)k].c_str()); }
+        unlink(idp.c_str());
+    };
+    *fall_back = false;  // from here on the lanes own the run: a failure is reported, nothing is run twice
+    if (o.timing)
+        for (int k = 0; k < n_lanes; k++)
+            fprintf(stderr, "[timing] lane %d of %d: device %d, blocks from file offset %llu (first record at +%llu) to %llu (+%llu)\n", k, n_lanes, devmap[(size_t)k],
+                    (unsigned long long)lr[(size_t)k].coff_start, (unsigned long long)lr[(size_t)k].first_rec, (unsigned long long)lr[(size_t)k].coff_end,
+                    (unsigned long long)lr[(size_t)k].end_rec);
+    fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+    for (int k = 0; k < n_lanes; k++) {
+        outp[(size_t)k] = std::string(stem) + "." + std::to_string(k) + ".out";
+        stp[(size_t)k] = std::string(stem) + "." + std::to_string(k) + ".status";
+        char lane[256];
+        snprintf(lane, sizeof lane, "%d/%d:%d:%d:%llu:%llu:%llu:%llu", k, n_lanes, devmap[(size_t)k], distinct ? 1 : 0, (unsigned long long)lr[(size_t)k].coff_start,
+                 (unsigned long long)lr[(size_t)k].first_rec, (unsigned long long)lr[(size_t)k].coff_end, (unsigned long long)lr[(size_t)k].end_rec);
+        std::vector<std::string> envs;
+        for (char **e = environ; *e; e++)
+            if (strncmp(*e, "FADE_LANE", 9) != 0) envs.push_back(*e);
+        envs.push_back(std::string("FADE_LANE=") + lane);
+        envs.push_back("FADE_LANE_CL=" + cl);
+        envs.push_back("FADE_LANE_STATUS=" + stp[(size_t)k]);
+        envs.push_back("FADE_LANE_NCCL_ID=" + idp);
+        std::vector<char *> envp;
+        for (auto &e : envs) envp.push_back(const_cast<char *>(e.c_str()));
+        envp.push_back(nullptr);
+        std::vector<std::string> args = {"/proc/self/exe", "annotate", "-t", std::to_string(threads_each), "--min-length", std::to_string(o.floor_len),
+                                         "-w", std::to_string(o.window), "--batch", std::to_string(o.batch)};
+        if (o.bam) args.push_back("-b");
+        if (o.ubam) args.push_back("-u");
+        if (o.timing) args.push_back("--timing");
+        args.push_back(o.pos[1]);
+        args.push_back(o.pos[2]);
+        std::vector<char *> argv;
+        for (auto &a : args) argv.push_back(const_cast<char *>(a.c_str()));
+        argv.push_back(nullptr);
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_addopen(&fa, 1, outp[(size_t)k].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        const int rc = posix_spawn(&pids[(size_t)k], "/proc/self/exe", &fa, nullptr, argv.data(), envp.data());
+        posix_spawn_file_actions_destroy(&fa);
+        if (rc != 0) {
+            fprintf(stderr, "[E::fade annotate] cannot start lane %d: %s\n", k, strerror(rc));
+            pids[(size_t)k] = -1;
+        }
+    }
+    bool ok = true;
+    for (int k = 0; k < n_lanes; k++) {
+        if (pids[(size_t)k] < 0) { ok = false; continue; }
+        int st = 0;
+        if (waitpid(pids[(size_t)k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            fprintf(stderr, "[E::fade annotate] lane %d of %d failed\n", k, n_lanes);
+            ok = false;
+        }
+    }
+    int64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t n_oversize = 0;
+    for (int k = 0; k < n_lanes && ok; k++) {
+        FILE *s = fopen(stp[(size_t)k].c_str(), "r");
+        long long v[9], red[8];
+        if (!s || fscanf(s, "%lld %lld %lld %lld %lld %lld %lld %lld %lld", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) ok = false;
+        else {
+            for (int q = 0; q < 8; q++) totals[q] += v[q];
+            n_oversize += v[8];
+            // lanes on distinct devices have summed the counters among themselves (RCCL): every lane then holds the totals
+            if (distinct && fscanf(s, "%lld %lld %lld %lld %lld %lld %lld %lld", &red[0], &red[1], &red[2], &red[3], &red[4], &red[5], &red[6], &red[7]) == 8 && k == n_lanes - 1)
+                for (int q = 0; q < 8; q++)
+                    if (red[q] != totals[q]) { fprintf(stderr, "[E::fade annotate] the lanes' RCCL sum differs from the sum of their reports\n"); ok = false; break; }
+        }
+        if (s) fclose(s);
+    }
+    if (!ok) { cleanup(); return 1; }
+    // the outputs, lane after lane (lane 0 wrote the header), then the end-of-file block
+    std::vector<char> buf((size_t)8 << 20);
+    for (int k = 0; k < n_lanes; k++) {
+        FILE *in = fopen(outp[(size_t)k].c_str(), "rb");
+        if (!in) { cleanup(); return 1; }
+        size_t got;
+        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0)
+            if (fwrite(buf.data(), 1, got, stdout) != got) { fclose(in); cleanup(); fprintf(stderr, "[E::fade annotate] write error on the output stream\n"); return 1; }
+        fclose(in);
+    }
+    if (o.bam || o.ubam) fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout);
+    fflush(stdout);
+    cleanup();
+    if (n_oversize)
+        fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read or window beyond the kernels' limits\n", (long long)n_oversize);
+    if (o.stats) {
+        const double rc = (double)std::max<int64_t>(totals[0], 1);
+        fprintf(stderr, "read count:\t%lld\nClipped %%:\t%g\n%% With Supplementary alns:\t%g\nArtifact rate:\t%g\n"
+                        "%% With Supplementary alns and artifacts:\t%g\nArtifact rate left only:\t%g\nArtifact rate right only:\t%g\n",
+                (long long)totals[0], totals[1] / rc, totals[2] / rc, totals[4] / rc, totals[3] / rc, totals[6] / rc, totals[7] / rc);
+    }
+    return 0;
+}
+
 static int annotate_main(const std::string &cl, const Opts &o) {
     StageClock ck_total, ck_fasta, ck_upload, ck_read, ck_pack, ck_submit, ck_collect, ck_tags, ck_write;
     ck_total.start();
     if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (annotate begins)\n", since_process_start());
     if (o.timing) fprintf(stderr, "[timing] %d threads%s\n", o.threads > 0 ? o.threads : default_threads(), o.threads > 0 ? "" : " (default: affinity and cgroup quota)");
+    const LaneEnv lane = lane_env();  // set when this process is one lane of a `--gpus N` run (annotate_lanes_main)
     // anno.d:18-19 (htslib log format)
-    fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+    if (!lane.on) fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
     const int nthreads = o.threads > 0 ? o.threads : default_threads();
-    const int ngpu = std::max(1, o.gpus);
+    const int ngpu = lane.on ? 1 : std::max(1, o.gpus);
     std::vector<fadehip_ctx *> ctxs((size_t)ngpu, nullptr);
     std::vector<BlockPool> blocks((size_t)ngpu);
     struct CtxGuard {
@@ -517,6 +797,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
     Pool pool(nthreads);
     try {
         Reader reader(o.pos[1], &pool);   // anno.d:22 (every stage's parallel work runs on the one pool)
+        if (lane.on) reader.restrict_to(lane.range);  // this lane's records only
         // (the reader starts at once: the first batches inflate while the FASTA loads and the genome goes to HBM)
         // Stages: [reader: BGZF inflate / SAM parse] -> [this thread: pack into a pinned block, upload + run (both return
         // at once), fetch the oldest batch's results] -> [writer: tags, format, BGZF deflate].  Each stage has its own
@@ -557,7 +838,8 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         std::vector<int> devmap((size_t)ngpu);
         for (int d = 0; d < ngpu; d++) devmap[(size_t)d] = d;
         bool distinct_devices = true;
-        if (const char *dm = getenv("FADE_DEVICE_MAP")) {
+        if (lane.on) devmap[0] = lane.device;
+        else if (const char *dm = getenv("FADE_DEVICE_MAP")) {
             int d = 0;
             for (const char *q = dm; *q && d < ngpu; d++) {
                 devmap[(size_t)d] = atoi(q);
@@ -596,7 +878,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
         ck_fasta.stop();
         Header hdr = reader.header();     // anno.d:24
-        hdr.add_pg("fade-annotate", "fade", FADE_VERSION, cl);  // anno.d:25-32
+        hdr.add_pg("fade-annotate", "fade", FADE_VERSION, lane.on ? lane.cl : cl);  // anno.d:25-32
 
         // contigs of the BAM header, in tid order, must be present in the FASTA (fetchSequence by name, analysis.d:63)
         const Header &h = reader.header();
@@ -642,7 +924,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         // BAM output: the BGZF blocks are compressed on the device (FADE_BGZF_DEVICE=0 keeps them on the host pool)
         std::unique_ptr<DeviceBgzf> dev_codec;
         if (fmt == OutFmt::BAM && !(getenv("FADE_BGZF_DEVICE") && atoi(getenv("FADE_BGZF_DEVICE")) == 0)) dev_codec.reset(new DeviceBgzf(ctxs[0]));
-        Writer writer(stdout, fmt, hdr, &pool, dev_codec.get());
+        Writer writer(stdout, fmt, hdr, &pool, dev_codec.get(), !lane.on || lane.k == 0, !lane.on);
 
         StageThreads wstage;  // declared after the writer it uses: joined before the writer goes away
         wstage.unblock = [&] {
@@ -767,7 +1049,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         }
         if (failed) return 1;
         writer.close();
-        if (n_oversize)
+        if (n_oversize && !lane.on)
             fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read longer than %d bases or window longer than %d\n",
                     (long long)n_oversize, FADEHIP_MAX_LONG_QUERY, prm.max_ref_len);
         // the one collective of the path: sum the stats.d counters over the devices (RCCL over xGMI)
@@ -781,7 +1063,29 @@ static int annotate_main(const std::string &cl, const Opts &o) {
             for (int d = 0; d < ngpu; d++)
                 for (int k = 0; k < 8; k++) totals[k] += per_dev[(size_t)d][(size_t)k];
         }
-        if (o.stats) {  // stats.d:56-72 layout
+        if (lane.on) {
+            // the lane's report for the parent; lanes on distinct devices first sum their counters among themselves, the one
+            // collective of the path: ncclAllReduce over xGMI, one rank per process
+            long long red[8];
+            bool have_red = false;
+            if (lane.rccl && lane.n > 1) {
+                int64_t t[8];
+                std::copy(totals, totals + 8, t);
+                if (fadehip_stats_allreduce_rank(ctxs[0], lane.k, lane.n, lane.id_path.c_str(), t, 8)) return die(ctxs[0], "stats all-reduce (lanes)");
+                for (int q = 0; q < 8; q++) red[q] = (long long)t[q];
+                have_red = true;
+            }
+            FILE *sf = fopen(lane.status_path.c_str(), "w");
+            if (!sf) { fprintf(stderr, "[E::fade annotate] cannot write %s\n", lane.status_path.c_str()); return 1; }
+            for (int q = 0; q < 8; q++) fprintf(sf, "%lld ", (long long)totals[q]);
+            fprintf(sf, "%lld\n", (long long)n_oversize);
+            if (have_red) {
+                for (int q = 0; q < 8; q++) fprintf(sf, "%lld ", red[q]);
+                fprintf(sf, "\n");
+            }
+            fclose(sf);
+        }
+        if (o.stats && !lane.on) {  // stats.d:56-72 layout
             const double rc = (double)std::max<int64_t>(totals[0], 1);
             fprintf(stderr, "read count:\t%lld\nClipped %%:\t%g\n%% With Supplementary alns:\t%g\nArtifact rate:\t%g\n"
                             "%% With Supplementary alns and artifacts:\t%g\nArtifact rate left only:\t%g\nArtifact rate right only:\t%g\n",
@@ -1244,6 +1548,13 @@ int main(int argc, char **argv) {
         if (o.bam && o.ubam) {  // app.d:94-99
             fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");
             return 1;
+        }
+        // --gpus N on a BAM file: one process per GPU, each on its own share of the input (annotate_lanes_main); input that
+        // cannot be cut (a pipe, SAM text, a small file) is read by one process that deals batches to the N devices
+        if (o.gpus > 1 && !lane_env().on && !(getenv("FADE_LANES") && atoi(getenv("FADE_LANES")) == 0)) {
+            bool fall_back = true;
+            const int lrc = annotate_lanes_main(cl, o, &fall_back);
+            if (lrc == 0 || !fall_back) return lrc;
         }
         const int rc = annotate_main(cl, o);
         if (o.timing) {

@@ -734,6 +734,11 @@ inline void bgzf_compress_block(const uint8_t *src, size_t n, int level, std::ve
 class ByteSource {  // buffered FILE* with peek
 public:
     explicit ByteSource(FILE *f) : f_(f), buf_(1 << 20) {}
+    // continue at an absolute file offset (a seekable file; what was buffered is dropped)
+    void seek(uint64_t off) {
+        if (fseeko(f_, (off_t)off, SEEK_SET) != 0) throw std::runtime_error("cannot seek in the input (lanes need a regular file)");
+        beg_ = end_ = 0;
+    }
     size_t peek(uint8_t *dst, size_t n) {
         fill(n);
         const size_t k = std::min(n, end_ - beg_);
@@ -897,6 +902,16 @@ inline ReadProf &read_prof() {
 
 // Inflates BGZF blocks in parallel batches and serves the uncompressed byte stream, either copied out (read) or
 // in place (data / avail / consume / more) so that the BAM reader can frame records without a per-record copy loop.
+// One lane's share of a BAM file (`fade annotate --gpus N`: N readers on disjoint BGZF virtual-offset ranges).
+// A lane starts at the record at (coff_start, first_rec) — file offset of a BGZF block, offset in that block's inflated
+// bytes — and ends exactly in front of the record at (coff_end, end_rec), where the next lane starts; coff_end = 0: at the
+// end of the file.  The record chain of a lane must land exactly on its end: a lane whose neighbour guessed its start wrong
+// fails with "truncated BAM record" (the driver then falls back to one lane), it never emits a damaged record.
+struct LaneRange {
+    bool on = false;
+    uint64_t coff_start = 0, first_rec = 0, coff_end = 0, end_rec = 0;
+};
+
 class BgzfIn {
 public:
     BgzfIn(ByteSource *src, Pool *pool) : src_(src), pool_(pool) {}
@@ -1004,11 +1019,37 @@ public:
         }, CPU_INFLATE);
         read_prof().inflate += ReadProf::now() - t0;
         if (bad_) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
+        // a lane's last block is served up to the next lane's first record only
+        if (trunc_blk_ != (size_t)-1 && trunc_blk_ >= first && trunc_blk_ < last) {
+            const size_t j = trunc_blk_ - first;
+            if (lim_rec_ > isz[j]) throw std::runtime_error("lane range ends beyond its last block");
+            dst.resize(base + ooff[j] + (size_t)lim_rec_);
+        }
         return true;
     }
 
     ~BgzfIn() {
         if (pending_.valid()) pending_.wait();
+    }
+    // From here on serve only the blocks of a lane's range (the header has been read from the start of the file): blocks
+    // at file offsets [coff_start, coff_end), plus the first end_rec inflated bytes of the block at coff_end.
+    void restrict(uint64_t coff_start, uint64_t coff_end, uint64_t end_rec) {
+        if (pending_.valid()) pending_.wait();
+        src_->seek(coff_start);
+        cbuf_[0].clear();
+        cbuf_[1].clear();
+        cbase_[0] = cbase_[1] = coff_start;
+        out_.clear();
+        pos_ = 0;
+        cur_ = 0;
+        primed_ = false;
+        eof_ = false;
+        offs_.clear();
+        blk_next_ = 0;
+        lim_coff_ = coff_end;
+        lim_rec_ = end_rec;
+        limited_ = coff_end != 0;
+        trunc_blk_ = (size_t)-1;
     }
 
 private:
@@ -1032,9 +1073,13 @@ private:
             read_prof().wait_io += t1 - t0;
             offs_.clear();
             blk_next_ = 0;
+            trunc_blk_ = (size_t)-1;
             size_t o = 0;
             const size_t have = comp_.size();
+            const uint64_t gbase = cbase_[cur_];  // file offset of this buffer's first byte
+            bool lane_done = false;
             while (o + 18 <= have) {
+                if (limited_ && (gbase + o > lim_coff_ || (gbase + o == lim_coff_ && lim_rec_ == 0))) { lane_done = true; break; }
                 const uint8_t *h = comp_.data() + o;
                 if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF block");
                 uint16_t xlen;
@@ -1048,7 +1093,22 @@ private:
                 if (bsize < 12 + (size_t)xlen + 8) throw std::runtime_error("corrupt BGZF block (BSIZE smaller than its own header and trailer)");
                 if (o + bsize > have) break;
                 offs_.push_back({o, bsize, (size_t)xlen});
+                if (limited_ && gbase + o == lim_coff_) {  // the block the next lane starts in: its first lim_rec_ bytes, then the lane is over
+                    trunc_blk_ = offs_.size() - 1;
+                    o += bsize;
+                    lane_done = true;
+                    break;
+                }
                 o += bsize;
+            }
+            if (lane_done) {
+                if (pending_.valid()) pending_.wait();  // (none is in flight here: the fetch of the next gulp starts below)
+                eof_ = true;
+                cur_ ^= 1;
+                cbuf_[cur_].clear();
+                read_prof().scan += ReadProf::now() - t1;
+                if (!offs_.empty()) return true;
+                return false;
             }
             if (offs_.empty()) {
                 if (have && eof_) throw std::runtime_error("truncated BGZF block");
@@ -1056,6 +1116,7 @@ private:
             }
             // the incomplete block at the end opens the other buffer, and the next gulp is read behind it meanwhile
             RawBuf &next = cbuf_[cur_ ^ 1];
+            cbase_[cur_ ^ 1] = gbase + o;
             next.resize(have - o);
             if (have - o) memcpy(next.data(), comp_.data() + o, have - o);
             if (!eof_) pending_ = std::async(std::launch::async, [this, &next] { fetch(next); });
@@ -1075,6 +1136,10 @@ private:
     ByteSource *src_;
     Pool *pool_;
     RawBuf cbuf_[2], out_;
+    uint64_t cbase_[2] = {0, 0};  // file offset of each compressed buffer's first byte
+    bool limited_ = false;        // restrict(): the lane's end
+    uint64_t lim_coff_ = 0, lim_rec_ = 0;
+    size_t trunc_blk_ = (size_t)-1;  // index in offs_ of the block served only up to lim_rec_
     int cur_ = 0;
     bool primed_ = false;
     std::atomic<bool> eof_{false};
@@ -1173,6 +1238,11 @@ public:
             if (!bgzf_->inflate_append(blk.buf, want)) {
                 if (pos < blk.buf.size()) throw std::runtime_error("truncated BAM record");
                 break;
+            }
+            if (skip_front_) {  // a lane's first block: what lies in front of its first record belongs to the lane before
+                if (skip_front_ > blk.buf.size()) throw std::runtime_error("lane range starts beyond its first block");
+                blk.buf.drop_front(skip_front_);
+                skip_front_ = 0;
             }
         }
         // what follows the last framed record belongs to the next block
@@ -1360,6 +1430,17 @@ private:
         }
         hdr_.parse_sq_from_text();
     }
+public:
+    // Serve only a lane's records from here on (BAM input from a regular file; the header has been read).
+    size_t bam_header_bytes() const { return hdr_bytes_; }
+    void restrict_to(const LaneRange &r) {
+        if (!bam_) throw std::runtime_error("lanes need BAM input");
+        carry_.clear();
+        bgzf_->restrict(r.coff_start, r.coff_end, r.end_rec);  // (lane 0 too: it re-enters at the block its first record starts in)
+        skip_front_ = (size_t)r.first_rec;
+    }
+
+private:
     void read_bam_header() {
         uint8_t m[4];
         if (bgzf_->read(m, 4) != 4 || memcmp(m, "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file");
@@ -1370,6 +1451,7 @@ private:
         while (!hdr_.text.empty() && hdr_.text.back() == '\0') hdr_.text.pop_back();
         int32_t nref;
         bgzf_->read((uint8_t *)&nref, 4);
+        hdr_bytes_ = 12 + (size_t)lt;
         for (int k = 0; k < nref; k++) {
             int32_t ln;
             bgzf_->read((uint8_t *)&ln, 4);
@@ -1380,8 +1462,10 @@ private:
             bgzf_->read((uint8_t *)&l, 4);
             hdr_.names.push_back(nm);
             hdr_.lens.push_back(l);
+            hdr_bytes_ += 8 + (size_t)ln;
         }
     }
+    size_t hdr_bytes_ = 0;  // inflated bytes of the BAM header (the first record starts behind them)
     Pool *pool_;
     FILE *f_ = nullptr;
     std::unique_ptr<ByteSource> src_;
@@ -1390,6 +1474,7 @@ private:
     Header hdr_;
     std::atomic<bool> bad_layout_{false};
     RawBuf carry_;          // read_block: inflated bytes behind the last framed record
+    size_t skip_front_ = 0; // restrict_to(): inflated bytes in front of the lane's first record, dropped from the first block read
     bool block_mode_ = false;
     size_t last_block_bytes_ = 0, last_block_recs_ = 0;  // inflated size / records of the previous read_block (the next one reserves as much)
     RawBuf text_;           // SAM text not yet handed out (complete lines from text_pos_ on)
@@ -1472,8 +1557,10 @@ struct BgzfDevice {
 
 class Writer {
 public:
-    Writer(FILE *f, OutFmt fmt, const Header &h, Pool *pool, BgzfDevice *dev = nullptr)
-        : f_(f), fmt_(fmt), hdr_(h), pool_(pool), dev_(fmt == OutFmt::BAM ? dev : nullptr), io_(f) {
+    // with_header / with_eof = false: a lane of a multi-lane run writes records only (the driver puts the pieces together)
+    Writer(FILE *f, OutFmt fmt, const Header &h, Pool *pool, BgzfDevice *dev = nullptr, bool with_header = true, bool with_eof = true)
+        : f_(f), fmt_(fmt), hdr_(h), pool_(pool), dev_(fmt == OutFmt::BAM ? dev : nullptr), with_eof_(with_eof), io_(f) {
+        if (!with_header) return;
         if (fmt_ == OutFmt::SAM) {
             std::vector<std::string> one(1, hdr_.text);
             io_.put(std::move(one));
@@ -1600,8 +1687,10 @@ public:
             flush_blocks(true);
             if (dev_)
                 for (int k = 0; k < dev_->lanes(); k++) collect_lane((int)((dev_seq_ + (size_t)k) % (size_t)dev_->lanes()));  // oldest first
-            std::vector<std::vector<uint8_t>> eof(1, std::vector<uint8_t>(BGZF_EOF, BGZF_EOF + sizeof BGZF_EOF));
-            io_.put(std::move(eof));
+            if (with_eof_) {
+                std::vector<std::vector<uint8_t>> eof(1, std::vector<uint8_t>(BGZF_EOF, BGZF_EOF + sizeof BGZF_EOF));
+                io_.put(std::move(eof));
+            }
         }
         io_.finish();
         if (io_.failed()) throw std::runtime_error("write error on the output stream");
@@ -1684,6 +1773,7 @@ private:
     Header hdr_;
     Pool *pool_;
     BgzfDevice *dev_;
+    bool with_eof_ = true;
     std::vector<bool> dev_busy_;
     size_t dev_seq_ = 0;  // flushes handed to the device so far
     RawBuf raw_;

@@ -264,6 +264,12 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
  * per device.  counters is [n_ctx][count] in, every row holds the sum on return. */
 int fadehip_stats_allreduce(fadehip_ctx *const *ctxs, int n_ctx, int64_t *counters, int count);
 
+/* The same sum with one PROCESS per GPU (the lanes of `fade annotate --gpus N`, bench.py's ranks use torch.distributed for
+ * it): rank 0 makes the ncclUniqueId and leaves it in the file id_path (written under another name, then renamed), the
+ * other ranks wait for the file (up to a minute); ncclCommInitRank, one ncclAllReduce(int64, sum), the communicator is
+ * destroyed again.  counters[count] in, the sums out. */
+int fadehip_stats_allreduce_rank(fadehip_ctx *ctx, int rank, int n_ranks, const char *id_path, int64_t *counters, int count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,45 @@ def test_cli_reads_standard_input():
     assert piped_bam.returncode == 0, piped_bam.stderr.decode()
     _, recs = samutil.parse_sam(piped_bam.stdout.decode())
     _check_records(recs, exp)
+
+
+@pytest.mark.parametrize("fmt", ["-b", "-u", ""])
+def test_cli_lanes_one_process_per_gpu_on_disjoint_ranges(tmp_path, fmt):
+    """`fade annotate --gpus 2` on a BAM file: two lanes, each a process with its own reader (a BGZF virtual-offset range
+    of the input), device context and writer; the parent cuts the file and concatenates the lanes' BGZF blocks.  Both lanes
+    sit on this box's one GPU (FADE_DEVICE_MAP=0,0: RCCL wants distinct devices, the parent sums the stats).  The records,
+    their order and the stats must be those of the one-process run; a lane's record chain has to end exactly where the
+    next lane's guessed start is, so a wrong cut cannot go unnoticed."""
+    import gzip
+    from fade_amd import synth
+    cfg, g, b = synth.make_config("C5", 30000, contig_len=400_000)
+    names = ["read%d" % (i // 2) for i in range(len(b["pos"]))]
+    b["qname"] = names
+    sam = tmp_path / "in.sam"
+    fa = tmp_path / "ref.fa"
+    sam.write_text(samutil.batch_to_sam(b, g.names, [int(x) for x in g.lengths], names))
+    fa.write_bytes(g.fasta_bytes())
+    bam = tmp_path / "in.bam"
+    p = _run(["out", "-b", str(sam)])  # (no rs tags yet: `out` passes every record through; a BAM of ~130 BGZF blocks)
+    assert p.returncode == 0, p.stderr.decode()
+    bam.write_bytes(p.stdout)
+    base = ["annotate", "--stats", "--timing", "--batch", "4096", "-w", "100"] + ([fmt] if fmt else [])
+    one = _run(base + [str(bam), str(fa)])
+    two = _run(base + ["--gpus", "2", str(bam), str(fa)], env=dict(os.environ, FADE_DEVICE_MAP="0,0"))
+    three = _run(base + ["--gpus", "3", str(bam), str(fa)], env=dict(os.environ, FADE_DEVICE_MAP="0,0,0"))
+    assert one.returncode == 0 and two.returncode == 0 and three.returncode == 0, one.stderr.decode()[-500:] + two.stderr.decode()[-1500:]
+    assert b"lane 1 of 2" in two.stderr and b"lane 2 of 3" in three.stderr and b"lane 1 of" not in one.stderr
+
+    def records(out):
+        if fmt == "":
+            return [l for l in out.decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
+        raw = gzip.decompress(out)
+        l_text = int.from_bytes(raw[4:8], "little")
+        text = raw[8:8 + l_text].decode()
+        return [l for l in text.splitlines() if not l.startswith("@PG\tID:fade-annotate")], raw[8 + l_text:]
+
+    assert records(one.stdout) == records(two.stdout) == records(three.stdout)
+    stats = lambda err: [l for l in err.decode().split("read count:")[1].splitlines() if not l.startswith("[timing]") and l][:7]
+    assert stats(one.stderr) == stats(two.stderr) == stats(three.stderr) and stats(one.stderr)[0] == "\t30000"
+    if fmt:
+        assert two.stdout.endswith(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
