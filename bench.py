@@ -197,6 +197,8 @@ def main():
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
 
     cfg = synth.config(args.config)
+    if cfg.get("p_clip_indel"):
+        args.synth = "numpy"  # (C6's indels in planted clips exist in fade_amd/synth.py only)
     t_setup = {}
     t0 = time.perf_counter()
     if args.synth == "native":

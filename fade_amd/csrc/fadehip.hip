@@ -322,41 +322,48 @@ int record(fadehip_ctx *ctx, Slot &s, int *idx, hipStream_t on = nullptr) {
 }
 
 template <int C>
-int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size_t lds, hipStream_t st, bool packed) {
+int launch_forward_c(fadehip_ctx *ctx, int cls, const SwArgs &a, int quads, size_t lds, hipStream_t st, bool packed, bool longw) {
     if constexpr (C >= NUM_CLASSES) {
         return set_err(ctx, FADEHIP_E_INVALID, "bad class %d", cls);
     } else {
         if (cls == C) {
             constexpr int R = class_rows(C);
-            if (packed)
+            if (packed && longw)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 0, true>), dim3(quads), dim3(64), lds, st, a);
+            else if (packed)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_pk_kernel<R, 0>), dim3(quads), dim3(64), lds, st, a);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward_kernel<R>), dim3(quads), dim3(64), lds, st, a);
             HIPCHK(ctx, hipGetLastError());
             return 0;
         }
-        return launch_forward_c<C + 1>(ctx, cls, a, quads, lds, st, packed);
+        return launch_forward_c<C + 1>(ctx, cls, a, quads, lds, st, packed, longw);
     }
 }
 
 // mode 1: score pass, 2: traced re-computation (default rules), 3: traced re-computation with rule switches
 template <int C>
-const void *pk_kernel_ptr(int cls, int mode) {
+const void *pk_kernel_ptr(int cls, int mode, bool longw) {
     if constexpr (C >= NUM_CLASSES) {
         return nullptr;
     } else {
         if (cls == C) {
             constexpr int R = class_rows(C);
+            if (longw) {  // windows beyond one staged chunk (CH_COLS columns) in this launch
+                if (mode == 1) return (const void *)sw_pk_kernel<R, 1, true>;
+                if (mode == 2) return (const void *)sw_pk_kernel<R, 2, true>;
+                return (const void *)sw_pk_kernel<R, 3, true>;
+            }
             if (mode == 1) return (const void *)sw_pk_kernel<R, 1>;
             if (mode == 2) return (const void *)sw_pk_kernel<R, 2>;
             return (const void *)sw_pk_kernel<R, 3>;
         }
-        return pk_kernel_ptr<C + 1>(cls, mode);
+        return pk_kernel_ptr<C + 1>(cls, mode, longw);
     }
 }
 
-int launch_pk_mode(fadehip_ctx *ctx, int cls, int mode, const SwArgs &a, int waves, size_t lds, hipStream_t st) {
-    const void *fn = pk_kernel_ptr<0>(cls, mode);
+int launch_pk_mode(fadehip_ctx *ctx, int cls, int mode, const SwArgs &a, int waves, size_t lds, hipStream_t st, bool longw) {
+    const void *fn = pk_kernel_ptr<0>(cls, mode, longw);
     if (!fn) return set_err(ctx, FADEHIP_E_INVALID, "bad class %d", cls);
     SwArgs copy = a;
     void *args[] = {&copy};
@@ -365,13 +372,13 @@ int launch_pk_mode(fadehip_ctx *ctx, int cls, int mode, const SwArgs &a, int wav
 }
 
 // waves of a pass-2 kernel the device holds at once: the size of its persistent launch
-int resident_waves(fadehip_ctx *ctx, int cls, int mode, size_t lds) {
-    const uint64_t key = ((uint64_t)cls << 40) | ((uint64_t)mode << 32) | (uint64_t)lds;
+int resident_waves(fadehip_ctx *ctx, int cls, int mode, size_t lds, bool longw) {
+    const uint64_t key = ((uint64_t)cls << 40) | ((uint64_t)mode << 32) | ((uint64_t)longw << 36) | (uint64_t)lds;
     std::lock_guard<std::mutex> l(ctx->resident_mu);
     auto it = ctx->resident.find(key);
     if (it != ctx->resident.end()) return it->second;
     int per_cu = 0;
-    const void *fn = pk_kernel_ptr<0>(cls, mode);
+    const void *fn = pk_kernel_ptr<0>(cls, mode, longw);
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
     const int w = per_cu * std::max(ctx->cu_count, 1);
     ctx->resident[key] = w;
@@ -402,6 +409,7 @@ struct TwoPassPlan {
     int n_blocks1 = 0, ref_stride1 = 0;
     size_t lds1 = 0;
     int mode2 = 2;
+    bool longw = false;  // some window of the launch may be longer than one staged chunk
     int64_t chunk_oct = 1;
     int total_oct = 0;
     uint64_t wave_stride = 0;
@@ -419,10 +427,9 @@ int plan_two_pass(fadehip_ctx *ctx, const Slot &s, const ClassRun &c, TwoPassPla
     p.n_ck = s.use_ckpt ? (max_lr + 15 + CK_COLS - 1) / CK_COLS : 0;
     p.ck_stride = (uint64_t)p.n_ck * ck_dwords(R) * 64;  // dwords per pass-1 octet
     p.n_blocks1 = (max_lr + 15 + 3) / 4;
-    p.ref_stride1 = (((p.n_blocks1 * 4) * 2 + 15) / 16) * 16;
+    // LDS per 16-lane group: the window's columns (2 bytes each), a chunk of CH_COLS at a time when it is longer than that
+    p.ref_stride1 = std::min((((p.n_blocks1 * 4) * 2 + 15) / 16) * 16, (CH_COLS + 16) * 2);
     p.lds1 = (size_t)p.ref_stride1 * 4;
-    if (p.lds1 > 64 * 1024)
-        return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, p.lds1);
     const bool alt_rules = (ctx->sc.rules & (FADEHIP_RULE_HDIR_DIAG_F_E | FADEHIP_RULE_GAP_TIE_EXTENDS)) !=
                            (FADEHIP_RULE_HDIR_DIAG_F_E | FADEHIP_RULE_GAP_TIE_EXTENDS);
     p.mode2 = alt_rules ? 3 : 2;
@@ -436,7 +443,8 @@ int plan_two_pass(fadehip_ctx *ctx, const Slot &s, const ClassRun &c, TwoPassPla
     // any batch has run, a moderate guess.  Few waves cost time only when candidates abound; many cost time always,
     // because each must find a wave slot next to the other slots' score passes before it can see that nothing is left.
     p.wave_stride = (uint64_t)p.n_blocks1 * R * 64;  // dwords
-    const int resident = resident_waves(ctx, cls, p.mode2, p.lds1);
+    p.longw = p.n_blocks1 > CH_BLOCKS;
+    const int resident = resident_waves(ctx, cls, p.mode2, p.lds1, p.longw);
     const int bound_waves = (int)std::min<int64_t>(p.chunk_oct + NUM_BUCKETS, resident);
     int p2_waves = s.p2_last_octs[cls] >= 0 ? std::min(2 * s.p2_last_octs[cls] + 64, bound_waves) : std::min(1024, bound_waves);
     if (ctx->p2_waves_fixed > 0) p2_waves = std::min(ctx->p2_waves_fixed, bound_waves);
@@ -518,7 +526,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
             HIPCHK(ctx, hipStreamWaitEvent(sst, s.ev[ef], 0));
         }
         if (c.timed && (rc = record(ctx, s, &e0, sst))) return rc;
-        if ((rc = launch_pk_mode(ctx, cls, 1, a, octs, lds1, sst))) return rc;
+        if ((rc = launch_pk_mode(ctx, cls, 1, a, octs, lds1, sst, p.longw))) return rc;
         if ((c.timed || sst != st) && (rc = record(ctx, s, &e1, sst))) return rc;
         if (sst != st) HIPCHK(ctx, hipStreamWaitEvent(st, s.ev[e1], 0));
         // pass 2 + tracebacks + re-traced paths: one persistent launch
@@ -543,7 +551,7 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
         b2.gate = c.gate;
         b2.early_out = (c.gate && c.meta && !ctx->prm.trace_all) ? 1 : 0;
         b2.rerun_total = &s.d_plan()->rerun_total;
-        if ((rc = launch_pk_mode(ctx, cls, mode2, b2, std::min(p2_waves, octs + NUM_BUCKETS), lds1, st))) return rc;
+        if ((rc = launch_pk_mode(ctx, cls, mode2, b2, std::min(p2_waves, octs + NUM_BUCKETS), lds1, st, p.longw))) return rc;
         if (c.timed) {
             if ((rc = record(ctx, s, &e2))) return rc;
             s.fwd_spans.push_back({e0, e1});
@@ -562,7 +570,7 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
     const int n_blocks = (max_lr + 15 + 3) / 4;
     // dwords of trace per wave: 4 bits per cell slot either way
     const uint64_t quad_stride = (uint64_t)n_blocks * (packed ? R : R / 2) * 64;
-    const int ref_stride = (((n_blocks * 4) * (packed ? 2 : 1) + 15) / 16) * 16;
+    const int ref_stride = packed ? std::min((((n_blocks * 4) * 2 + 15) / 16) * 16, (CH_COLS + 16) * 2) : (((n_blocks * 4) + 15) / 16) * 16;
     const size_t lds = (size_t)ref_stride * 4;
     if (lds > 64 * 1024)
         return set_err(ctx, FADEHIP_E_UNSUPPORTED, "reference window of %d bases needs %zu B LDS per wave (max 64 KiB)", max_lr, lds);
@@ -591,7 +599,7 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
         a.sc = ctx->sc;
         int e0 = -1, e1 = -1, e2 = -1;
         if (c.timed && (rc = record(ctx, s, &e0))) return rc;
-        rc = launch_forward_c<0>(ctx, cls, a, quads, lds, st, packed);
+        rc = launch_forward_c<0>(ctx, cls, a, quads, lds, st, packed, n_blocks > CH_BLOCKS);
         if (rc) return rc;
         if (c.timed && (rc = record(ctx, s, &e1))) return rc;
         TbArgs t;

@@ -96,9 +96,11 @@ __host__ __device__ inline int class_of_len(int lq) {
 // take sw_long_kernel (a thread per alignment; rare in short-read libraries, e.g. merged pairs).
 constexpr int LONG_LIST = NUM_CLASSES, NUM_LISTS = NUM_CLASSES + 1;
 constexpr int MAX_LONG_QUERY = 1 << 15;
-// The wave kernels stage a group's window in LDS, 2 bytes per column for 4 groups inside the 64 KiB a workgroup may
-// ask for: windows longer than this also take sw_long_kernel.
-constexpr int WAVE_MAX_WINDOW = 8000;
+// The wave kernels stage a group's window in LDS 2,048 columns at a time (CH_COLS; 2 bytes per column): a window of any
+// length streams through.  What bounds it is the end-cell key: the score pass keeps the sweep step of a row pair's best
+// cell as 2 t + 1 in 16 bits, so a sweep has at most 32,767 steps.  Windows beyond WAVE_MAX_WINDOW take sw_long_kernel.
+constexpr int WAVE_MAX_WINDOW = 32000;
+constexpr int CH_BLOCKS = 512, CH_COLS = 4 * CH_BLOCKS;  // blocks (of 4 sweep steps = 4 columns at lane 0) per staged chunk
 __host__ __device__ inline int list_of_len(int lq, int64_t lr = 0) {
     const int c = class_of_len(lq);
     if (c >= 0) return lr > WAVE_MAX_WINDOW ? LONG_LIST : c;
@@ -1167,7 +1169,10 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 // 3 or 4 waves per SIMD (40 / 85 spilled registers) changed nothing measurable, it is left alone.
 __host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return MODE != 1 ? 1 : (R <= 10 ? 4 : (R <= 16 ? 3 : 2)); }
 
-template <int R, int MODE>
+// LONGW: the launch may hold windows longer than one staged chunk (CH_COLS columns); the sweep then re-stages at chunk
+// boundaries.  A kernel of its own, so that the ordinary launch keeps its registers (the chunk loop cost the 150-base
+// score pass 29 spilled registers when it was a run-time branch).
+template <int R, int MODE, bool LONGW = false>
 __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs a) {
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x;
@@ -1273,24 +1278,30 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // columns into the slack the host adds to ref_stride).
     uint16_t *lref = reinterpret_cast<uint16_t *>(lds + g * a.ref_stride);
     const int n_cols = n_blocks * 4;
-    for (int k0 = lig * 8; k0 < n_cols; k0 += 128) {
-        Nib8 na, nb;
-        na.word = nb.word = 0; na.byte0 = nb.byte0 = 0;
-        const uint64_t ra0 = wa.r_base + (uint64_t)k0, rb0 = wb.r_base + (uint64_t)k0;
-        if (k0 < lrA) na = load_nib8(a.r_nib, ra0);
-        if (k0 < lrB) nb = load_nib8(a.r_nib, rb0);
-        uint32_t o[4];
+    // columns [c0, c0 + CH_COLS + 8) of the window go to lref[0 ..): a chunk and the first columns of the next (the sweep
+    // fetches a block's class words one block ahead)
+    auto stage = [&](const int c0) __attribute__((always_inline)) {
+        const int c1 = min(n_cols, c0 + CH_COLS + 8);
+        for (int k0 = c0 + lig * 8; k0 < c1; k0 += 128) {
+            Nib8 na, nb;
+            na.word = nb.word = 0; na.byte0 = nb.byte0 = 0;
+            const uint64_t ra0 = wa.r_base + (uint64_t)k0, rb0 = wb.r_base + (uint64_t)k0;
+            if (k0 < lrA) na = load_nib8(a.r_nib, ra0);
+            if (k0 < lrB) nb = load_nib8(a.r_nib, rb0);
+            uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t ca = PAD_CLASS, cb = PAD_CLASS;
-            if (k0 + j < lrA) ca = lut4(CLASS_LUT, nib8_at(na, ra0 + (uint32_t)j));
-            if (k0 + j < lrB) cb = lut4(CLASS_LUT, nib8_at(nb, rb0 + (uint32_t)j));
-            const uint32_t e = (7u * ca + cb) * 16u;
-            if (j & 1) o[j >> 1] |= e << 16;
-            else o[j >> 1] = e;
+            for (int j = 0; j < 8; j++) {
+                uint32_t ca = PAD_CLASS, cb = PAD_CLASS;
+                if (k0 + j < lrA) ca = lut4(CLASS_LUT, nib8_at(na, ra0 + (uint32_t)j));
+                if (k0 + j < lrB) cb = lut4(CLASS_LUT, nib8_at(nb, rb0 + (uint32_t)j));
+                const uint32_t e = (7u * ca + cb) * 16u;
+                if (j & 1) o[j >> 1] |= e << 16;
+                else o[j >> 1] = e;
+            }
+            *reinterpret_cast<uint4 *>(lref + (k0 - c0)) = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<uint4 *>(lref + k0) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
+    };
+    stage(0);
     // query classes per row (A | B << 16); `special` = some real row is N or a wildcard (class >= 4).  A lane's R rows
     // are R consecutive bases of the (reverse-complemented) query: eight per pair of aligned dwords.
     uint32_t qcls[R];
@@ -1424,15 +1435,26 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // before: +0.5-1 % in tools/stream_probe.py, within noise in bench.py, no register more.  The traced passes have no
     // registers to spare and are not issue-bound.)
     uint64_t rw_next = *reinterpret_cast<const uint64_t *>(lref);
-    for (int blk0 = 0; blk0 < n_blocks; blk0 += GROUP) {
-    const int blk_end = (MODE == 1) ? min(n_blocks, blk0 + GROUP) : n_blocks;
+    // a window longer than a chunk streams through LDS: at every chunk boundary the next CH_COLS (+ 8) columns replace the
+    // last (a wave is a workgroup: the barrier costs nothing, and windows of up to 2,044 columns never get here)
+    for (int cb = 0; cb < (LONGW ? n_blocks : 1); cb += CH_BLOCKS) {
+    if constexpr (LONGW) {
+        if (cb) {
+            __syncthreads();
+            stage(cb * 4);
+            __syncthreads();
+        }
+    }
+    const int cb_end = LONGW ? min(n_blocks, cb + CH_BLOCKS) : n_blocks;
+    for (int blk0 = cb; blk0 < cb_end; blk0 += GROUP) {
+    const int blk_end = (MODE == 1) ? min(cb_end, blk0 + GROUP) : cb_end;
     for (int blk = blk0; blk < blk_end; blk++) {
         uint64_t rw;
         if constexpr (MODE == 1) {
             rw = rw_next;
-            rw_next = *reinterpret_cast<const uint64_t *>(lref + min(blk + 1, n_blocks - 1) * 4);
+            rw_next = *reinterpret_cast<const uint64_t *>(lref + (min(blk + 1, n_blocks - 1) - cb) * 4);  // (up to one block into the next chunk's columns)
         } else {
-            rw = *reinterpret_cast<const uint64_t *>(lref + blk * 4);
+            rw = *reinterpret_cast<const uint64_t *>(lref + (blk - cb) * 4);
         }
         uint32_t acc[R];
         if constexpr (MODE != 1) {
@@ -1563,6 +1585,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         }
     }
     }
+    }  // chunks
     };  // sweep
     if (__any(special)) sweep(std::false_type{});
     else sweep(std::true_type{});

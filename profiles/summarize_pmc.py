@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_C2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_C2"
 config = sys.argv[2] if len(sys.argv) > 2 else "C2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
@@ -35,7 +35,7 @@ def load(d):
 calib_bytes = 2 << 30
 wcal = [v["WRITE_SIZE"] for k, v in cw.items() if "calib_write" in k][0] * 1024 / calib_bytes
 fcal = [v["FETCH_SIZE"] for k, v in cf.items() if "calib_read" in k][0] * 1024 / calib_bytes
-out = {"source": "rocprofv3 --pmc (separate passes) on `python3 bench.py --config %s --steps 2 --warmup 1 --no-cpu --slots 1`, MI355X; "
+out = {"source": "rocprofv3 --pmc (separate passes) on `python3 bench.py --config %s --steps 2 --warmup 1 --no-cpu --no-e2e --slots 1`, MI355X; "
                  "per-launch averages over all launches of the run" % config,
        "workload": config,
        "units": "FETCH_SIZE/WRITE_SIZE are KiB; corrected as MI355X_MICROARCH.md §HBM prescribes and as calibrated here",

@@ -145,19 +145,55 @@ def test_sw_scoring_outside_the_profile_range_is_rejected():
 
 
 def test_sw_long_windows(oracle):
-    """Windows longer than the 8000 columns the wave kernels can stage in LDS take the thread-per-alignment kernel."""
+    """Windows stream through the wave kernels' LDS a chunk of 2,048 columns at a time (up to 32,000 columns: the end-cell
+    key's 16 bits); beyond that the thread-per-alignment kernel serves them.  Lengths around every boundary: one chunk
+    (2,044 columns with the sweep's 15 steps of skew), the old 8,000-column limit, 32,000."""
     import fade_amd
-    c = fade_amd.Context(device=0, max_ref_len=20000)
+    c = fade_amd.Context(device=0, max_ref_len=40000)
     try:
         rng = np.random.default_rng(77)
         qs, rs = [], []
-        for lr in (7990, 8000, 8001, 12000, 20000):
-            for lq, kind in ((50, "planted"), (150, "related"), (600, "random")):
+        for lr in (2030, 2044, 2045, 2060, 4090, 4100, 7990, 8001, 12000, 20000, 31990, 32000, 32001, 36000):
+            for lq, kind in ((50, "planted"), (150, "related"), (250, "random"), (600, "random")):
                 q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(lr, lr), kinds=(kind,))
                 qs += q
                 rs += r
+        # planted matches at the very end of long windows (the last chunk), and across a chunk boundary
+        for lr, at in ((20000, 19900), (6000, 2040), (10000, 4090)):
+            r = helpers_rand(rng, lr)
+            q = helpers_rand(rng, 150)
+            q[40:140] = r[at - 50:at + 50]
+            qs.append(q)
+            rs.append(r)
         _compare(c, oracle, qs, rs)
         with pytest.raises(fade_amd.FadeHipError):
-            c.sw_batch([b"ACGT"], [b"A" * 20001])
+            c.sw_batch([b"ACGT"], [b"A" * 40001])
+    finally:
+        c.close()
+
+
+def helpers_rand(rng, n):
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+
+
+def test_annotate_long_windows_take_the_wave_kernels(oracle):
+    """Level 2 with a window size that puts every window beyond one staged chunk (-w 1500: ~3,100 columns) and beyond the old
+    8,000-column limit (-w 5000): rs, tags and stats against the oracle, and the device profile shows no thread-per-alignment
+    fallback (the score pass ran: forward_ms of the wave kernels covers all alignments)."""
+    import fade_amd
+    from fade_amd import format_tags, synth
+    cfg, g, b = synth.make_config("C2", 3000, contig_len=300_000)
+    c = fade_amd.Context(device=0)
+    try:
+        c.genome_upload(g.names, g.ascii_contigs())
+        G = oracle.GenomeHolder(g.names, [a.tobytes() for a in g.ascii_contigs()])
+        for w in (1500, 5000):
+            rs, aln, st = c.annotate(b, cfg["floor_len"], w)
+            tags = format_tags(b, g.names, rs, aln)
+            ors, oam = oracle.annotate_batch_soa(G, b, cfg["floor_len"], w, threads=8)
+            assert np.array_equal(rs, ors), w
+            for i in range(len(ors)):
+                assert (tags[i]["am"] if i in tags else None) == oam[i], (w, i)
+            assert len(tags) > 50
     finally:
         c.close()
