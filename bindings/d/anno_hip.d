@@ -85,12 +85,12 @@ int annotateHip(string cl, string[] args, ubyte con, int artifact_floor_length, 
         seqOff[$ - 1] = cast(uint) seq.length;
         rs.length = chunk.length;
         aln.length = chunk.length;
-        // (ABI 2: the arrays may also live in ONE pinned block laid out by fadehip_batch_bind, with the records
-        // anno.d:61-65 settles left out and counted in n_skipped -- what fade_main.cpp's pack_chunk does; this sketch
-        // keeps the simple form: every record, arrays from anywhere)
+        // (the arrays may also live in ONE pinned block laid out by fadehip_batch_bind, records without an S op carrying
+        // no bases, and the ABI-3 bounds n_with_seq / l_seq_min / l_seq_max filled in -- what fade_main.cpp's pack_chunk
+        // does; this sketch keeps the simple form: every record with its bases, arrays from anywhere, bounds unknown = 0)
         fadehip_read_batch b = {
             cast(int) chunk.length, tid.ptr, pos.ptr, flag.ptr, hasSa.ptr, lseq.ptr, cigarOff.ptr,
-            cigarOps.ptr, seqOff.ptr, seq.ptr, 0, 0
+            cigarOps.ptr, seqOff.ptr, seq.ptr, 0, 0, 0, 0, 0, 0
         };
         fadehip_anno_out o;
         o.rs = rs.ptr;

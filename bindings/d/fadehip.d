@@ -1,4 +1,4 @@
-/// extern(C) binding of include/fadehip.h (ABI version 2) for the D host of blachlylab/fade.
+/// extern(C) binding of include/fadehip.h (ABI version 3) for the D host of blachlylab/fade.
 ///
 /// NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no D compiler (ldc2, dmd, gdc, dub are
 /// all absent) and none of FADE's dependencies, so this file has never been compiled or run.  It mirrors
@@ -8,7 +8,7 @@ module fadehip;
 
 extern (C) nothrow @nogc:
 
-enum FADEHIP_ABI_VERSION = 2;
+enum FADEHIP_ABI_VERSION = 3;
 enum FADEHIP_MAX_OPS = 16;
 enum FADEHIP_MAX_QUERY = 512;
 enum FADEHIP_MAX_LONG_QUERY = 32768;
@@ -80,6 +80,10 @@ struct fadehip_read_batch
     const(ubyte)* seq_packed;
     int n_skipped; /// records left out because anno.d:61-65 gives them rs = 0 (unmapped, no S op)
     int ref_span_bound; /// max cigar.alignedLength over the batch, 0 = let the library scan the CIGARs
+    int n_with_seq;     /// ABI 3: records whose seq_off slice is not empty (0 = unknown)
+    int l_seq_min;      /// ABI 3: bounds of l_seq over the records with bases (0 = unknown)
+    int l_seq_max;
+    int reserved;
 }
 
 struct fadehip_aln
@@ -136,3 +140,11 @@ int fadehip_annotate_collect(fadehip_ctx* ctx, int slot, fadehip_anno_out* out_)
 int fadehip_sync(fadehip_ctx* ctx);
 int fadehip_last_run_profile(fadehip_ctx* ctx, int slot, float* ms4, long* counts6);
 int fadehip_stats_allreduce(fadehip_ctx** ctxs, int n_ctx, long* counters, int count);
+/// one process per GPU: rank 0 writes the RCCL id to id_path, the others read it (fadehip.h)
+int fadehip_stats_allreduce_rank(fadehip_ctx* ctx, int rank, int n_ranks, const(char)* id_path, long* counters, int count);
+
+/// BGZF members made on the device (htslib bgzf_write's deflate under util.d:65-76); lane 0 or 1
+enum FADEHIP_BGZF_BLOCK = 0xff00;
+enum FADEHIP_BGZF_LANES = 2;
+int fadehip_bgzf_deflate_submit(fadehip_ctx* ctx, int lane, const(void)* src, size_t n_bytes);
+int fadehip_bgzf_deflate_wait(fadehip_ctx* ctx, int lane, const(ubyte)** out_, size_t* out_bytes);
