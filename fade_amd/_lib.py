@@ -30,7 +30,8 @@ EXPORTS = [
     "fadehip_genome_upload", "fadehip_annotate_upload", "fadehip_annotate_run", "fadehip_annotate_submit",
     "fadehip_annotate_results", "fadehip_annotate_collect",
     "fadehip_sync", "fadehip_last_run_profile", "fadehip_stats_allreduce",
-    "fadehip_bgzf_deflate_submit", "fadehip_bgzf_deflate_wait", "fadehip_stats_allreduce_rank",
+    "fadehip_bgzf_deflate_submit", "fadehip_bgzf_deflate_wait", "fadehip_stats_allreduce_rank", "fadehip_bgzf_inflate",
+    "fadehip_bam_open", "fadehip_bam_front", "fadehip_bam_back", "fadehip_bam_totals", "fadehip_bam_close",
 ]
 BGZF_BLOCK = 0xff00
 BGZF_LANES = 2
@@ -78,6 +79,11 @@ class AnnoView(C.Structure):
                 ("stats", C.c_int64 * 8), ("n_oversize", C.c_int32), ("reserved", C.c_int32)]
 
 
+class BamConfig(C.Structure):
+    _fields_ = [("floor_len", C.c_int32), ("window", C.c_int32), ("n_ref", C.c_int32), ("reserved", C.c_int32),
+                ("ref_names", C.POINTER(C.c_char_p)), ("first_record", C.c_uint32), ("reserved2", C.c_uint32)]
+
+
 class FadeHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("fadehip error %d: %s" % (code, msg))
@@ -123,6 +129,13 @@ def load():
     L.fadehip_bgzf_deflate_submit.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.fadehip_stats_allreduce_rank.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, vp, C.c_int]
     L.fadehip_bgzf_deflate_wait.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.fadehip_bgzf_inflate.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fadehip_bam_open.argtypes = [vp, C.POINTER(BamConfig), C.POINTER(vp)]
+    L.fadehip_bam_front.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.fadehip_bam_back.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.fadehip_bam_totals.argtypes = [vp, C.POINTER(i64 * 8), C.POINTER(i64), C.POINTER(i64)]
+    L.fadehip_bam_close.argtypes = [vp]
+    L.fadehip_bam_close.restype = None
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here means the .so is stale against include/fadehip.h
     _lib = L

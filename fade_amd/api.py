@@ -282,6 +282,22 @@ class Context:
         self.bgzf_deflate_submit(lane, data)
         return self.bgzf_deflate_wait(lane)
 
+    def bam_stream(self, ref_names, floor_len=5, window=300, first_record=0):
+        """The file path on the device (fadehip_bam_*): BGZF members of a BAM's records in, BGZF members of the annotated
+        records out.  ref_names: the BAM header's contigs (the genome must be uploaded)."""
+        return BamStream(self, ref_names, floor_len, window, first_record)
+
+    def bgzf_inflate(self, members, out_cap=None):
+        """Whole BGZF members (bytes / uint8 array) -> their payloads, inflated on the device (CRC32 and ISIZE checked)."""
+        arr = np.frombuffer(members, dtype=np.uint8) if isinstance(members, (bytes, bytearray, memoryview)) else np.ascontiguousarray(members, dtype=np.uint8)
+        if out_cap is None:  # ISIZE of every member: at most 64 KiB each, and a member takes at least 28 bytes
+            out_cap = 65536 * (arr.nbytes // 28 + 1)
+            out_cap = min(out_cap, max(1 << 16, arr.nbytes * 1100))
+        out = np.empty(out_cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self._L.fadehip_bgzf_inflate(self._h, arr.ctypes.data, arr.nbytes, out.ctypes.data, out_cap, C.byref(n)))
+        return out[:n.value]
+
     def sync(self):
         self._chk(self._L.fadehip_sync(self._h))
 
@@ -400,6 +416,37 @@ def format_tags(batch, contig_names, rs, aln):
         out[i] = dict(rs=int(rs[i]), am=left[0] + ";" + right[0], as_=left[1] + ";" + right[1],
                       ar=left[2] + ";" + right[2], ab=left[3] + ";" + right[3])
     return out
+
+
+class BamStream:
+    def __init__(self, ctx, ref_names, floor_len, window, first_record):
+        self._ctx, self._L = ctx, ctx._L
+        names = [n.encode() if isinstance(n, str) else bytes(n) for n in ref_names]
+        arr = (C.c_char_p * max(len(names), 1))(*names)
+        cfg = _lib.BamConfig(floor_len, window, len(names), 0, arr, first_record, 0)
+        h = C.c_void_p()
+        ctx._chk(self._L.fadehip_bam_open(ctx._h, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._keep = None
+
+    def front(self, members, last=False):
+        arr = np.frombuffer(members, dtype=np.uint8) if isinstance(members, (bytes, bytearray, memoryview)) else np.ascontiguousarray(members, dtype=np.uint8)
+        self._ctx._chk(self._L.fadehip_bam_front(self._h, arr.ctypes.data if arr.nbytes else None, arr.nbytes, 1 if last else 0))
+
+    def back(self):
+        p, n = C.c_void_p(), C.c_size_t(0)
+        self._ctx._chk(self._L.fadehip_bam_back(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def totals(self):
+        st, nr, no = (C.c_int64 * 8)(), C.c_int64(0), C.c_int64(0)
+        self._ctx._chk(self._L.fadehip_bam_totals(self._h, C.byref(st), C.byref(nr), C.byref(no)))
+        return [int(x) for x in st], int(nr.value), int(no.value)
+
+    def close(self):
+        if self._h:
+            self._L.fadehip_bam_close(self._h)
+            self._h = None
 
 
 def annotate_records(ctx, batch, floor_len=5, window=300):

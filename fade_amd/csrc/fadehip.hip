@@ -8,8 +8,11 @@
 // planning kernel builds — and results / collect waits for the slot.
 #include "fadehip_kernels.hpp"
 #include "bgzf_deflate.hpp"
+#include "bgzf_inflate.hpp"
+#include "bam_device.hpp"
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -125,6 +128,8 @@ struct Slot {
     uint32_t out_bound = 0, out_cap = 0;  // upload: alignments at most; run: entries of the result array
     std::vector<std::pair<int64_t, int>> wide;
     bool use_ckpt = false;              // this run's score passes leave wave snapshots (see run_class_two_pass)
+    bool device_only = false;           // the file path: rs and the alignments stay on the device (only the counter block comes back)
+    bool wide_all = false;              // the file path: some read's alignedLength is long and which ones is not known on the host
     int wave_lr_bound = 0, long_max_lq = 0, long_max_lr = 0;
     int floor_len = 0, window = 0;
     int n_reads = 0, n_skipped = 0;
@@ -155,6 +160,13 @@ struct BgzfLane {
     int state = 0;  // 0 idle, 1 submitted
 };
 
+// The synchronous inflate entry (fadehip_bgzf_inflate): buffers kept between calls.
+struct InflateLane {
+    hipStream_t stream = nullptr;
+    DevBuf comp, blocks, out, status, ticket;
+    PinBuf h_status;
+};
+
 }  // namespace
 
 struct fadehip_ctx {
@@ -183,6 +195,7 @@ struct fadehip_ctx {
     int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
     bool debug = false;
     BgzfLane bgzf[FADEHIP_BGZF_LANES];
+    InflateLane inf;
     bool bgzf_ready = false;           // the compressor's LDS size has been declared to the runtime
     std::map<uint64_t, int> resident;  // (class, mode, LDS bytes) -> waves of that kernel the device holds at once
     std::mutex resident_mu;
@@ -787,7 +800,7 @@ int plan_run(fadehip_ctx *ctx, Slot &s) {
         uint32_t n_long = s.hist[LONG_LIST];  // reads beyond 512 bases
         int64_t max_lr = 1;
         int max_lq = s.hist[LONG_LIST] ? std::min(s.max_lq, MAX_LONG_QUERY) : 1;
-        if (2 * w + WIDE_MIN_SPAN > WAVE_MAX_WINDOW) {
+        if (2 * w + WIDE_MIN_SPAN > WAVE_MAX_WINDOW || s.wide_all) {
             // with this window size a read of ordinary span may have a long window: any record that carries bases may
             // land on the long list
             n_long = s.out_bound;
@@ -828,7 +841,7 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
     s.res_aln_off = ((size_t)n + 255) & ~(size_t)255;
     if ((rc = reserve(ctx, s.rs, (size_t)n)) || (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)std::max<uint32_t>(total_bound, 1))) ||
         (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)) ||
-        (rc = reserve_pinned(ctx, s.res, s.res_aln_off + sizeof(fadehip_aln) * (size_t)total_bound)))
+        (!s.device_only && (rc = reserve_pinned(ctx, s.res, s.res_aln_off + sizeof(fadehip_aln) * (size_t)total_bound))))
         return rc;
     for (int c = 0; c < NUM_LISTS; c++) {
         if (!s.bound[c]) continue;
@@ -935,6 +948,7 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
     if ((rc = record(ctx, s, &s.ev_end))) return rc;
     // results to the slot's pinned block; the counter block tells the host how many entries of each list are live
     HIPCHK(ctx, hipMemcpyAsync(s.h_zb, s.zblock.p, Slot::ZB_BYTES, hipMemcpyDeviceToHost, st));
+    if (s.device_only) return 0;
     HIPCHK(ctx, hipMemcpyAsync(s.res.p, s.rs.p, (size_t)n, hipMemcpyDeviceToHost, st));
     if (total_bound)
         HIPCHK(ctx, hipMemcpyAsync(s.res.p + s.res_aln_off, s.aln.p, sizeof(fadehip_aln) * (size_t)total_bound, hipMemcpyDeviceToHost, st));
@@ -999,6 +1013,69 @@ int finish_run(fadehip_ctx *ctx, Slot &s, int slot) {
         fprintf(stderr, "[fadehip] slot %d: %d reads, %u alignments, %lld candidates traced, %lld re-run, trace need %lld B\n", slot, n, at,
                 (long long)s.n_cand, (long long)s.n_rerun, (long long)s.prof_counts[2]);
     s.state = 3;
+    return 0;
+}
+
+
+// The BGZF members of p[0, n): where each one's DEFLATE stream lies, its ISIZE and CRC32 (SAM spec 4.1: gzip member with
+// FEXTRA and the subfield 'B','C' holding BSIZE = member size - 1).  Stops in front of a member that is not whole
+// (*consumed = bytes of whole members); false + msg for bytes that are not a BGZF member.
+bool scan_bgzf_members(const uint8_t *p, size_t n, std::vector<bgzf::InflateBlock> &blocks, size_t *consumed, uint64_t *total_out, std::string &msg) {
+    size_t at = 0;
+    uint64_t out = *total_out;
+    while (n - at >= 18) {
+        const uint8_t *m = p + at;
+        if (m[0] != 0x1f || m[1] != 0x8b || m[2] != 8 || !(m[3] & 4)) {
+            msg = "not a BGZF member at byte " + std::to_string(at) + " (gzip magic / FEXTRA missing)";
+            return false;
+        }
+        const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
+        if (n - at < 12 + xlen) break;
+        size_t bsize = 0;
+        for (size_t x = 12; x + 4 <= 12 + xlen;) {
+            const size_t slen = (size_t)m[x + 2] | ((size_t)m[x + 3] << 8);
+            if (m[x] == 'B' && m[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = ((size_t)m[x + 4] | ((size_t)m[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 2 + 8) {
+            msg = "BGZF member at byte " + std::to_string(at) + " has no BC subfield or an impossible BSIZE";
+            return false;
+        }
+        if (n - at < bsize) break;
+        bgzf::InflateBlock b;
+        b.src_off = at + 12 + xlen;
+        b.src_len = (uint32_t)(bsize - 12 - xlen - 8);
+        memcpy(&b.crc, m + bsize - 8, 4);
+        memcpy(&b.isize, m + bsize - 4, 4);
+        b.dst_off = out;
+        b.pad = 0;
+        if (b.isize > 65536u) {
+            msg = "BGZF member at byte " + std::to_string(at) + " claims ISIZE " + std::to_string(b.isize) + " (at most 65536)";
+            return false;
+        }
+        out += b.isize;
+        blocks.push_back(b);
+        at += bsize;
+    }
+    *consumed = at;
+    *total_out = out;
+    return true;
+}
+
+const char *inflate_error_name(uint32_t e) {
+    static const char *const nm[] = {"ok", "reserved block type", "stored block LEN/NLEN mismatch", "bad dynamic-Huffman header", "invalid code",
+                                     "distance beyond the block's start", "more bytes than ISIZE", "stream runs past the member's end",
+                                     "fewer bytes than ISIZE", "CRC32 mismatch"};
+    return e < sizeof nm / sizeof nm[0] ? nm[e] : "unknown";
+}
+
+// the inflate launch: as many waves as the device holds (8 per SIMD), each drawing members from the ticket
+int launch_inflate(fadehip_ctx *ctx, hipStream_t st, const bgzf::InflateArgs &a) {
+    HIPCHK(ctx, hipMemsetAsync(a.ticket, 0, 8, st));
+    const unsigned wgs = (a.n_blocks + bgzf::INF_WAVES - 1) / bgzf::INF_WAVES;
+    const unsigned grid = std::max(1u, std::min<unsigned>(wgs, (unsigned)std::max(ctx->cu_count, 1) * 8u));
+    hipLaunchKernelGGL(bgzf::bgzf_inflate_kernel, dim3(grid), dim3(bgzf::INF_WG), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }
 
@@ -1147,6 +1224,9 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         if (l.h_total) (void)hipHostFree(l.h_total);
         if (l.stream && (&l == &ctx->bgzf[0] || l.stream != ctx->bgzf[0].stream)) (void)hipStreamDestroy(l.stream);
     }
+    for (DevBuf *b : {&ctx->inf.comp, &ctx->inf.blocks, &ctx->inf.out, &ctx->inf.status, &ctx->inf.ticket}) release(*b);
+    release(ctx->inf.h_status);
+    if (ctx->inf.stream) (void)hipStreamDestroy(ctx->inf.stream);
     release(ctx->genome);
     for (DevBuf *b : {&ctx->l1_q, &ctx->l1_r, &ctx->l1_qn, &ctx->l1_rn, &ctx->l1_bad, &ctx->l1_work, &ctx->l1_aln}) release(*b);
     release(ctx->contig_len);
@@ -1501,6 +1581,8 @@ int fadehip_annotate_run(fadehip_ctx *ctx, int slot, int32_t floor_len, int32_t 
         s.n_reads = nx.n_reads;
         s.n_skipped = nx.n_skipped;
         s.have_batch = true;
+        s.device_only = false;
+        s.wide_all = false;
         s.next.valid = false;
         if (s.n_reads) HIPCHK(ctx, hipStreamWaitEvent(s.stream, s.ev_copied, 0));
     }
@@ -1605,11 +1687,8 @@ int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t co
 }
 
 // ------------------------------------------------------------------------------- BGZF compression
-int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, size_t n_bytes) {
-    if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
-    if (lane < 0 || lane >= FADEHIP_BGZF_LANES) return set_err(ctx, FADEHIP_E_INVALID, "bgzf lane %d out of range", lane);
-    if (!src || n_bytes == 0 || n_bytes > ((size_t)1 << 31)) return set_err(ctx, FADEHIP_E_INVALID, "bgzf: 1 .. 2^31 bytes per call");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+// the compressor's launches for n_bytes at d_src (device memory with 64 readable bytes behind the end) on the lane's stream
+static int bgzf_lane_ready(fadehip_ctx *ctx, int lane) {
     BgzfLane &l = ctx->bgzf[lane];
     if (!l.stream) {
         // (every stream is an HSA queue with a 173 MB context-save area to set up and to give back: FADEHIP_BGZF_ONE_STREAM=1
@@ -1624,18 +1703,20 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     }
     if (l.state == 1) HIPCHK(ctx, hipStreamSynchronize(l.stream));  // never waited for: its buffers are still in use
     l.state = 0;
+    return 0;
+}
+static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t n_bytes) {
+    BgzfLane &l = ctx->bgzf[lane];
     const uint32_t nb = (uint32_t)((n_bytes + bgzf::BLOCK - 1) / bgzf::BLOCK);
     int rc;
-    if ((rc = reserve(ctx, l.src, n_bytes + 64)) || (rc = reserve(ctx, l.slots, (size_t)nb * bgzf::SLOT)) ||
-        (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 1024)) || (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) ||
-        (rc = reserve(ctx, l.packed, (size_t)nb * bgzf::SLOT)))
+    if ((rc = reserve(ctx, l.slots, (size_t)nb * bgzf::SLOT)) || (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 1024)) ||
+        (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) || (rc = reserve(ctx, l.packed, (size_t)nb * bgzf::SLOT)))
         return rc;
     uint32_t *d_size = (uint32_t *)l.meta.p, *d_crc = d_size + nb, *d_ticket = d_crc + nb;
     uint64_t *d_total = (uint64_t *)(((uintptr_t)(d_ticket + 2) + 7) & ~(uintptr_t)7);
-    HIPCHK(ctx, hipMemcpyAsync(l.src.p, src, n_bytes, hipMemcpyHostToDevice, l.stream));
     HIPCHK(ctx, hipMemsetAsync(d_ticket, 0, 8, l.stream));
     bgzf::DeflateArgs a;
-    a.src = (const uint8_t *)l.src.p;
+    a.src = d_src;
     a.n_bytes = n_bytes;
     a.n_blocks = nb;
     a.slots = (uint8_t *)l.slots.p;
@@ -1660,6 +1741,19 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     l.n_blocks = nb;
     l.state = 1;
     return 0;
+}
+
+int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, size_t n_bytes) {
+    if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
+    if (lane < 0 || lane >= FADEHIP_BGZF_LANES) return set_err(ctx, FADEHIP_E_INVALID, "bgzf lane %d out of range", lane);
+    if (!src || n_bytes == 0 || n_bytes > ((size_t)1 << 31)) return set_err(ctx, FADEHIP_E_INVALID, "bgzf: 1 .. 2^31 bytes per call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = bgzf_lane_ready(ctx, lane))) return rc;
+    BgzfLane &l = ctx->bgzf[lane];
+    if ((rc = reserve(ctx, l.src, n_bytes + 64))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(l.src.p, src, n_bytes, hipMemcpyHostToDevice, l.stream));
+    return bgzf_enqueue(ctx, lane, (const uint8_t *)l.src.p, n_bytes);
 }
 
 int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, size_t *out_bytes) {
@@ -1710,6 +1804,453 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
     *out = l.out.p;
     *out_bytes = (size_t)total;
     return 0;
+}
+
+// ------------------------------------------------------------------------------- BGZF decompression
+int fadehip_bgzf_inflate(fadehip_ctx *ctx, const void *members, size_t n_bytes, void *out, size_t out_cap, size_t *out_bytes) {
+    if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
+    if (!out_bytes || (n_bytes && !members)) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
+    *out_bytes = 0;
+    if (n_bytes == 0) return 0;
+    std::vector<bgzf::InflateBlock> blocks;
+    size_t consumed = 0;
+    uint64_t total = 0;
+    std::string msg;
+    if (!scan_bgzf_members((const uint8_t *)members, n_bytes, blocks, &consumed, &total, msg)) return set_err(ctx, FADEHIP_E_INVALID, "bgzf inflate: %s", msg.c_str());
+    if (consumed != n_bytes) return set_err(ctx, FADEHIP_E_INVALID, "bgzf inflate: the last member is not whole (%zu of %zu bytes are whole members)", consumed, n_bytes);
+    if (total > out_cap || (total && !out)) return set_err(ctx, FADEHIP_E_INVALID, "bgzf inflate: %llu bytes do not fit out_cap %zu", (unsigned long long)total, out_cap);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    InflateLane &l = ctx->inf;
+    if (!l.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    const uint32_t nb = (uint32_t)blocks.size();
+    int rc;
+    if ((rc = reserve(ctx, l.comp, n_bytes + 16)) || (rc = reserve(ctx, l.blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
+        (rc = reserve(ctx, l.out, (size_t)total + 64)) || (rc = reserve(ctx, l.status, 4 * (size_t)nb)) || (rc = reserve(ctx, l.ticket, 64)) ||
+        (rc = reserve_pinned(ctx, l.h_status, 4 * (size_t)nb + 8)))
+        return rc;
+    HIPCHK(ctx, hipMemcpyAsync(l.comp.p, members, n_bytes, hipMemcpyHostToDevice, l.stream));
+    HIPCHK(ctx, hipMemcpyAsync(l.blocks.p, blocks.data(), sizeof(bgzf::InflateBlock) * (size_t)nb, hipMemcpyHostToDevice, l.stream));
+    HIPCHK(ctx, hipStreamSynchronize(l.stream));  // (blocks is a pageable vector about to go out of scope)
+    bgzf::InflateArgs a;
+    a.comp = (const uint8_t *)l.comp.p;
+    a.blocks = (const bgzf::InflateBlock *)l.blocks.p;
+    a.n_blocks = nb;
+    a.out = (uint8_t *)l.out.p;
+    a.out_shift = nullptr;
+    a.status = (uint32_t *)l.status.p;
+    a.ticket = (uint32_t *)l.ticket.p;
+    a.check_crc = 1;
+    if ((rc = launch_inflate(ctx, l.stream, a))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(l.h_status.p, l.ticket.p, 8, hipMemcpyDeviceToHost, l.stream));
+    HIPCHK(ctx, hipStreamSynchronize(l.stream));
+    const uint32_t n_bad = ((const uint32_t *)l.h_status.p)[1];
+    if (n_bad) {
+        HIPCHK(ctx, hipMemcpy(l.h_status.p, l.status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        const uint32_t *stt = (const uint32_t *)l.h_status.p;
+        for (uint32_t k = 0; k < nb; k++)
+            if (stt[k]) return set_err(ctx, FADEHIP_E_INVALID, "bgzf inflate: member %u of %u: %s (%u members failed)", k, nb, inflate_error_name(stt[k]), n_bad);
+    }
+    if (total) HIPCHK(ctx, hipMemcpy(out, l.out.p, (size_t)total, hipMemcpyDeviceToHost));
+    *out_bytes = (size_t)total;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- the file path on the device
+struct fadehip_bam_stream {
+    fadehip_ctx *ctx = nullptr;
+    int32_t floor_len = 0, window = 0, n_ref = 0;
+    uint32_t first_record = 0;
+    DevBuf names_text, names_off;
+    // front half (one call at a time)
+    DevBuf comp, blocks, status, ticket;
+    DevBuf u[2];                 // inflated bytes, ping-pong: the tail of one chunk is carried to the front of the next
+    uint32_t prev_len = 0, prev_consumed = 0;  // of u[(k - 1) & 1]
+    DevBuf seg, slots, rec_off, info, sent_of, art_of, out_size, blk32, blk64, counts;
+    PinBuf h_blocks, h_counts;
+    uint64_t k_front = 0, k_back = 0;
+    struct Out {
+        DevBuf o;
+        size_t bytes = 0;
+        hipEvent_t ready = nullptr;
+        int state = 0;  // 0 free, 1 waiting for back
+    } ring[FADEHIP_BAM_CHUNKS];
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t n_records = 0, n_oversize = 0, n_redone = 0;
+    bool failed = false, ended = false, closing = false;
+    double t_inflate = 0, t_frame = 0, t_pack = 0, t_run = 0, t_tags = 0;
+};
+
+namespace {
+
+int bam_fail(fadehip_bam_stream *st, int rc) {
+    {
+        std::lock_guard<std::mutex> l(st->mu);
+        st->failed = true;
+    }
+    st->cv.notify_all();
+    return rc;
+}
+
+int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_bytes, int last) {
+    fadehip_ctx *ctx = st->ctx;
+    Slot &s = ctx->slots[0];
+    int rc;
+    if ((rc = ensure_slot(ctx, s))) return rc;
+    hipStream_t q = s.stream;
+    const uint64_t k = st->k_front;
+    // ---- the members, and where their payloads go
+    std::vector<bgzf::InflateBlock> blocks;
+    size_t consumed = 0;
+    uint64_t total = 0;
+    std::string msg;
+    if (n_bytes && !scan_bgzf_members(members, n_bytes, blocks, &consumed, &total, msg)) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: %s", msg.c_str());
+    if (consumed != n_bytes) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: front takes whole BGZF members (%zu of %zu bytes are)", consumed, n_bytes);
+    const uint32_t carry = st->prev_len - st->prev_consumed;
+    if ((uint64_t)carry + total > (uint64_t)bam::MAX_U) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu inflated bytes in one call (at most %u)", (unsigned long long)total + carry, bam::MAX_U);
+    const uint32_t u_len = carry + (uint32_t)total;
+    DevBuf &ub = st->u[k & 1];
+    if ((rc = reserve(ctx, ub, (size_t)u_len + 256))) return rc;
+    uint8_t *u = (uint8_t *)ub.p;
+    if (carry) HIPCHK(ctx, hipMemcpyAsync(u, (const uint8_t *)st->u[(k + 1) & 1].p + st->prev_consumed, carry, hipMemcpyDeviceToDevice, q));
+    const uint32_t nb = (uint32_t)blocks.size();
+    if (nb) {
+        for (auto &b : blocks) b.dst_off += carry;
+        if ((rc = reserve(ctx, st->comp, n_bytes + 16)) || (rc = reserve(ctx, st->blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
+            (rc = reserve(ctx, st->status, 4 * (size_t)nb)) || (rc = reserve(ctx, st->ticket, 64)) ||
+            (rc = reserve_pinned(ctx, st->h_blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)))
+            return rc;
+        memcpy(st->h_blocks.p, blocks.data(), sizeof(bgzf::InflateBlock) * (size_t)nb);
+        HIPCHK(ctx, hipMemcpyAsync(st->comp.p, members, n_bytes, hipMemcpyHostToDevice, q));
+        HIPCHK(ctx, hipMemcpyAsync(st->blocks.p, st->h_blocks.p, sizeof(bgzf::InflateBlock) * (size_t)nb, hipMemcpyHostToDevice, q));
+        bgzf::InflateArgs ia;
+        ia.comp = (const uint8_t *)st->comp.p;
+        ia.blocks = (const bgzf::InflateBlock *)st->blocks.p;
+        ia.n_blocks = nb;
+        ia.out = u;
+        ia.out_shift = nullptr;
+        ia.status = (uint32_t *)st->status.p;
+        ia.ticket = (uint32_t *)st->ticket.p;
+        ia.check_crc = 1;
+        if ((rc = launch_inflate(ctx, q, ia))) return rc;
+    }
+    // ---- framing
+    const uint32_t n_seg = (u_len + bam::SEG - 1) / bam::SEG;
+    const uint32_t rec_cap = u_len / 36u + 2u;
+    if ((rc = reserve(ctx, st->seg, 16 * (size_t)std::max(n_seg, 1u))) || (rc = reserve(ctx, st->slots, 4 * (size_t)bam::SEG_SLOTS * std::max(n_seg, 1u))) ||
+        (rc = reserve(ctx, st->rec_off, 4 * (size_t)rec_cap)) || (rc = reserve(ctx, st->counts, sizeof(bam::ChunkCounts))) ||
+        (rc = reserve_pinned(ctx, st->h_counts, sizeof(bam::ChunkCounts) + 16)))
+        return rc;
+    bam::ChunkCounts *d_counts = (bam::ChunkCounts *)st->counts.p;
+    bam::ChunkCounts *h_counts = (bam::ChunkCounts *)st->h_counts.p;
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, sizeof(bam::ChunkCounts), q));
+    HIPCHK(ctx, hipMemsetAsync(&d_counts->l_seq_min, 0xff, 4, q));
+    bam::FrameArgs fa;
+    fa.u = u;
+    fa.u_len = u_len;
+    fa.first = k == 0 ? st->first_record : 0u;
+    fa.n_ref = st->n_ref;
+    fa.n_seg_cap = n_seg;
+    fa.cand = (uint32_t *)st->seg.p;
+    fa.exit_ = fa.cand + std::max(n_seg, 1u);
+    fa.cnt = fa.exit_ + std::max(n_seg, 1u);
+    fa.base = fa.cnt + std::max(n_seg, 1u);
+    fa.slots = (uint32_t *)st->slots.p;
+    fa.rec_off = (uint32_t *)st->rec_off.p;
+    fa.rec_cap = rec_cap;
+    fa.counts = d_counts;
+    if (n_seg) {
+        hipLaunchKernelGGL(bam::bam_frame_walk_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, q, fa);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(bam::bam_frame_resolve_kernel, dim3(1), dim3(64), 0, q, fa);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(bam::bam_frame_compact_kernel, dim3(std::max(1u, (n_seg + 3) / 4)), dim3(256), 0, q, fa);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
+    uint32_t *h_tick = (uint32_t *)(st->h_counts.p + sizeof(bam::ChunkCounts));
+    h_tick[0] = h_tick[1] = 0;
+    if (nb) HIPCHK(ctx, hipMemcpyAsync(h_tick, st->ticket.p, 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(ctx, hipStreamSynchronize(q));  // (1) the records of this call
+    if (nb && h_tick[1]) {
+        std::vector<uint32_t> stt(nb);
+        HIPCHK(ctx, hipMemcpy(stt.data(), st->status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < nb; b++)
+            if (stt[b]) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu, member %u of %u: %s (%u members failed)", (unsigned long long)k, b, nb, inflate_error_name(stt[b]), h_tick[1]);
+    }
+    if (h_counts->frame_err)
+        return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu: %s at inflated offset %u", (unsigned long long)k,
+                       h_counts->frame_err == 1 ? "a record's block_size is impossible" : "the first record lies beyond the bytes given", h_counts->frame_err_at);
+    const uint32_t n_rec = h_counts->n_records, used = h_counts->consumed;
+    if (last && used != u_len) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: the input ends inside a record (%u bytes behind the last whole one)", u_len - used);
+    st->prev_len = u_len;
+    st->prev_consumed = used;
+    st->n_redone += h_counts->n_redone;
+    // ---- a place in the ring
+    fadehip_bam_stream::Out *out;
+    {
+        std::unique_lock<std::mutex> l(st->mu);
+        out = &st->ring[k % FADEHIP_BAM_CHUNKS];
+        st->cv.wait(l, [&] { return out->state == 0 || st->failed || st->closing; });
+        if (st->failed || st->closing) return set_err(ctx, FADEHIP_E_STATE, "bam stream: stopped");
+    }
+    out->bytes = 0;
+    if (n_rec) {
+        // ---- the batch: which records go to the device's gate, their arrays
+        const uint32_t nblk = (n_rec + bam::PACK_BLOCK - 1) / bam::PACK_BLOCK, ntb = (n_rec + bam::TAG_BLOCK - 1) / bam::TAG_BLOCK;
+        if ((rc = reserve(ctx, st->info, 4 * (size_t)n_rec)) || (rc = reserve(ctx, st->sent_of, 4 * (size_t)n_rec)) ||
+            (rc = reserve(ctx, st->out_size, 4 * (size_t)n_rec)) || (rc = reserve(ctx, st->blk32, 24 * (size_t)nblk)) || (rc = reserve(ctx, st->blk64, 16 * (size_t)ntb)))
+            return rc;
+        bam::PackArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.u = u;
+        pa.rec_off = fa.rec_off;
+        pa.counts_in = d_counts;
+        pa.r0 = 0;
+        pa.r1_cap = n_rec;
+        pa.info = (uint32_t *)st->info.p;
+        pa.blk_sums = (uint32_t *)st->blk32.p;
+        pa.blk_base = pa.blk_sums + 3 * (size_t)nblk;
+        pa.counts = d_counts;
+        pa.sent_of = (int32_t *)st->sent_of.p;
+        hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(nblk), dim3(bam::PACK_BLOCK), 0, q, pa);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
+        HIPCHK(ctx, hipStreamSynchronize(q));  // (2) the sizes of the batch
+        if (h_counts->n_bad_layout)
+            return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu: %u records whose fields do not fit their block_size or whose tags are not whole fields (corrupt BAM)", (unsigned long long)k, h_counts->n_bad_layout);
+        const uint32_t n_sent = h_counts->n_sent;
+        if ((uint64_t)h_counts->n_seq * 2 >= ((uint64_t)1 << 32)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: packed sequence bytes per call must stay below 2^31");
+        if (s.state == 2) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+        s.state = 0;
+        s.device_only = true;
+        s.next.valid = false;
+        s.have_batch = false;
+        s.cur = 0;
+        s.L = batch_layout(n_sent, h_counts->n_cig, h_counts->n_seq);
+        if ((rc = reserve(ctx, s.in[0], s.L.total))) return rc;
+        uint8_t *ib = (uint8_t *)s.in[0].p;
+        pa.tid = (int32_t *)(ib + s.L.off[A_TID]);
+        pa.pos = (int32_t *)(ib + s.L.off[A_POS]);
+        pa.lseq = (int32_t *)(ib + s.L.off[A_LSEQ]);
+        pa.cigar_off = (uint32_t *)(ib + s.L.off[A_CIGOFF]);
+        pa.seq_off = (uint32_t *)(ib + s.L.off[A_SEQOFF]);
+        pa.flag = (uint16_t *)(ib + s.L.off[A_FLAG]);
+        pa.has_sa = ib + s.L.off[A_SA];
+        pa.cigar_ops = (uint32_t *)(ib + s.L.off[A_CIG]);
+        pa.seq = ib + s.L.off[A_SEQ];
+        hipLaunchKernelGGL(bam::bam_pack_write_kernel, dim3(nblk), dim3(bam::PACK_BLOCK), 0, q, pa);
+        HIPCHK(ctx, hipGetLastError());
+        // ---- annotateTask on the device (level 2's kernels), results left there
+        s.n_reads = (int)n_sent;
+        s.n_skipped = (int)(n_rec - n_sent);
+        s.floor_len = st->floor_len;
+        s.window = st->window;
+        memset(s.hist, 0, sizeof s.hist);
+        s.wide.clear();
+        s.wide_all = false;
+        s.out_bound = n_sent;
+        s.max_lq = 0;
+        s.span_bound = 1;
+        if (n_sent) {
+            const int lmin = (int)std::min<uint32_t>(h_counts->l_seq_min, (uint32_t)MAX_LONG_QUERY), lmax = (int)std::min<uint32_t>(h_counts->l_seq_max, (uint32_t)MAX_LONG_QUERY);
+            const int c_lo = list_of_len(std::max(lmin, 1)), c_hi = list_of_len(std::max(lmax, 1));
+            for (int c = c_lo; c <= c_hi; c++) s.hist[c] = n_sent;  // any of them may be of any length in between
+            if (h_counts->n_long_q) s.hist[LONG_LIST] = h_counts->n_long_q;  // (the exact number of reads beyond 512 bases)
+            s.max_lq = std::max(lmax, 1);
+            s.span_bound = std::max<int64_t>(h_counts->span_max, 1);
+            s.wide_all = s.span_bound > WIDE_MIN_SPAN;
+        }
+        if (n_sent) {
+            if ((rc = plan_run(ctx, s)) || (rc = enqueue_run(ctx, s))) {
+                (void)hipStreamSynchronize(q);
+                return rc;
+            }
+            s.state = 2;
+        }
+        // ---- what anno.d:94-107 adds: sizes, offsets
+        if ((rc = reserve(ctx, st->art_of, 4 * (size_t)std::max(n_sent, 1u)))) return rc;
+        if (n_sent) {
+            HIPCHK(ctx, hipMemsetAsync(st->art_of.p, 0xff, 4 * (size_t)n_sent, q));
+            if (s.out_cap) {
+                hipLaunchKernelGGL(bam::bam_art_index_kernel, dim3((s.out_cap + 255) / 256), dim3(256), 0, q, (const fadehip_aln *)s.aln.p,
+                                   (const uint32_t *)(s.d_counters() + 2 * NUM_LISTS + 3), s.out_cap, (int32_t *)st->art_of.p, n_sent);
+                HIPCHK(ctx, hipGetLastError());
+            }
+        }
+        bam::TagArgs ta;
+        memset(&ta, 0, sizeof ta);
+        ta.u = u;
+        ta.rec_off = fa.rec_off;
+        ta.counts_in = d_counts;
+        ta.r0 = 0;
+        ta.r1_cap = n_rec;
+        ta.info = pa.info;
+        ta.sent_of = pa.sent_of;
+        ta.rs = (const uint8_t *)s.rs.p;
+        ta.aln = (const fadehip_aln *)s.aln.p;
+        ta.art_of = (const int32_t *)st->art_of.p;
+        ta.names.text = (const char *)st->names_text.p;
+        ta.names.off = (const uint32_t *)st->names_off.p;
+        ta.names.n = st->n_ref;
+        ta.out_size = (uint32_t *)st->out_size.p;
+        ta.blk_sums = (uint64_t *)st->blk64.p;
+        ta.blk_base = ta.blk_sums + ntb;
+        ta.counts = d_counts;
+        ta.out_base = 0;
+        hipLaunchKernelGGL(bam::bam_tag_size_kernel, dim3(ntb), dim3(bam::TAG_BLOCK), 0, q, ta);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(bam::bam_tag_scan_kernel, dim3(1), dim3(1024), 0, q, ta, ntb);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
+        if (n_sent) {
+            if ((rc = finish_run(ctx, s, 0))) return rc;  // (3) waits for the stream: run and sizes
+            for (int t = 0; t < 8; t++) st->stats[t] += s.stats[t];
+            st->n_oversize += s.n_oversize;
+        } else {
+            HIPCHK(ctx, hipStreamSynchronize(q));
+            st->stats[0] += n_rec;
+        }
+        const uint64_t out_bytes = h_counts->out_bytes;
+        if (out_bytes > ((uint64_t)1 << 31)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu output bytes in one call (at most 2^31)", (unsigned long long)out_bytes);
+        if ((rc = reserve(ctx, out->o, (size_t)out_bytes + 256))) return rc;
+        ta.o = (uint8_t *)out->o.p;
+        hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(ntb), dim3(bam::TAG_BLOCK), 0, q, ta);
+        HIPCHK(ctx, hipGetLastError());
+        out->bytes = (size_t)out_bytes;
+        st->n_records += n_rec;
+    }
+    if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(out->ready, q));
+    // the inflated bytes of this call are read by the next call's carry copy and by nothing else once the rewrite is done:
+    // both are on this stream, in order.
+    {
+        std::lock_guard<std::mutex> l(st->mu);
+        out->state = 1;
+        st->k_front = k + 1;
+        if (last) st->ended = true;
+    }
+    st->cv.notify_all();
+    return 0;
+}
+
+}  // namespace
+
+int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out) {
+    if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
+    if (!cfg || !out || cfg->n_ref < 0 || (cfg->n_ref && !cfg->ref_names) || cfg->window < 0) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: bad configuration");
+    if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
+    if (!ctx->two_pass) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: needs the default kernels (FADEHIP_KERNEL unset)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    fadehip_bam_stream *st = new (std::nothrow) fadehip_bam_stream;
+    if (!st) return set_err(ctx, FADEHIP_E_NOMEM, "out of memory");
+    st->ctx = ctx;
+    st->floor_len = cfg->floor_len;
+    st->window = cfg->window;
+    st->n_ref = cfg->n_ref;
+    st->first_record = cfg->first_record;
+    std::string text;
+    std::vector<uint32_t> off((size_t)cfg->n_ref + 1, 0);
+    for (int k = 0; k < cfg->n_ref; k++) {
+        if (!cfg->ref_names[k]) { delete st; return set_err(ctx, FADEHIP_E_INVALID, "bam stream: ref_names[%d] is NULL", k); }
+        off[(size_t)k] = (uint32_t)text.size();
+        text += cfg->ref_names[k];
+    }
+    off[(size_t)cfg->n_ref] = (uint32_t)text.size();
+    int rc;
+    if ((rc = reserve(ctx, st->names_text, text.size() + 1)) || (rc = reserve(ctx, st->names_off, 4 * off.size()))) { fadehip_bam_close(st); return rc; }
+    if (hipMemcpy(st->names_text.p, text.data(), text.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(st->names_off.p, off.data(), 4 * off.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        fadehip_bam_close(st);
+        return set_err(ctx, FADEHIP_E_HIP, "bam stream: copying the contig names failed");
+    }
+    *out = st;
+    return 0;
+}
+
+int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_bytes, int last) {
+    if (!st) return set_err(nullptr, FADEHIP_E_INVALID, "stream is NULL");
+    fadehip_ctx *ctx = st->ctx;
+    if (n_bytes && !members) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
+    if (st->failed) return set_err(ctx, FADEHIP_E_STATE, "bam stream: an earlier call failed");
+    if (st->ended) return set_err(ctx, FADEHIP_E_STATE, "bam stream: front after the last call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = bam_front_impl(st, (const uint8_t *)members, n_bytes, last);
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->slots[0].stream);
+        return bam_fail(st, rc);
+    }
+    return 0;
+}
+
+int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_bytes) {
+    if (!st) return set_err(nullptr, FADEHIP_E_INVALID, "stream is NULL");
+    fadehip_ctx *ctx = st->ctx;
+    if (!out || !out_bytes) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
+    *out = nullptr;
+    *out_bytes = 0;
+    fadehip_bam_stream::Out *o;
+    {
+        std::unique_lock<std::mutex> l(st->mu);
+        o = &st->ring[st->k_back % FADEHIP_BAM_CHUNKS];
+        if (o->state != 1) return set_err(ctx, FADEHIP_E_STATE, st->failed ? "bam stream: an earlier call failed" : "bam stream: no front call is waiting for back");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = 0;
+    if (o->bytes) {
+        const int lane = (int)(st->k_back & 1);  // the lanes in turn: a call's bytes stay valid during the next call
+        if ((rc = bgzf_lane_ready(ctx, lane))) return bam_fail(st, rc);
+        BgzfLane &l = ctx->bgzf[lane];
+        if (hipStreamWaitEvent(l.stream, o->ready, 0) != hipSuccess) return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: hipStreamWaitEvent failed"));
+        if ((rc = bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes)) || (rc = fadehip_bgzf_deflate_wait(ctx, lane, out, out_bytes))) return bam_fail(st, rc);
+    } else if (o->ready) {
+        (void)hipEventSynchronize(o->ready);
+    }
+    {
+        std::lock_guard<std::mutex> l(st->mu);
+        o->state = 0;
+        st->k_back++;
+    }
+    st->cv.notify_all();
+    return 0;
+}
+
+int fadehip_bam_totals(fadehip_bam_stream *st, int64_t stats[8], int64_t *n_records, int64_t *n_oversize) {
+    if (!st) return set_err(nullptr, FADEHIP_E_INVALID, "stream is NULL");
+    std::lock_guard<std::mutex> l(st->mu);
+    if (stats) memcpy(stats, st->stats, sizeof st->stats);
+    if (n_records) *n_records = st->n_records;
+    if (n_oversize) *n_oversize = st->n_oversize;
+    return 0;
+}
+
+void fadehip_bam_close(fadehip_bam_stream *st) {
+    if (!st) return;
+    {
+        std::lock_guard<std::mutex> l(st->mu);
+        st->closing = true;
+    }
+    st->cv.notify_all();
+    fadehip_ctx *ctx = st->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->slots[0].stream) (void)hipStreamSynchronize(ctx->slots[0].stream);
+    for (BgzfLane &l : ctx->bgzf)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+    ctx->slots[0].device_only = false;
+    ctx->slots[0].wide_all = false;
+    for (DevBuf *b : {&st->names_text, &st->names_off, &st->comp, &st->blocks, &st->status, &st->ticket, &st->u[0], &st->u[1], &st->seg, &st->slots,
+                      &st->rec_off, &st->info, &st->sent_of, &st->art_of, &st->out_size, &st->blk32, &st->blk64, &st->counts})
+        release(*b);
+    release(st->h_blocks);
+    release(st->h_counts);
+    for (auto &o : st->ring) {
+        release(o.o);
+        if (o.ready) (void)hipEventDestroy(o.ready);
+    }
+    delete st;
 }
 
 int fadehip_stats_allreduce(fadehip_ctx *const *ctxs, int n_ctx, int64_t *counters, int count) {

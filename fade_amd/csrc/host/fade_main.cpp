@@ -772,6 +772,265 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
     return 0;
 }
 
+// `fade annotate -b in.bam ref.fa` with the whole file path on the device (fadehip_bam_*): this process reads compressed
+// bytes and writes compressed bytes; inflate, framing, annotateTask, the tags and deflate are kernels.  Three threads
+// around the library's two halves: [reader: file -> pinned buffers, cut at BGZF member boundaries] -> [this thread:
+// front] -> [back thread: back] -> [writer thread: fwrite].  FADE_BAM_DEVICE=0 (or any input that is not a BAM file, any
+// output that is not BAM, --gpus N) takes the host pipeline of annotate_main instead.
+static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall_back) {
+    *fall_back = true;
+    const std::string &path = o.pos[1];
+    struct stat sb;
+    if (!o.bam || path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
+    StageClock ck_total, ck_fasta, ck_upload, ck_front, ck_back, ck_fwrite, ck_fread;
+    ck_total.start();
+    const int nthreads = o.threads > 0 ? o.threads : default_threads();
+    Pool pool(std::min(nthreads, 4));
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return 1;
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    // header; the member that holds the first record and the record's offset in its payload
+    Header hdr;
+    uint64_t coff = 0;
+    uint32_t first_rec = 0;
+    try {
+        Reader rd(path, &pool);
+        if (!rd.is_bam()) return 1;
+        hdr = rd.header();
+        const size_t hdr_bytes = rd.bam_header_bytes();
+        uint64_t at = 0, cum = 0;
+        for (;;) {
+            uint8_t h[18], t[4];
+            if (pread(fileno(f), h, 18, (off_t)at) != 18) return 1;
+            if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') return 1;  // (other gzip subfields first: the host path reads it)
+            const uint32_t bs = (uint32_t)(h[16] | (h[17] << 8)) + 1u;
+            if (pread(fileno(f), t, 4, (off_t)(at + bs - 4)) != 4) return 1;
+            const uint32_t isz = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (cum + isz > hdr_bytes || (uint64_t)at + bs >= (uint64_t)sb.st_size) { coff = at; first_rec = (uint32_t)(hdr_bytes - cum); break; }
+            cum += isz;
+            at += bs;
+        }
+        if (first_rec > 65536) return 1;
+    } catch (const std::exception &e) {
+        return 1;  // the host path reports what is wrong with the file
+    }
+    *fall_back = false;
+    if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (annotate begins; file path on the device)\n", since_process_start());
+    fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+    fadehip_ctx *ctx = nullptr;
+    fadehip_bam_stream *st = nullptr;
+    struct Guard {
+        fadehip_ctx *&c;
+        fadehip_bam_stream *&s;
+        std::vector<void *> pinned;
+        ~Guard() {
+            if (s) fadehip_bam_close(s);
+            for (void *p : pinned) fadehip_host_free(c, p);
+            fadehip_destroy(c);
+        }
+    } guard{ctx, st, {}};
+    try {
+        fadehip_params prm;
+        fadehip_params_default(&prm);
+        setenv("FADEHIP_TAIL_CUS", "0", 0);  // one batch at a time: no CU-masked stream, fewer queues
+        int device = 0;
+        if (const char *dm = getenv("FADE_DEVICE_MAP")) device = atoi(dm);
+        std::string create_err;
+        std::future<int> creating = std::async(std::launch::async, [&]() -> int {
+            if (fadehip_create(&ctx, device, &prm)) { create_err = fadehip_last_error(nullptr); return 1; }
+            return 0;
+        });
+        ck_fasta.start();
+        Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
+        ck_fasta.stop();
+        Header out_hdr = hdr;
+        out_hdr.add_pg("fade-annotate", "fade", FADE_VERSION, cl);  // anno.d:25-32
+        std::vector<int64_t> lens(hdr.names.size());
+        std::vector<const uint8_t *> ptrs(hdr.names.size());
+        for (size_t k = 0; k < hdr.names.size(); k++) {
+            size_t q = 0;
+            while (q < fa.names.size() && fa.names[q] != hdr.names[k]) q++;
+            if (q == fa.names.size()) { fprintf(stderr, "[E::fade annotate] reference %s of the BAM header is not in %s\n", hdr.names[k].c_str(), o.pos[2].c_str()); return 1; }
+            if ((int64_t)fa.seqs[q].size() < hdr.lens[k]) {
+                fprintf(stderr, "[E::fade annotate] %s is shorter in the FASTA (%zu) than in the header (%lld)\n", hdr.names[k].c_str(), fa.seqs[q].size(), (long long)hdr.lens[k]);
+                return 1;
+            }
+            lens[k] = hdr.lens[k];
+            ptrs[k] = (const uint8_t *)fa.seqs[q].data();
+        }
+        if (hdr.names.empty()) { fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n"); return 1; }
+        ck_upload.start();
+        if (creating.get()) { fprintf(stderr, "[E::fade annotate] cannot open the GPU path: %s\n", create_err.c_str()); return 1; }
+        if (fadehip_genome_upload(ctx, (int)lens.size(), lens.data(), ptrs.data())) { fprintf(stderr, "[E::fade annotate] genome upload: %s\n", fadehip_last_error(ctx)); return 1; }
+        std::vector<const char *> names;
+        for (auto &n : hdr.names) names.push_back(n.c_str());
+        fadehip_bam_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.floor_len = o.floor_len;
+        cfg.window = o.window;
+        cfg.n_ref = (int32_t)names.size();
+        cfg.ref_names = names.data();
+        cfg.first_record = first_rec;
+        if (fadehip_bam_open(ctx, &cfg, &st)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
+        ck_upload.stop();
+        fa.seqs.clear();
+        fa.seqs.shrink_to_fit();
+        // the header goes out through the CPU writer (its members only: no end-of-file block yet)
+        {
+            Writer hw(stdout, OutFmt::BAM, out_hdr, &pool, nullptr, true, false);
+            hw.close();
+        }
+        // ---- the stages
+        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : 64) << 20;
+        constexpr int NBUF = 3;
+        struct In { uint8_t *p = nullptr; size_t n = 0; bool last = false; };
+        In bufs[NBUF];
+        for (int k = 0; k < NBUF; k++) {
+            void *p = nullptr;
+            if (fadehip_host_alloc(ctx, chunk + 65536 + 64, &p)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
+            guard.pinned.push_back(p);
+            bufs[k].p = (uint8_t *)p;
+        }
+        BoundedQueue<int> q_free(NBUF + 1), q_full(NBUF + 1), q_done(FADEHIP_BAM_CHUNKS + 1);
+        struct OutRef { const uint8_t *p; size_t n; };
+        BoundedQueue<OutRef> q_write(1);  // (a call's bytes stay valid during the next back call only)
+        for (int k = 0; k < NBUF; k++) q_free.push(k);
+        std::string stage_err;
+        std::mutex err_m;
+        auto set_err = [&](const std::string &e) {
+            std::lock_guard<std::mutex> l(err_m);
+            if (stage_err.empty()) stage_err = e;
+        };
+        std::atomic<bool> abort_all{false};
+        StageThreads stages;
+        stages.unblock = [&] {
+            abort_all = true;
+            q_free.close(); q_full.close(); q_done.close(); q_write.close();
+        };
+        stages.th.emplace_back([&] {  // reader: whole members per buffer, the cut-off tail moves to the next buffer
+            try {
+                uint64_t at = coff;
+                size_t tail_n = 0;
+                std::vector<uint8_t> tail;
+                int k;
+                bool eof = false;
+                while (!eof && !abort_all && q_free.pop(k)) {
+                    In &b = bufs[k];
+                    if (tail_n) memcpy(b.p, tail.data(), tail_n);
+                    ck_fread.start();
+                    size_t got = tail_n;
+                    while (got < chunk) {
+                        const ssize_t r = pread(fileno(f), b.p + got, chunk - got, (off_t)at);
+                        if (r < 0) throw std::runtime_error("read error on " + path);
+                        if (r == 0) { eof = true; break; }
+                        got += (size_t)r;
+                        at += (uint64_t)r;
+                    }
+                    ck_fread.stop();
+                    // whole members
+                    size_t w = 0;
+                    while (w + 18 <= got) {
+                        const uint8_t *m = b.p + w;
+                        if (m[0] != 0x1f || m[1] != 0x8b) throw std::runtime_error("not a BGZF member in " + path);
+                        const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
+                        if (w + 12 + xlen > got) break;
+                        size_t bs = 0;
+                        for (size_t x = 12; x + 4 <= 12 + xlen;) {
+                            const size_t sl = (size_t)m[x + 2] | ((size_t)m[x + 3] << 8);
+                            if (m[x] == 'B' && m[x + 1] == 'C' && sl == 2 && x + 6 <= 12 + xlen) bs = ((size_t)m[x + 4] | ((size_t)m[x + 5] << 8)) + 1;
+                            x += 4 + sl;
+                        }
+                        if (bs < 12 + xlen + 10) throw std::runtime_error("BGZF member without a usable BC subfield in " + path);
+                        if (w + bs > got) break;
+                        w += bs;
+                    }
+                    if (eof && w != got) throw std::runtime_error("the file ends inside a BGZF member: " + path);
+                    tail_n = got - w;
+                    tail.assign(b.p + w, b.p + got);
+                    b.n = w;
+                    b.last = eof;
+                    q_full.push(k);
+                }
+            } catch (const std::exception &e) {
+                set_err(e.what());
+            }
+            q_full.close();
+        });
+        stages.th.emplace_back([&] {  // back: compress, hand to the writer
+            int tok;
+            try {
+                while (q_done.pop(tok)) {
+                    const uint8_t *p = nullptr;
+                    size_t n = 0;
+                    ck_back.start();
+                    const int rc = fadehip_bam_back(st, &p, &n);
+                    ck_back.stop();
+                    if (rc) throw std::runtime_error(std::string("device: ") + fadehip_last_error(ctx));
+                    q_write.push(OutRef{p, n});
+                }
+            } catch (const std::exception &e) {
+                set_err(e.what());
+                abort_all = true;
+                while (q_done.pop(tok)) {}
+            }
+            q_write.close();
+        });
+        stages.th.emplace_back([&] {  // writer
+            OutRef r;
+            bool ok = true;
+            while (q_write.pop(r)) {
+                if (!ok || !r.n) continue;
+                ck_fwrite.start();
+                if (fwrite(r.p, 1, r.n, stdout) != r.n) { set_err("write error on the output stream"); ok = false; abort_all = true; }
+                ck_fwrite.stop();
+            }
+        });
+        int k;
+        bool failed = false;
+        while (!failed && !abort_all && q_full.pop(k)) {
+            ck_front.start();
+            const int rc = fadehip_bam_front(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0);
+            ck_front.stop();
+            if (rc) { set_err(std::string("device: ") + fadehip_last_error(ctx)); failed = true; break; }
+            q_free.push(k);
+            q_done.push(0);
+        }
+        q_done.close();
+        if (failed) { abort_all = true; q_free.close(); while (q_full.pop(k)) {} }
+        for (auto &t : stages.th) t.join();
+        stages.unblock = nullptr;
+        if (!stage_err.empty()) { fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str()); return 1; }
+        fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout);
+        fflush(stdout);
+        int64_t totals[8], n_rec = 0, n_over = 0;
+        fadehip_bam_totals(st, totals, &n_rec, &n_over);
+        if (n_over) fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read longer than %d bases or window longer than %d\n",
+                            (long long)n_over, FADEHIP_MAX_LONG_QUERY, prm.max_ref_len);
+        if (o.stats) {  // stats.d:56-72 layout
+            const double rc = (double)std::max<int64_t>(totals[0], 1);
+            fprintf(stderr, "read count:\t%lld\nClipped %%:\t%g\n%% With Supplementary alns:\t%g\nArtifact rate:\t%g\n"
+                            "%% With Supplementary alns and artifacts:\t%g\nArtifact rate left only:\t%g\nArtifact rate right only:\t%g\n",
+                    (long long)totals[0], totals[1] / rc, totals[2] / rc, totals[4] / rc, totals[3] / rc, totals[6] / rc, totals[7] / rc);
+        }
+        ck_total.stop();
+        if (o.timing) {
+            fprintf(stderr, "[timing] total %.3f s: fasta %.3f, create+genome upload %.3f | reader: file reads %.3f | front (inflate, frame, annotate, tags) %.3f | "
+                            "back (deflate, copy out) %.3f | fwrite %.3f (stages overlap); %lld records\n",
+                    ck_total.t, ck_fasta.t, ck_upload.t, ck_fread.t, ck_front.t, ck_back.t, ck_fwrite.t, (long long)n_rec);
+        }
+        if (!(getenv("FADE_FAST_EXIT") && atoi(getenv("FADE_FAST_EXIT")) == 0)) {
+            if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (leaving by _exit)\n", since_process_start());
+            fflush(stdout);
+            fflush(stderr);
+            _exit(0);
+        }
+    } catch (const std::exception &e) {
+        fprintf(stderr, "[E::fade annotate] %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
 static int annotate_main(const std::string &cl, const Opts &o) {
     StageClock ck_total, ck_fasta, ck_upload, ck_read, ck_pack, ck_submit, ck_collect, ck_tags, ck_write;
     ck_total.start();
@@ -1555,6 +1814,12 @@ int main(int argc, char **argv) {
             bool fall_back = true;
             const int lrc = annotate_lanes_main(cl, o, &fall_back);
             if (lrc == 0 || !fall_back) return lrc;
+        }
+        // BAM file in, BAM out, one device: the file path on the device (FADE_BAM_DEVICE=0: the host pipeline)
+        if (o.bam && o.gpus <= 1 && !lane_env().on && !(getenv("FADE_BAM_DEVICE") && atoi(getenv("FADE_BAM_DEVICE")) == 0)) {
+            bool fall_back = true;
+            const int src = annotate_stream_main(cl, o, &fall_back);
+            if (src == 0 || !fall_back) return src;
         }
         const int rc = annotate_main(cl, o);
         if (o.timing) {

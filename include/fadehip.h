@@ -260,6 +260,55 @@ int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t co
 int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, size_t n_bytes);
 int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, size_t *out_bytes);
 
+/* ------------------------------------------------------ BGZF decompression of the input stream -- */
+/* What htslib's bgzf_read + zlib's inflate do under dhtslib's SAMReader for `bam.allRecords` (anno.d:44): whole BGZF
+ * members in, their payloads out, in order and contiguous.  On the device: one wavefront per member (a DEFLATE stream
+ * decodes serially; a file has tens of thousands of members), tables in LDS, CRC32 and ISIZE of every trailer checked.
+ * members[0, n_bytes) must hold whole members only (a reader cuts at member boundaries: BSIZE of the BC subfield);
+ * out receives at most out_cap bytes, *out_bytes their number.  Synchronous (H2D, kernel, D2H); the streaming file path
+ * (fadehip_bam_*) keeps the bytes on the device instead.  A malformed member or a corrupt stream: FADEHIP_E_INVALID
+ * with the member's index and the reason in fadehip_last_error. */
+int fadehip_bgzf_inflate(fadehip_ctx *ctx, const void *members, size_t n_bytes, void *out, size_t out_cap, size_t *out_bytes);
+
+/* ------------------------------------------------------ the file path on the device: BGZF in, BGZF out -- */
+/* anno.d:44-50 as a byte stream: `foreach(rec; bam.allRecords) { annotateTask(rec); out.write(rec); }` with the reader's
+ * inflate, the record framing, annotateTask (the level-2 kernels), the tag updates of anno.d:63,94-107 and the writer's
+ * deflate all on the device.  The host reads compressed bytes from the input file and writes compressed bytes to the
+ * output file; 1.0 byte in and about as much out cross PCIe per compressed byte of the file, nothing else.
+ *
+ * The caller parses the BAM header itself (it needs the contig names for fadehip_genome_upload anyway), writes the
+ * output's header members itself, and then passes the input's members from the one that holds the first record on
+ * (first_record = bytes of that member's payload in front of the first record: the BGZF virtual offset's low 16 bits).
+ *   front : whole BGZF members of the input (any number; cut where the caller likes — records may span members and
+ *           calls).  Inflates, frames, annotates and rewrites the records that are complete; the tail of a record cut by
+ *           the end of the call is kept for the next one.  Returns when the records' new bytes are on the device (the call
+ *           waits for the device three times: sizes come back, buffers are sized, the next kernels go out).
+ *   back  : compresses what the oldest finished front call produced and returns the BGZF members in pinned memory, valid
+ *           until the back call AFTER the next (a writer thread may still be writing them while the next call compresses).  Outputs come in input order.  Without a finished front call waiting: FADEHIP_E_STATE
+ *           (it never blocks for one).
+ * front and back may run on two threads (one each): while back compresses chunk k, front works on chunk k+1; front
+ * blocks while FADEHIP_BAM_CHUNKS finished chunks await back (a single-threaded caller alternates front and back).  A record already carrying rs / am / as / ar / ab is updated the way
+ * htslib's bam_aux_update_* do (first occurrence: in place or replaced at its position).  Errors (corrupt member,
+ * impossible record, input ending inside a record when last != 0) fail the call and every later one.
+ * The genome must have been uploaded (fadehip_genome_upload); the stream uses the ctx's slot 0 and both BGZF lanes. */
+typedef struct fadehip_bam_stream fadehip_bam_stream;
+typedef struct fadehip_bam_config {
+    int32_t floor_len;            /* --min-length (anno.d: artifact_floor_length) */
+    int32_t window;               /* -w (align_buffer_size) */
+    int32_t n_ref;                /* contigs of the BAM header: refID is checked against it, ref_names[refID] goes into am */
+    int32_t reserved;
+    const char *const *ref_names; /* [n_ref] NUL-terminated */
+    uint32_t first_record;        /* payload bytes of the first member passed to front that precede the first record */
+    uint32_t reserved2;
+} fadehip_bam_config;
+#define FADEHIP_BAM_CHUNKS 3
+int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out);
+int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_bytes, int last);
+int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_bytes);
+/* totals so far: the eight Stats.parse counters (stats.d:45-54), records, reads beyond the kernels' limits */
+int fadehip_bam_totals(fadehip_bam_stream *st, int64_t stats[8], int64_t *n_records, int64_t *n_oversize);
+void fadehip_bam_close(fadehip_bam_stream *st);
+
 /* Sum counters over the ranks' devices with one ncclAllReduce (RCCL) — single process, one ctx
  * per device.  counters is [n_ctx][count] in, every row holds the sum on return. */
 int fadehip_stats_allreduce(fadehip_ctx *const *ctxs, int n_ctx, int64_t *counters, int count);

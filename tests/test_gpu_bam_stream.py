@@ -1,0 +1,183 @@
+"""The file path on the device (include/fadehip.h fadehip_bam_*; fade_amd/csrc/bam_device.hpp, bgzf_inflate.hpp,
+bgzf_deflate.hpp): `fade annotate -b in.bam ref.fa` with inflate, record framing, annotateTask, the tags of
+anno.d:63,94-107 and deflate all on the device.  The checker is the host pipeline (FADE_BAM_DEVICE=0), itself held to the
+oracle's golden records by tests/test_gpu_cli.py: the two outputs must inflate to the SAME BYTES — header, every record,
+every tag, in order."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import fade_amd
+import samutil
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FADE = os.path.join(ROOT, "fade_amd", "fade")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([FADE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+
+
+def _bam_of(sam, path):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s", "sam2bam"])
+    with open(path, "wb") as fo:
+        subprocess.check_call([os.path.join(ROOT, "tools", "sam2bam"), str(sam)], stdout=fo)
+
+
+def _params(tag):
+    for line in open(os.path.join(GOLD, tag + ".expected.tsv")):
+        if line.startswith("#floor_len"):
+            p = dict(kv.split("=") for kv in line[1:].split())
+            return int(p["floor_len"]), int(p["window"])
+    raise AssertionError(tag)
+
+
+def _members(buf):
+    out, at = [], 0
+    while at < len(buf):
+        bsize = struct.unpack_from("<H", buf, at + 16)[0] + 1
+        out.append(buf[at:at + bsize])
+        at += bsize
+    return out
+
+
+@pytest.mark.parametrize("tag", ["anno_c1", "anno_c2", "anno_c5", "anno_floor0"])
+def test_device_file_path_equals_the_host_pipeline_on_the_golden_inputs(tmp_path, tag):
+    floor_len, window = _params(tag)
+    bam = tmp_path / "in.bam"
+    _bam_of(os.path.join(GOLD, tag + ".sam"), bam)
+    base = ["annotate", "--stats", "--timing", "--min-length", str(floor_len), "-w", str(window), "-b", str(bam), os.path.join(GOLD, tag + ".fa")]
+    dev = _run(base)
+    host = _run(base, {"FADE_BAM_DEVICE": "0"})
+    assert dev.returncode == 0, dev.stderr.decode()[-2000:]
+    assert host.returncode == 0, host.stderr.decode()[-2000:]
+    assert b"file path on the device" in dev.stderr and b"file path on the device" not in host.stderr
+    assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
+    assert dev.stdout.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
+    assert stats(dev.stderr) == stats(host.stderr) and len(stats(dev.stderr)) == 7
+    # a second pass over the annotated file: every record carries rs (and some am / as / ar / ab) already — htslib's
+    # update-in-place semantics on the device, again equal to the host's
+    again = tmp_path / "anno.bam"
+    again.write_bytes(dev.stdout)
+    base2 = base[:-2] + [str(again), base[-1]]
+    dev2 = _run(base2)
+    host2 = _run(base2, {"FADE_BAM_DEVICE": "0"})
+    assert dev2.returncode == 0 and host2.returncode == 0, dev2.stderr.decode()[-2000:]
+    assert gzip.decompress(dev2.stdout) == gzip.decompress(host2.stdout)
+    _, _, r1 = samutil.bam_to_sam_records(dev.stdout)
+    _, _, r2 = samutil.bam_to_sam_records(dev2.stdout)
+    assert r1 == r2
+
+
+@pytest.fixture(scope="module")
+def big(tmp_path_factory):
+    """30,000 reads of C5 (30 % soft-clipped) as a BAM of ~130 BGZF members, records straddling them."""
+    from fade_amd import synth
+    d = tmp_path_factory.mktemp("bamstream")
+    cfg, g, b = synth.make_config("C5", 30000, contig_len=400_000)
+    names = ["read%d" % (i // 2) for i in range(len(b["pos"]))]
+    b["qname"] = names
+    sam, fa, bam = d / "in.sam", d / "ref.fa", d / "in.bam"
+    sam.write_text(samutil.batch_to_sam(b, g.names, [int(x) for x in g.lengths], names))
+    fa.write_bytes(g.fasta_bytes())
+    p = _run(["out", "-b", str(sam)])
+    assert p.returncode == 0, p.stderr.decode()
+    bam.write_bytes(p.stdout)
+    host = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", str(bam), str(fa)], {"FADE_BAM_DEVICE": "0"})
+    assert host.returncode == 0, host.stderr.decode()[-2000:]
+    return dict(bam=bam, fa=fa, host=host, g=g)
+
+
+@pytest.mark.parametrize("chunk_mb", ["1", "64"])
+def test_records_that_straddle_members_and_calls(big, chunk_mb):
+    dev = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", str(big["bam"]), str(big["fa"])], {"FADE_BAM_CHUNK_MB": chunk_mb})
+    assert dev.returncode == 0, dev.stderr.decode()[-2000:]
+    assert b"file path on the device" in dev.stderr
+    assert gzip.decompress(dev.stdout) == gzip.decompress(big["host"].stdout)
+    stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
+    assert stats(dev.stderr) == stats(big["host"].stderr)
+
+
+def test_stream_api_one_member_per_call(big):
+    """The C ABI itself, fed the smallest pieces it takes: one BGZF member per front call (most records then straddle calls),
+    front and back alternating on one thread."""
+    raw = big["bam"].read_bytes()
+    payload = gzip.decompress(raw)
+    # the BAM header: magic, l_text, text, n_ref, (l_name, name, l_ref)*
+    assert payload[:4] == b"BAM\1"
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    names = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", payload, at)[0]
+        names.append(payload[at + 4:at + 4 + ln - 1].decode())
+        at += 4 + ln + 4
+    hdr_bytes = at
+    ms = _members(raw)
+    cum, k = 0, 0
+    while cum + struct.unpack_from("<I", ms[k], len(ms[k]) - 4)[0] <= hdr_bytes:
+        cum += struct.unpack_from("<I", ms[k], len(ms[k]) - 4)[0]
+        k += 1
+    g = big["g"]
+    ctx = fade_amd.Context(device=0)
+    try:
+        ctx.genome_upload(g.names, g.ascii_contigs())
+        st = ctx.bam_stream(names, floor_len=5, window=100, first_record=hdr_bytes - cum)
+        body = ms[k:]
+        if len(body[-1]) == 28:  # the end-of-file member: an empty payload, passed like any other
+            pass
+        out = []
+        for j, m in enumerate(body):
+            st.front(m, last=(j == len(body) - 1))
+            out.append(st.back())
+        with pytest.raises(fade_amd.FadeHipError):
+            st.back()  # nothing pending: an error, not a wait
+        totals, n_rec, n_over = st.totals()
+        st.close()
+    finally:
+        ctx.close()
+    got = gzip.decompress(b"".join(out))
+    want = gzip.decompress(big["host"].stdout)
+    # the host run's output starts with its header (with the @PG line the CLI adds); the records behind it must be equal
+    l_text_w = struct.unpack_from("<i", want, 4)[0]
+    w_at = 8 + l_text_w
+    n_ref_w = struct.unpack_from("<i", want, w_at)[0]
+    w_at += 4
+    for _ in range(n_ref_w):
+        w_at += 4 + struct.unpack_from("<i", want, w_at)[0] + 4
+    assert got == want[w_at:]
+    assert n_rec == 30000 and totals[0] == 30000 and n_over == 0
+
+
+def test_corrupt_inputs_fail_the_run(tmp_path, big):
+    raw = bytearray(big["bam"].read_bytes())
+    # a flipped bit in the middle of a member's DEFLATE stream
+    ms = _members(bytes(raw))
+    at = sum(len(m) for m in ms[:40]) + 30
+    raw[at] ^= 0x10
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(bytes(raw))
+    p = _run(["annotate", "-b", "-w", "100", str(bad), str(big["fa"])])
+    assert p.returncode != 0 and b"[E::fade annotate]" in p.stderr
+    # a file cut inside a member, and one cut between members but inside a record
+    whole = big["bam"].read_bytes()
+    cut1 = tmp_path / "cut1.bam"
+    cut1.write_bytes(whole[:len(whole) // 2])
+    p = _run(["annotate", "-b", "-w", "100", str(cut1), str(big["fa"])])
+    assert p.returncode != 0
+    cut2 = tmp_path / "cut2.bam"
+    cut2.write_bytes(b"".join(ms[:50]))
+    p = _run(["annotate", "-b", "-w", "100", str(cut2), str(big["fa"])])
+    assert p.returncode != 0 and b"inside a record" in p.stderr
