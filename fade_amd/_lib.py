@@ -31,7 +31,7 @@ EXPORTS = [
     "fadehip_annotate_results", "fadehip_annotate_collect",
     "fadehip_sync", "fadehip_last_run_profile", "fadehip_stats_allreduce",
     "fadehip_bgzf_deflate_submit", "fadehip_bgzf_deflate_wait", "fadehip_stats_allreduce_rank", "fadehip_bgzf_inflate",
-    "fadehip_bam_open", "fadehip_bam_front", "fadehip_bam_back", "fadehip_bam_totals", "fadehip_bam_close",
+    "fadehip_bam_open", "fadehip_bam_front", "fadehip_bam_front_raw", "fadehip_bam_back", "fadehip_bam_totals", "fadehip_bam_close",
 ]
 BGZF_BLOCK = 0xff00
 BGZF_LANES = 2
@@ -132,6 +132,7 @@ def load():
     L.fadehip_bgzf_inflate.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fadehip_bam_open.argtypes = [vp, C.POINTER(BamConfig), C.POINTER(vp)]
     L.fadehip_bam_front.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.fadehip_bam_front_raw.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.fadehip_bam_back.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fadehip_bam_totals.argtypes = [vp, C.POINTER(i64 * 8), C.POINTER(i64), C.POINTER(i64)]
     L.fadehip_bam_close.argtypes = [vp]

@@ -433,6 +433,10 @@ class BamStream:
         arr = np.frombuffer(members, dtype=np.uint8) if isinstance(members, (bytes, bytearray, memoryview)) else np.ascontiguousarray(members, dtype=np.uint8)
         self._ctx._chk(self._L.fadehip_bam_front(self._h, arr.ctypes.data if arr.nbytes else None, arr.nbytes, 1 if last else 0))
 
+    def front_raw(self, payload, last=False):
+        arr = np.frombuffer(payload, dtype=np.uint8) if isinstance(payload, (bytes, bytearray, memoryview)) else np.ascontiguousarray(payload, dtype=np.uint8)
+        self._ctx._chk(self._L.fadehip_bam_front_raw(self._h, arr.ctypes.data if arr.nbytes else None, arr.nbytes, 1 if last else 0))
+
     def back(self):
         p, n = C.c_void_p(), C.c_size_t(0)
         self._ctx._chk(self._L.fadehip_bam_back(self._h, C.byref(p), C.byref(n)))

@@ -6,7 +6,7 @@
 //   anno.d:61-65 does not settle)  --[gate, score pass, pass 2: fadehip_kernels.hpp]-->  rs, alignments
 //   --tag sizes, scan-->  output offsets  --rewrite-->  output bytes O (records + rs / am / as / ar / ab)  --> compressor
 //
-// Framing.  BAM records are chained by block_size; following the chain is serial, so it is done speculatively per 16 KB
+// Framing.  BAM records are chained by block_size; following the chain is serial, so it is done speculatively per 64 KB
 // segment: a wave looks for the first position in its segment that looks like a record (block_size, refID, pos,
 // l_read_name, n_cigar_op, l_seq, next_refID, next_pos consistent with each other and with the header, name
 // NUL-terminated) and walks the chain from there; a single wave then checks, segment by segment, that the chain really
@@ -28,7 +28,7 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return *reinterpret
 __device__ __forceinline__ int32_t ld32s(const uint8_t *p) { return *reinterpret_cast<const i32u *>(p); }
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return *reinterpret_cast<const u16u *>(p); }
 
-constexpr uint32_t SEG = 16384;                 // framing segment
+constexpr uint32_t SEG = 65536;                 // framing segment (the resolving wave takes ~250 ns per segment: 0.5 ms per 128 MB)
 constexpr uint32_t SEG_SLOTS = SEG / 36 + 2;    // record starts a segment can hold (a record takes at least 36 bytes)
 constexpr uint32_t EXIT_INCOMPLETE = 0x80000000u, EXIT_BAD = 0x40000000u, EXIT_MASK = 0x3fffffffu;
 constexpr uint32_t MAX_U = 0x3fffff00u;         // inflated bytes per chunk (offsets are 30 bits + two flags)

@@ -1,6 +1,8 @@
-// bgzf_deflate.hpp — BGZF (SAM spec §4.1) compression on gfx950: one 1024-thread workgroup per BGZF block of up to 0xff00
-// input bytes, the whole block resident in LDS (153 KB of the CU's 160 KB: one workgroup per CU, 256 blocks in flight;
-// the LDS footprint leaves room for one workgroup only, so the sixteen waves that hide its latencies come from that one).
+// bgzf_deflate.hpp — BGZF (SAM spec §4.1) compression on gfx950: one 512-thread workgroup per BGZF block of up to 0x7f00
+// input bytes, the whole block resident in LDS (80 KB: TWO workgroups per CU, 512 blocks in flight).  A block's time is
+// set by the serial roles of phase A (one wave each), so what a CU gains from a second block is a second pipeline; with
+// 0xff00-byte blocks (160 KB, one workgroup per CU: round 3's first form) the same kernel ran at 9.8 GB/s.  The smaller
+// footprint also lets other kernels (the inflater, the record kernels of the file path) share a CU with a compressor.
 //
 // What it replaces: htslib's bgzf_write -> zlib deflate behind `SAMWriter(..., SAMWriterTypes.BAM)` (source/util.d:65-76),
 // i.e. the serialised write at source/anno.d:47-49 — 7 of the 12.7 core-seconds `fade annotate` spent per 10 M reads.
@@ -24,922 +26,26 @@
 #include <stdint.h>
 #include "bgzf_huff.hpp"
 
+// Two geometries of the same kernels.  64: htslib's 0xff00-byte blocks, the block and its tables fill the CU's LDS, one
+// workgroup per CU — the smallest output (a block's dynamic-Huffman header and its cold start weigh half as much).  32:
+// 0x7f00-byte blocks, 80 KB of LDS, two workgroups per CU — a block's time is set by the serial roles of phase A, so a CU
+// gains a second pipeline (9.8 -> 14.6 GB/s, 18 GB/s in the kernel) and other kernels can share a CU with a compressor;
+// the output is 0.5 % larger on uniform-quality BAM payload and 1 % larger where qualities run (there a member shrinks
+// to 8 KB and its header shows).  fadehip.hip picks per call: 32 while the stream is mostly incompressible bases
+// (ratio above 0.45), 64 otherwise, so that the output stays below zlib -6's in both regimes.
+#define FADEHIP_BGZF_GEOM 64
+#define FADEHIP_BGZF_NS bgzf64
+#include "bgzf_deflate_body.hpp"
+#undef FADEHIP_BGZF_GEOM
+#undef FADEHIP_BGZF_NS
+#define FADEHIP_BGZF_GEOM 32
+#define FADEHIP_BGZF_NS bgzf32
+#include "bgzf_deflate_body.hpp"
+#undef FADEHIP_BGZF_GEOM
+#undef FADEHIP_BGZF_NS
+
 namespace fadehip {
 namespace bgzf {
-
-constexpr int BLOCK = 0xff00;  // input bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
-constexpr int WG = 512;   // 8 waves: hasher, six extenders, parser.  Measured: 768 threads (ten extenders, 168 VGPRs, 11 spilled) and
-                          // 1024 (fourteen, 128 VGPRs, 41 spilled) are slower: the serial roles set the pace, and spills sit in their fences
-constexpr int DIST_T0 = 320;  // threads DIST_T0 .. + 29 serve the distance alphabet where the first 286 serve literals / lengths
-constexpr int N_WAVES = WG / 64;
-constexpr int HASH_BITS = 12, WAYS = 4;
-constexpr int MAX_MATCHES = 8192;
-constexpr int MIN_MATCH = 4, MAX_MATCH = 258;
-constexpr int N_WORDS = (BLOCK + 31) / 32;   // words of a per-position bitmap
-constexpr int WPT = (N_WORDS + WG - 1) / WG;  // ... per thread in the per-range phases (a range = 64 positions)
-constexpr int SLOT = 65536;                  // bytes of a block's output slot (payload <= 65510: BSIZE is 16 bits)
-constexpr int MAX_PAYLOAD = 65536 - 26;
-
-// LDS layout (bytes)
-constexpr int R1 = 8, R2 = 24;  // slots of phase A's candidate ring (64 x 8 bytes each) and length ring (64 x 4)
-constexpr int L_DATA = 0, L_HEAD = 65536, L_MATCH = L_HEAD + 32768, L_TOK = L_MATCH + 32768, L_MAT = L_TOK + 8192,
-              L_MISC = L_MAT + 8192, L_CRING = L_MISC + 6144, L_LRING = L_CRING + R1 * 512, LDS_BYTES = L_LRING + R2 * 256;
-static_assert(LDS_BYTES <= 160 * 1024, "one workgroup must fit the CU's LDS");
-// ... of the head region once the matches are found
-constexpr int H_MPRE = 0, H_H8 = 8192, H_AL = H_H8 + 8 * 320 * 4, H_SL = H_AL + 320 * 4, H_AD = H_SL + 320 * 4, H_SD = H_AD + 64 * 4,
-              H_CRCT = H_SD + 64 * 4, H_END = H_CRCT + 4096;
-static_assert(H_END <= 32768, "phase B temporaries must fit the hash region");
-
-struct Misc {  // the small arrays of a block
-    uint32_t abort, dbg[3], carry, mcount, full, blk, m_l, m_d, hdr_bits, total_bits, stored, pad[3];
-    uint32_t freq_l[320], freq_d[64];
-    uint8_t ll[320], dl[64];
-    uint16_t lc[320], dc[64];
-    uint32_t hdr[160];
-    uint32_t bl_l[16], bl_d[16], nc_l[16], nc_d[16];
-    uint32_t x2n[32];
-    uint32_t sortbuf[64];
-    uint32_t wtmp[N_WAVES];
-    uint32_t crc_part[N_WAVES];
-    // phase A's rings (see there): sequence / free numbers per slot, the extenders' ticket
-    uint32_t cand_seq[R1], cand_free[R1], lens_seq[R2], lens_free[R2], ext_ticket;
-    // the header's run-length tokens (symbol | extra << 8) and the code-length alphabet
-    uint16_t cltok[320];
-    uint32_t cl_freq[NUM_CL + 1], cl_len[NUM_CL + 1], cl_code[NUM_CL + 1], cl_n, cl_hlit, cl_hdist, cl_hclen;
-};
-static_assert(sizeof(Misc) <= 6144, "Misc outgrew its slice");
-
-struct DeflateArgs {
-    const uint8_t *src;   // the byte stream (device)
-    uint64_t n_bytes;
-    uint32_t n_blocks;
-    uint8_t *slots;       // [n_blocks][SLOT]
-    uint32_t *out_size;   // [n_blocks] payload bytes
-    uint32_t *out_crc;    // [n_blocks]
-    uint32_t *ticket;     // blocks are drawn from here
-    unsigned long long *prof;  // optional [8]: shader clocks per phase, summed over blocks by lane 0 (FADEHIP_BGZF_PROF)
-};
-
-__device__ __forceinline__ uint32_t lds_load32u(const uint8_t *base, uint32_t p) {  // 4 bytes at any offset
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(base) + (p >> 2);
-    return __builtin_amdgcn_alignbyte(w[1], w[0], p & 3u);
+using bgzf64::claim_ticket;  // (the inflater draws its tickets the same way)
 }
-__device__ __forceinline__ uint64_t lds_load64u(const uint8_t *base, uint32_t p) {  // 8 bytes at any offset
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(base) + (p >> 2);
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-    return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, p & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, p & 3u) << 32);
-}
-__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
-
-// Waits for *turn == v.  Every wait of the pipeline is bounded: a wait that outlasts SPIN_LIMIT polls (a hundred times
-// the longest legitimate one) raises the block's abort flag, which ends every other wait and every role's loop too, so
-// that the workgroup always drains; the block is then reported as failed (out_size = ~0) instead of hanging the device.
-constexpr uint32_t SPIN_LIMIT = 1u << 18;
-// (Every value the loop branches on goes through v_readfirstlane: the waits are wave-uniform by construction, and the
-// compiler must know it — with per-lane exit conditions it nests the roles' loops around exec masks, and a back edge of
-// that nest re-used a stale ticket: two extenders on one piece.)
-__device__ __forceinline__ bool spin_until(uint32_t *turn, uint32_t v, uint32_t *abort_flag, uint32_t who) {
-    uint32_t polls = 0;
-    for (;;) {
-        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (x == v) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++polls & 255u) == 0) {
-            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
-            if (polls >= SPIN_LIMIT) {
-                abort_flag[1] = x;  // (dbg: what it saw ...
-                abort_flag[2] = v;  //  ... and wanted)
-                abort_flag[3] = (uint32_t)(threadIdx.x >> 6);
-                __hip_atomic_store(abort_flag, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return false;
-            }
-        }
-    }
-}
-// the next ticket of a wave-shared counter, as a wave-uniform value (kept out of line: inlined into the extenders' loop the
-// claim was hoisted around the loop's exec-mask bookkeeping and a back edge re-used a stale ticket)
-__device__ __noinline__ int claim_ticket(uint32_t *counter) {
-    uint32_t tk = 0;
-    if ((threadIdx.x & 63) == 0) tk = atomicAdd(counter, 1u);
-    return __builtin_amdgcn_readlane((int)tk, 0);
-}
-__device__ __forceinline__ void publish(uint32_t *turn, uint32_t v) {
-    __hip_atomic_store(turn, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// exclusive scan of one value per thread over the workgroup (tmp: N_WAVES words of LDS); *total = the sum
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    __syncthreads();  // tmp may still be read from an earlier scan
-    if (lane == 63) tmp[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, sum = 0;
-#pragma unroll
-    for (int w = 0; w < N_WAVES; w++) {
-        const uint32_t t = tmp[w];
-        if (w < wave) base += t;
-        sum += t;
-    }
-    *total = sum;
-    return base + inc - v;
-}
-
-// An array of up to 64 NR entries spread over the lanes of a wavefront (entry i in lane i % 64 of register i / 64), read
-// and written with v_readlane / v_writelane by code the whole wave runs in lockstep on wave-uniform indices: the accessor
-// the serial Huffman routines of bgzf_huff.hpp take on the device (a dependent LDS round trip costs ~130 clocks, a lane
-// access ~10, and those routines are chains of dependent accesses).
-template <int NR>
-struct WaveArr {
-    uint32_t r[NR];
-    __device__ __forceinline__ uint32_t get(int i) const {  // i is wave-uniform
-        const int k = i >> 6, l = i & 63;
-        uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)r[0], l);
-#pragma unroll
-        for (int j = 1; j < NR; j++)
-            if (k == j) v = (uint32_t)__builtin_amdgcn_readlane((int)r[j], l);
-        return v;
-    }
-    __device__ __forceinline__ void set(int i, uint32_t v) {  // i and v are wave-uniform
-        const int k = i >> 6, l = i & 63;
-#pragma unroll
-        for (int j = 0; j < NR; j++)
-            if (k == j) asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r[j]) : "s"(v), "s"(l) : "m0");  // (one SGPR per VALU instruction)
-    }
-};
-// bit sink of the header: whole words to LDS by lane 0, the accumulator wave-uniform
-struct LdsSink {
-    uint32_t *w;
-    uint64_t acc = 0;
-    int cnt = 0;
-    uint32_t wi = 0;
-    __device__ __forceinline__ void put(uint32_t v, int n) {
-        acc |= (uint64_t)v << cnt;
-        cnt += n;
-        if (cnt >= 32) {
-            if ((threadIdx.x & 63) == 0) w[wi] = (uint32_t)acc;
-            wi++;
-            acc >>= 32;
-            cnt -= 32;
-        }
-    }
-    __device__ __forceinline__ uint32_t finish() {
-        if (cnt && (threadIdx.x & 63) == 0) w[wi] = (uint32_t)acc;
-        return 32u * wi + (uint32_t)cnt;
-    }
-};
-
-// bits of the token that starts at bit b of bitmap word w (a literal, or the match whose record the match bitmap counts to)
-__device__ __forceinline__ void token_bits(const uint8_t *data, uint32_t mw, uint32_t mbase, const uint32_t *match, const Misc *ms, int w, int b,
-                                           uint64_t &bits, int &nb) {
-    if ((mw >> b) & 1u) {
-        const uint32_t rec = match[mbase + (uint32_t)__builtin_popcount(mw & ((1u << b) - 1u))];
-        const Sym ls = length_symbol((rec >> 16) + 3u), ds = dist_symbol(rec & 0xffffu);
-        uint64_t v = ms->lc[ls.sym];
-        int k = ms->ll[ls.sym];
-        v |= (uint64_t)ls.eval << k;
-        k += (int)ls.ebits;
-        v |= (uint64_t)ms->dc[ds.sym] << k;
-        k += ms->dl[ds.sym];
-        v |= (uint64_t)ds.eval << k;
-        k += (int)ds.ebits;
-        bits = v;
-        nb = k;
-    } else {
-        const uint32_t c = data[32 * w + b];
-        bits = ms->lc[c];
-        nb = ms->ll[c];
-    }
-}
-
-// ---- phase A's three roles (inlined: out of line they measured a third slower)
-struct RoleArgs {
-    uint8_t *data;
-    uint16_t *head;
-    uint32_t *match, *tokw, *matw;
-    Misc *ms;
-    uint2 *cand_ring;
-    uint32_t *lens_ring;
-    int n, n_pieces, lane;
-    unsigned long long *prof;  // optional: [60 + 2 role] clocks waited, [61 + 2 role] clocks in the role (summed over waves)
-};
-__device__ __forceinline__ void role_hasher(const RoleArgs r) {
-    uint8_t *const data = r.data; uint16_t *const head = r.head; Misc *const ms = r.ms; uint2 *const cand_ring = r.cand_ring;
-    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
-    unsigned long long t_wait = 0;
-    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
-    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
-        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
-        const bool ok = spin_until(turn, v, ab, who);
-        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
-        return ok;
-    };
-    bool live = true;  // (wave-uniform; an aborted role runs its loop out without waiting or working)
-    for (int piece = 0; piece < n_pieces && live; piece++) {
-        const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
-        const bool valid = (int)p + MIN_MATCH <= n;
-        const uint32_t v = valid ? lds_load32u(data, p) : 0u;
-        uint2 *bucket = reinterpret_cast<uint2 *>(head) + hash4(v);
-        const int slot = piece % R1;
-        live = timed_spin(&ms->cand_free[slot], (uint32_t)piece, &ms->abort, 0x10000000u | (uint32_t)piece);
-        uint2 bk = make_uint2(0, 0);
-        if (valid) {
-            bk = *bucket;
-            *bucket = make_uint2((p + 1u) | (bk.x << 16), (bk.x >> 16) | (bk.y << 16));  // newest first; the oldest of the four leaves
-        }
-        cand_ring[slot * 64 + lane] = bk;
-        if (lane == 0) publish(&ms->cand_seq[slot], (uint32_t)piece + 1u);
-    }
-    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 0], t_wait); atomicAdd(&r.prof[61 + 2 * 0], __builtin_readcyclecounter() - t_role0); }
-}
-__device__ __forceinline__ void role_extender(const RoleArgs r) {
-    uint8_t *const data = r.data; Misc *const ms = r.ms; uint2 *const cand_ring = r.cand_ring; uint32_t *const lens_ring = r.lens_ring;
-    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
-    unsigned long long t_wait = 0;
-    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
-    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
-        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
-        const bool ok = spin_until(turn, v, ab, who);
-        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
-        return ok;
-    };
-    bool live = true;
-    for (int piece = claim_ticket(&ms->ext_ticket); piece < n_pieces; piece = claim_ticket(&ms->ext_ticket)) {
-        if (!live) continue;  // (aborted: the tickets are drawn to the end, nothing else is done)
-        const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
-        const bool valid = (int)p + MIN_MATCH <= n;
-        const uint32_t v = valid ? lds_load32u(data, p) : 0u;
-        const int slot = piece % R1;
-        live = timed_spin(&ms->cand_seq[slot], (uint32_t)piece + 1u, &ms->abort, 0x20000000u | (uint32_t)piece);
-        if (!live) continue;
-        const uint2 bk = cand_ring[slot * 64 + lane];
-        if (lane == 0) publish(&ms->cand_free[slot], (uint32_t)(piece + R1));
-        uint32_t len = 0, dist = 0;
-        // a position that an earlier match already covers can start no token: its matches are never looked at (the
-        // parse starts at `carry`, which only grows), so they need not be found either
-        const uint32_t covered_to = __hip_atomic_load(&ms->carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (valid && p >= covered_to) {
-            const uint32_t maxlen = (uint32_t)min(MAX_MATCH, n - (int)p);
-            // up to five candidates: the nearest of the distances 1 .. 8 whose four bytes agree, and the bucket's four
-            // positions; their loads are issued together and they are extended side by side (one LDS round trip per
-            // four bytes of the LONGEST match, not per candidate)
-            uint32_t cp[5];
-            uint32_t alive = 0;
-            {
-                uint32_t vd[8];
-#pragma unroll
-                for (uint32_t d = 1; d <= 8u; d++) vd[d - 1] = lds_load32u(data, p >= d ? p - d : p);
-                uint32_t dsmall = 0;
-#pragma unroll
-                for (uint32_t d = 8; d >= 1u; d--)
-                    if (p >= d && vd[d - 1] == v) dsmall = d;
-                cp[0] = p - dsmall;
-                if (dsmall) alive |= 1u;
-            }
-            const uint32_t c4[4] = {bk.x & 0xffffu, bk.x >> 16, bk.y & 0xffffu, bk.y >> 16};
-            uint32_t cv[4];
-#pragma unroll
-            for (int w = 0; w < WAYS; w++) {
-                cp[1 + w] = c4[w] ? c4[w] - 1u : 0u;
-                cv[w] = lds_load32u(data, cp[1 + w]);
-            }
-#pragma unroll
-            for (int w = 0; w < WAYS; w++)
-                if (c4[w] && p - cp[1 + w] <= 32768u && cv[w] == v) alive |= 2u << w;
-            uint32_t cl[5] = {0, 0, 0, 0, 0};
-            uint32_t off = 4;
-            while (alive && off < maxlen) {  // eight bytes per round trip
-                const uint64_t pw = lds_load64u(data, p + off);
-                uint64_t x[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) x[k] = lds_load64u(data, cp[k] + off) ^ pw;
-#pragma unroll
-                for (int k = 0; k < 5; k++)
-                    if (((alive >> k) & 1u) && x[k]) {
-                        cl[k] = off + ((uint32_t)__builtin_ctzll(x[k]) >> 3);
-                        alive &= ~(1u << k);
-                    }
-                off += 8;
-            }
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                uint32_t l = ((alive >> k) & 1u) ? maxlen : cl[k];  // still equal where the limit was reached
-                if (l > maxlen) l = maxlen;
-                if (l > len) { len = l; dist = p - cp[k]; }
-            }
-        }
-        if (len < (uint32_t)MIN_MATCH) len = 0;
-        const int lslot = piece % R2;
-        live = timed_spin(&ms->lens_free[lslot], (uint32_t)piece, &ms->abort, 0x30000000u | (uint32_t)piece);
-        if (!live) continue;
-        lens_ring[lslot * 64 + lane] = len | (dist << 16);
-        if (lane == 0) publish(&ms->lens_seq[lslot], (uint32_t)piece + 1u);
-    }
-    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 1], t_wait); atomicAdd(&r.prof[61 + 2 * 1], __builtin_readcyclecounter() - t_role0); }
-}
-__device__ __forceinline__ void role_parser(const RoleArgs r) {
-    uint32_t *const match = r.match, *const tokw = r.tokw, *const matw = r.matw; Misc *const ms = r.ms; uint32_t *const lens_ring = r.lens_ring;
-    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
-    unsigned long long t_wait = 0;
-    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
-    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
-        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
-        const bool ok = spin_until(turn, v, ab, who);
-        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
-        return ok;
-    };
-    // The parser sets the block's pace (every piece passes through this one wave, carry in hand), so its round trips are
-    // taken off the chain: the next piece's (length, distance) words are fetched while this piece is parsed, the neighbour's
-    // length comes by DPP (wave_shl:1) instead of through the LDS crossbar, and a match's slot in the list is an mbcnt.
-    int carry = 0;
-    uint32_t mcount = 0, full = 0;
-    bool live = n_pieces > 0 && timed_spin(&ms->lens_seq[0], 1u, &ms->abort, 0x40000000u);
-    uint32_t lx = live ? lens_ring[lane] : 0u;
-    for (int piece = 0; piece < n_pieces && live; piece++) {
-        const int lslot = piece % R2;
-        const uint32_t len = lx & 0xffffu, dist = lx >> 16;
-        if (lane == 0) publish(&ms->lens_free[lslot], (uint32_t)(piece + R2));  // (this piece's words are in registers: its slot goes back)
-        // the next piece's words are fetched while this one is parsed
-        uint32_t lx_next = 0;
-        const int nslot = (piece + 1) % R2;
-        if (piece + 1 < n_pieces) {
-            live = timed_spin(&ms->lens_seq[nslot], (uint32_t)piece + 2u, &ms->abort, 0x40000000u | (uint32_t)(piece + 1));
-            if (live) lx_next = lens_ring[nslot * 64 + lane];
-        }
-        // a match yields to a longer one at the next position
-        const uint32_t len_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const bool yield = len && lane < 63 && len_next > len;
-        const int cb = piece * 64, nv = min(64, n - cb);
-        uint64_t has = __ballot(len != 0 && !yield);
-        if (full || mcount + (uint32_t)__popcll(has) > (uint32_t)MAX_MATCHES) { full = 1; has = 0; }  // the match list is full: literals from here on
-        const uint64_t vmask = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
-        // greedy: from `cur`, the next match start at or after it is taken and covers its length; what no match covers is a literal
-        uint64_t matmask = 0, covered = 0;
-        int cur = max(carry - cb, 0);
-        const int cur0 = cur;
-        while (cur < nv) {
-            const uint64_t rem = has & (~0ull << cur);
-            if (!rem) break;
-            const int j = (int)__builtin_ctzll(rem);
-            const int e = j + (int)__builtin_amdgcn_readlane((int)len, j);  // first position after the match
-            matmask |= 1ull << j;
-            covered |= (e >= 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((j == 63) ? ~0ull : ((1ull << (j + 1)) - 1ull));
-            cur = e;
-        }
-        const uint64_t tokmask = vmask & ~covered & (cur0 >= 64 ? 0ull : (~0ull << cur0));
-        if (cur < nv) cur = nv;
-        if (cb + cur > carry) carry = cb + cur;
-        if ((matmask >> lane) & 1ull) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(matmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matmask, 0u));
-            match[mcount + before] = dist | ((len - 3u) << 16);
-        }
-        mcount += (uint32_t)__popcll(matmask);
-        if (lane == 0) {
-            *reinterpret_cast<uint2 *>(tokw + 2 * piece) = make_uint2((uint32_t)tokmask, (uint32_t)(tokmask >> 32));
-            *reinterpret_cast<uint2 *>(matw + 2 * piece) = make_uint2((uint32_t)matmask, (uint32_t)(matmask >> 32));
-            __hip_atomic_store(&ms->carry, (uint32_t)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        lx = lx_next;
-    }
-    if (lane == 0) ms->mcount = mcount;
-    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 2], t_wait); atomicAdd(&r.prof[61 + 2 * 2], __builtin_readcyclecounter() - t_role0); }
-}
-
-__global__ __launch_bounds__(WG) void bgzf_deflate_kernel(DeflateArgs a) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    uint8_t *const data = lds + L_DATA;
-    uint16_t *const head = reinterpret_cast<uint16_t *>(lds + L_HEAD);
-    uint32_t *const match = reinterpret_cast<uint32_t *>(lds + L_MATCH);
-    uint32_t *const tokw = reinterpret_cast<uint32_t *>(lds + L_TOK);
-    uint32_t *const matw = reinterpret_cast<uint32_t *>(lds + L_MAT);
-    Misc *const ms = reinterpret_cast<Misc *>(lds + L_MISC);
-    uint2 *const cand_ring = reinterpret_cast<uint2 *>(lds + L_CRING);
-    uint32_t *const lens_ring = reinterpret_cast<uint32_t *>(lds + L_LRING);
-    uint32_t *const mpre = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_MPRE);
-    uint32_t *const h8 = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_H8);
-    uint32_t *const A_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AL), *const S_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SL);
-    uint32_t *const A_d = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AD), *const S_d = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SD);
-    uint32_t *const crct = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_CRCT);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    if (tid == 0) crc_x2n_table(ms->x2n);
-    for (;;) {
-        __syncthreads();  // the previous block's LDS is no longer read
-        if (tid == 0) ms->blk = atomicAdd(a.ticket, 1u);
-        __syncthreads();
-        const uint32_t blk = ms->blk;
-        if (blk >= a.n_blocks) break;  // (uniform: every thread reads the same word)
-        unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
-        auto stamp = [&](int k) {
-            if (a.prof && tid == 0) {
-                const unsigned long long t = __builtin_readcyclecounter();
-                atomicAdd(&a.prof[k], t - t_prev);
-                t_prev = t;
-            }
-        };
-        const uint64_t off = (uint64_t)blk * BLOCK;
-        const int n = (int)(a.n_bytes - off < (uint64_t)BLOCK ? a.n_bytes - off : (uint64_t)BLOCK);
-        const uint8_t *src = a.src + off;
-        uint8_t *const out = a.slots + (uint64_t)blk * SLOT;
-        uint32_t *const out32 = reinterpret_cast<uint32_t *>(out);
-
-        // ---- load the block (the stream starts 16-byte aligned and BLOCK is a multiple of 16), clear the tables
-        {
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-            uint4 *d4 = reinterpret_cast<uint4 *>(data);
-            const int n16 = n >> 4;
-            for (int k = tid; k < n16; k += WG) d4[k] = s4[k];
-            for (int k = (n16 << 4) + tid; k < n; k += WG) data[k] = src[k];
-            for (int k = n + tid; k < ((n + 15) & ~15) + 272 && k < 65536; k += WG) data[k] = 0;  // what a compare may read past the end
-            uint4 *z = reinterpret_cast<uint4 *>(lds + L_HEAD);
-            for (int k = tid; k < 32768 / 16; k += WG) z[k] = make_uint4(0, 0, 0, 0);
-            uint4 *zb = reinterpret_cast<uint4 *>(lds + L_TOK);
-            for (int k = tid; k < 16384 / 16; k += WG) zb[k] = make_uint4(0, 0, 0, 0);
-            if (tid == 0) { ms->carry = 0; ms->mcount = 0; ms->stored = 0; ms->ext_ticket = 0; ms->abort = 0; }
-            if (tid < R1) { ms->cand_seq[tid] = 0; ms->cand_free[tid] = (uint32_t)tid; }
-            if (tid < R2) { ms->lens_seq[tid] = 0; ms->lens_free[tid] = (uint32_t)tid; }
-        }
-        __syncthreads();
-        stamp(0);
-
-        // ---- A: matches and the parse, as a pipeline of wave roles over pieces of 64 positions.  The two steps that must
-        // see the pieces in order never hand a turn from wave to wave (a hand-over costs ~900 clocks, 2,040 of them a block):
-        //   wave 0, the hasher, walks the pieces through the hash heads (a bucket's read, then its write, in LDS order) and
-        //           leaves each position's four candidates in a small ring;
-        //   waves 1 .. 14, the extenders, claim pieces by ticket, take the candidates (the slot goes back at once), extend
-        //           them and leave (length, distance) in a second ring;
-        //   wave 15, the parser, takes the pieces in order, carry and match count in registers.
-        // Slots carry sequence numbers: a ring slot s is written for piece k only when `free` says k, read only when `seq`
-        // says k + 1.  Every wait is for a lower-numbered piece's step, so the waits cannot form a cycle.
-        const int n_pieces = (n + 63) >> 6;
-        {
-            RoleArgs ra;
-            ra.data = data; ra.head = head; ra.match = match; ra.tokw = tokw; ra.matw = matw; ra.ms = ms;
-            ra.cand_ring = cand_ring; ra.lens_ring = lens_ring; ra.n = n; ra.n_pieces = n_pieces; ra.lane = lane; ra.prof = a.prof;
-            if (wave == 0) role_hasher(ra);
-            else if (wave < N_WAVES - 1) role_extender(ra);
-            else role_parser(ra);
-        }
-        __syncthreads();
-        if (ms->abort) {  // (uniform) a wait of the pipeline timed out: the block is reported, not compressed
-            if (tid == 0) {
-                a.out_size[blk] = 0xffffffffu;
-                a.out_crc[blk] = ms->abort;
-                if (a.prof) {  // the rings as they stand (FADEHIP_BGZF_PROF): [8..) of the profile words
-                    unsigned long long *d = a.prof + 8;
-                    int q = 0;
-                    d[q++] = ms->abort; d[q++] = ms->ext_ticket; d[q++] = ms->carry; d[q++] = (unsigned long long)n | ((unsigned long long)ms->dbg[0] << 32);
-                    d[70] = ms->dbg[1]; d[71] = ms->dbg[2];
-                    for (int k = 0; k < R1; k++) { d[q++] = ms->cand_seq[k]; d[q++] = ms->cand_free[k]; }
-                    for (int k = 0; k < R2; k++) { d[q++] = ms->lens_seq[k]; d[q++] = ms->lens_free[k]; }
-                }
-            }
-            continue;
-        }
-        stamp(1);
-
-        // ---- B: match-index prefix, histograms
-        {
-            uint32_t *z = reinterpret_cast<uint32_t *>(lds + L_HEAD);
-            for (int k = tid; k < H_END / 4; k += WG) z[k] = 0;
-            if (tid < 16) { ms->bl_l[tid] = 0; ms->bl_d[tid] = 0; }
-        }
-        __syncthreads();
-        const int w0 = WPT * tid, w1 = min(w0 + WPT, N_WORDS);
-        uint32_t tw_r[WPT], mw_r[WPT], mb_r[WPT];  // this range's bitmap words and the match index each word starts at
-        {
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int k = 0; k < WPT; k++) {
-                const bool in = w0 + k < w1;
-                tw_r[k] = in ? tokw[w0 + k] : 0u;
-                mw_r[k] = in ? matw[w0 + k] : 0u;
-                cnt += (uint32_t)__builtin_popcount(mw_r[k]);
-            }
-            uint32_t all;
-            uint32_t at = block_excl_scan(cnt, ms->wtmp, &all);
-#pragma unroll
-            for (int k = 0; k < WPT; k++) {
-                mb_r[k] = at;
-                at += (uint32_t)__builtin_popcount(mw_r[k]);
-            }
-            (void)mpre;
-        }
-        {
-            uint32_t *hl = h8 + (lane & 7) * 320;
-#pragma unroll
-            for (int k = 0; k < WPT; k++) {
-                uint32_t tw = tw_r[k];
-                const uint32_t mw = mw_r[k];
-                while (tw) {
-                    const int b = __builtin_ctz(tw);
-                    tw &= tw - 1u;
-                    if ((mw >> b) & 1u) {
-                        const uint32_t rec = match[mb_r[k] + (uint32_t)__builtin_popcount(mw & ((1u << b) - 1u))];
-                        atomicAdd(&hl[length_symbol((rec >> 16) + 3u).sym], 1u);
-                        atomicAdd(&hl[288 + dist_symbol(rec & 0xffffu).sym], 1u);
-                    } else atomicAdd(&hl[data[32 * (w0 + k) + b]], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        for (int s = tid; s < 320; s += WG) {
-            uint32_t f = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) f += h8[k * 320 + s];
-            if (s < 288) ms->freq_l[s] = s == 256 ? 1u : (s < NUM_LITLEN ? f : 0u);
-            else ms->freq_d[s - 288] = (s - 288 < NUM_DIST) ? f : 0u;
-        }
-        __syncthreads();
-        stamp(2);
-        if (tid == 0) {  // at least two distance codes (as zlib makes sure of, for old inflaters)
-            int used = 0;
-            for (int s = 0; s < NUM_DIST; s++) used += ms->freq_d[s] != 0;
-            for (int s = 0; used < 2 && s < NUM_DIST; s++)
-                if (!ms->freq_d[s]) { ms->freq_d[s] = 1; used++; }
-            ms->m_l = 0;
-            ms->m_d = 0;
-        }
-        __syncthreads();
-        // rank the used symbols by (frequency, symbol)
-        if (tid < NUM_LITLEN) {
-            const uint32_t f = ms->freq_l[tid];
-            if (f) {
-                uint32_t r = 0;
-                for (int j = 0; j < NUM_LITLEN; j++) {
-                    const uint32_t g = ms->freq_l[j];
-                    r += g && (g < f || (g == f && j < tid));
-                }
-                A_l[r] = f;
-                S_l[r] = (uint32_t)tid;
-                atomicAdd(&ms->m_l, 1u);
-            }
-        } else if (tid >= DIST_T0 && tid < DIST_T0 + NUM_DIST) {
-            const int sd = tid - DIST_T0;
-            const uint32_t f = ms->freq_d[sd];
-            if (f) {
-                uint32_t r = 0;
-                for (int j = 0; j < NUM_DIST; j++) {
-                    const uint32_t g = ms->freq_d[j];
-                    r += g && (g < f || (g == f && j < sd));
-                }
-                A_d[r] = f;
-                S_d[r] = (uint32_t)sd;
-                atomicAdd(&ms->m_d, 1u);
-            }
-        }
-        if (tid < 320) ms->ll[tid] = 0;
-        if (tid < 64) ms->dl[tid] = 0;
-        __syncthreads();
-        // minimum-redundancy lengths: a lane per alphabet (a chain of ~3 m dependent LDS accesses: the one serial stretch of
-        // the block that no reformulation here made shorter — lane arrays read by v_readlane measured slower than LDS)
-        if (tid == 0) {
-            const int m = (int)ms->m_l;
-            mr_code_lengths(A_l, m);
-            limit_code_lengths(A_l, m, MAX_LITLEN_BITS, ms->sortbuf);
-        } else if (tid == 64) {
-            const int m = (int)ms->m_d;
-            mr_code_lengths(A_d, m);
-            limit_code_lengths(A_d, m, MAX_LITLEN_BITS, ms->sortbuf + 32);
-        }
-        __syncthreads();
-        if ((uint32_t)tid < ms->m_l) {
-            ms->ll[S_l[tid]] = (uint8_t)A_l[tid];
-            atomicAdd(&ms->bl_l[A_l[tid]], 1u);
-        } else if (tid >= DIST_T0 && (uint32_t)(tid - DIST_T0) < ms->m_d) {
-            ms->dl[S_d[tid - DIST_T0]] = (uint8_t)A_d[tid - DIST_T0];
-            atomicAdd(&ms->bl_d[A_d[tid - DIST_T0]], 1u);
-        }
-        __syncthreads();
-        if (tid == 0 || tid == 64) {  // first code of each length (RFC 1951 §3.2.2)
-            uint32_t *bl = tid ? ms->bl_d : ms->bl_l, *nc = tid ? ms->nc_d : ms->nc_l;
-            uint32_t c = 0;
-            bl[0] = 0;
-            nc[0] = 0;
-            for (int b = 1; b <= MAX_LITLEN_BITS; b++) {
-                c = (c + bl[b - 1]) << 1;
-                nc[b] = c;
-            }
-        }
-        __syncthreads();
-        if (tid < NUM_LITLEN + NUM_DIST) {
-            const bool is_d = tid >= NUM_LITLEN;
-            const int sym = is_d ? tid - NUM_LITLEN : tid;
-            const uint8_t *lens = is_d ? ms->dl : ms->ll;
-            const uint32_t l = lens[sym];
-            if (l) {
-                uint32_t before = 0;
-                for (int j = 0; j < sym; j++) before += lens[j] == l;
-                const uint32_t code = (is_d ? ms->nc_d : ms->nc_l)[l] + before;
-                (is_d ? ms->dc : ms->lc)[sym] = (uint16_t)(__builtin_bitreverse32(code) >> (32u - l));
-            }
-        }
-        __syncthreads();
-        stamp(3);
-
-        // ---- C: the dynamic-block header (RFC 1951 §3.2.7), in parallel: the hlit + hdist code lengths are cut into runs,
-        // every run start expands its run into code-length symbols (16 / 17 / 18 and plain lengths, the same sequence the
-        // serial cl_rle of bgzf_huff.hpp emits), a scan places them, the 19-symbol code is made by one lane, and every
-        // symbol's bits are OR-ed into the header words at scanned offsets.
-        if (tid == 0) { ms->cl_hlit = 257; ms->cl_hdist = 1; ms->cl_n = 0; }
-        if (tid < NUM_CL + 1) { ms->cl_freq[tid] = 0; ms->cl_len[tid] = 0; ms->cl_code[tid] = 0; }
-        for (int k = tid; k < 160; k += WG) ms->hdr[k] = 0;
-        __syncthreads();
-        if (tid < NUM_LITLEN && ms->ll[tid]) atomicMax(&ms->cl_hlit, (uint32_t)tid + 1u);
-        if (tid >= DIST_T0 && tid < DIST_T0 + NUM_DIST && ms->dl[tid - DIST_T0]) atomicMax(&ms->cl_hdist, (uint32_t)(tid - DIST_T0) + 1u);
-        __syncthreads();
-        {
-            const int hlit = (int)ms->cl_hlit, hdist = (int)ms->cl_hdist, nseq = hlit + hdist;
-            auto at = [&](int k) -> int { return k < hlit ? (int)ms->ll[k] : (int)ms->dl[k - hlit]; };
-            uint32_t ntok = 0;
-            int v = 0, run = 0;
-            if (tid < nseq) {
-                v = at(tid);
-                if (tid == 0 || at(tid - 1) != v) {  // a run starts here
-                    run = 1;
-                    while (tid + run < nseq && at(tid + run) == v) run++;
-                    if (v == 0) {
-                        const int full18 = run / 138, rem = run % 138;
-                        ntok = (uint32_t)full18 + (rem >= 3 ? 1u : (uint32_t)rem);
-                    } else {
-                        const int left = run - 1, full16 = left / 6, rem = left % 6;
-                        ntok = 1u + (uint32_t)full16 + (rem >= 3 ? 1u : (uint32_t)rem);
-                    }
-                }
-            }
-            uint32_t nt_all;
-            uint32_t at_tok = block_excl_scan(ntok, ms->wtmp, &nt_all);
-            if (run) {
-                auto emit = [&](int sym, int extra) {
-                    ms->cltok[at_tok++] = (uint16_t)(sym | (extra << 8));
-                    atomicAdd(&ms->cl_freq[sym], 1u);
-                };
-                int left = run;
-                if (v == 0) {
-                    while (left >= 11) { const int r = left > 138 ? 138 : left; emit(18, r - 11); left -= r; }
-                    if (left >= 3) { emit(17, left - 3); left = 0; }
-                    while (left-- > 0) emit(0, 0);
-                } else {
-                    emit(v, 0);
-                    left--;
-                    while (left >= 3) { const int r = left > 6 ? 6 : left; emit(16, r - 3); left -= r; }
-                    while (left-- > 0) emit(v, 0);
-                }
-            }
-            if (tid == 0) ms->cl_n = nt_all;
-        }
-        __syncthreads();
-        if (tid == 0) {  // the code-length code: 19 symbols, 7 bits at most
-            uint32_t *sf = ms->sortbuf, *ss = ms->sortbuf + 20, *bl = ms->sortbuf + 40;
-            int m = 0;
-            for (int sy = 0; sy < NUM_CL; sy++) {
-                const uint32_t f = ms->cl_freq[sy];
-                if (f) {
-                    int j = m++;
-                    while (j > 0 && sf[j - 1] > f) { sf[j] = sf[j - 1]; ss[j] = ss[j - 1]; j--; }
-                    sf[j] = f;
-                    ss[j] = (uint32_t)sy;
-                }
-            }
-            if (m == 1) ms->cl_len[ss[0]] = 1;
-            else {
-                mr_code_lengths(sf, m);
-                limit_code_lengths(sf, m, MAX_CL_BITS, bl);
-                for (int k = 0; k < m; k++) ms->cl_len[ss[k]] = sf[k];
-            }
-            for (int bb = 0; bb <= MAX_CL_BITS; bb++) bl[bb] = 0;
-            for (int sy = 0; sy < NUM_CL; sy++)
-                if (ms->cl_len[sy]) bl[ms->cl_len[sy]]++;
-            uint32_t c = 0;
-            sf[0] = 0;
-            for (int bb = 1; bb <= MAX_CL_BITS; bb++) {
-                c = (c + (bb > 1 ? bl[bb - 1] : 0u)) << 1;
-                sf[bb] = c;
-            }
-            for (int sy = 0; sy < NUM_CL; sy++) {
-                const uint32_t l = ms->cl_len[sy];
-                if (l) ms->cl_code[sy] = __builtin_bitreverse32(sf[l]++) >> (32u - l);
-            }
-            int hclen = NUM_CL;
-            while (hclen > 4 && ms->cl_len[cl_order(hclen - 1)] == 0) hclen--;
-            ms->cl_hclen = (uint32_t)hclen;
-            // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then 3 bits per code-length code length
-            WordSink sink;
-            sink.w = ms->hdr;
-            sink.put(1, 1);
-            sink.put(2, 2);
-            sink.put(ms->cl_hlit - 257u, 5);
-            sink.put(ms->cl_hdist - 1u, 5);
-            sink.put((uint32_t)(hclen - 4), 4);
-            for (int k = 0; k < hclen; k++) sink.put(ms->cl_len[cl_order(k)], 3);
-            sink.finish();
-        }
-        __syncthreads();
-        {
-            const uint32_t nt_all = ms->cl_n, fixed_bits = 17u + 3u * ms->cl_hclen;
-            uint32_t bits = 0, val = 0;
-            if ((uint32_t)tid < nt_all) {
-                const uint32_t t = ms->cltok[tid], sy = t & 255u, ex = t >> 8;
-                const uint32_t l = ms->cl_len[sy], eb = sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u;
-                val = ms->cl_code[sy] | (ex << l);
-                bits = l + eb;
-            }
-            uint32_t cl_bits_all;
-            const uint32_t o = fixed_bits + block_excl_scan(bits, ms->wtmp, &cl_bits_all);
-            if (bits) {
-                atomicOr(&ms->hdr[o >> 5], val << (o & 31u));
-                if ((o & 31u) + bits > 32u) atomicOr(&ms->hdr[(o >> 5) + 1u], val >> (32u - (o & 31u)));
-            }
-            if (tid == 0) ms->hdr_bits = fixed_bits + cl_bits_all;
-        }
-        // ---- D: the bit counts of the 1024 position ranges
-        uint32_t my_bits = 0;
-#pragma unroll
-        for (int k = 0; k < WPT; k++) {
-            uint32_t tw = tw_r[k];
-            while (tw) {
-                const int b = __builtin_ctz(tw);
-                tw &= tw - 1u;
-                uint64_t v;
-                int nb;
-                token_bits(data, mw_r[k], mb_r[k], match, ms, w0 + k, b, v, nb);
-                my_bits += (uint32_t)nb;
-            }
-        }
-        if (tid == WG - 1) my_bits += ms->ll[256];  // end of block
-        __syncthreads();  // hdr_bits is there
-        stamp(4);
-        uint32_t tok_bits_all;
-        const uint32_t b0 = ms->hdr_bits + block_excl_scan(my_bits, ms->wtmp, &tok_bits_all);
-        if (tid == 0) {
-            const uint32_t run = ms->hdr_bits + tok_bits_all;
-            ms->total_bits = run;
-            const uint32_t bytes = (run + 7u) >> 3;
-            ms->stored = bytes > (uint32_t)n + 5u || bytes > (uint32_t)MAX_PAYLOAD;
-        }
-        __syncthreads();
-        const uint32_t total_bits = ms->total_bits;
-        if (ms->stored) {
-            if (tid == 0) {
-                out[0] = 1;  // BFINAL = 1, BTYPE = 00; LEN, NLEN
-                out[1] = (uint8_t)(n & 255);
-                out[2] = (uint8_t)(n >> 8);
-                out[3] = (uint8_t)~(n & 255);
-                out[4] = (uint8_t)~(n >> 8);
-                a.out_size[blk] = (uint32_t)n + 5u;
-            }
-            for (int k = tid; k < n; k += WG) out[5 + k] = data[k];
-        } else {
-            const uint32_t b1 = b0 + my_bits;
-            const uint32_t hdr_words = (ms->hdr_bits + 31u) >> 5;
-            // words that more than one writer touches are cleared first and OR-ed atomically; the others are stored whole
-            if (my_bits) {
-                out32[b0 >> 5] = 0;
-                out32[(b1 - 1u) >> 5] = 0;
-            }
-            for (uint32_t k = tid; k < hdr_words; k += WG) out32[k] = 0;
-            __syncthreads();
-            for (uint32_t k = tid; k < hdr_words; k += WG) atomicOr(&out32[k], ms->hdr[k]);
-            if (my_bits) {
-                uint64_t acc = 0;
-                int cnt = (int)(b0 & 31u);
-                uint32_t wi = b0 >> 5;
-                const uint32_t w_first = wi, w_last = (b1 - 1u) >> 5;
-                auto put = [&](uint64_t v, int k) {
-                    acc |= v << cnt;
-                    cnt += k;
-                    if (cnt >= 32) {
-                        if (wi == w_first || wi == w_last) atomicOr(&out32[wi], (uint32_t)acc);
-                        else out32[wi] = (uint32_t)acc;
-                        wi++;
-                        acc >>= 32;
-                        cnt -= 32;
-                    }
-                };
-#pragma unroll
-                for (int k = 0; k < WPT; k++) {
-                    uint32_t tw = tw_r[k];
-                    while (tw) {
-                        const int b = __builtin_ctz(tw);
-                        tw &= tw - 1u;
-                        uint64_t v;
-                        int nb;
-                        token_bits(data, mw_r[k], mb_r[k], match, ms, w0 + k, b, v, nb);
-                        if (nb > 24) {  // (a token has up to 48 bits and the accumulator up to 31 pending)
-                            put(v & 0xffffffull, 24);
-                            put(v >> 24, nb - 24);
-                        } else put(v, nb);
-                    }
-                }
-                if (tid == WG - 1) put(ms->lc[256], ms->ll[256]);
-                if (cnt) atomicOr(&out32[wi], (uint32_t)acc);
-            }
-            if (tid == 0) a.out_size[blk] = (total_bits + 7u) >> 3;
-        }
-        __syncthreads();
-        stamp(5);
-
-        // ---- CRC-32 of the input: slicing-by-4 over 1024 pieces of 64 bytes, combined
-        if (tid < 256) crct[tid] = crc_table_entry((uint32_t)tid);
-        __syncthreads();
-        for (int t = 1; t < 4; t++) {
-            if (tid < 256) crct[256 * t + tid] = (crct[256 * (t - 1) + tid] >> 8) ^ crct[crct[256 * (t - 1) + tid] & 255u];
-            __syncthreads();
-        }
-        uint32_t part = 0;
-        {
-            constexpr int PIECE = ((65536 / WG + 3) / 4 + 1) * 4;  // bytes per thread, a multiple of 4, WG * PIECE >= BLOCK
-            static_assert(PIECE * WG >= BLOCK, "CRC pieces must cover the block");
-            const int lo = PIECE * tid, hi = min(lo + PIECE, n);
-            if (lo < hi) {
-                uint32_t c = 0xffffffffu;
-                int k = lo;
-                const uint32_t *dw = reinterpret_cast<const uint32_t *>(data);
-                for (; k + 4 <= hi; k += 4) {
-                    c ^= dw[k >> 2];
-                    c = crct[768 + (c & 255u)] ^ crct[512 + ((c >> 8) & 255u)] ^ crct[256 + ((c >> 16) & 255u)] ^ crct[c >> 24];
-                }
-                for (; k < hi; k++) c = crct[(c ^ data[k]) & 255u] ^ (c >> 8);
-                c = ~c;
-                part = crc_mulmod(crc_x8n((uint32_t)(n - hi), ms->x2n), c);  // crc(A || B) = x^(8 |B|) crc(A) ^ crc(B)
-            }
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) part ^= (uint32_t)__shfl_xor((int)part, m, 64);
-        if (lane == 0) ms->crc_part[wave] = part;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t c = 0;
-            for (int w = 0; w < N_WAVES; w++) c ^= ms->crc_part[w];
-            a.out_crc[blk] = c;
-        }
-        stamp(6);
-    }
-}
-
-// exclusive scan of the members' sizes (payload + 26 bytes of BGZF header and trailer): one workgroup
-__global__ __launch_bounds__(1024) void bgzf_scan_kernel(const uint32_t *out_size, uint32_t n_blocks, uint64_t *member_off, uint64_t *total) {
-    __shared__ uint64_t part[1024];
-    const int tid = threadIdx.x;
-    const uint32_t per = (n_blocks + 1023u) / 1024u, lo = (uint32_t)tid * per, hi = min(lo + per, n_blocks);
-    __shared__ int failed;
-    if (tid == 0) failed = 0;
-    __syncthreads();
-    uint64_t s = 0;
-    for (uint32_t k = lo; k < hi; k++) {
-        if (out_size[k] > (uint32_t)MAX_PAYLOAD) failed = 1;  // a block the compressor gave up on (see spin_until)
-        s += (uint64_t)out_size[k] + 26u;
-    }
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t run = 0;
-        for (int k = 0; k < 1024; k++) { const uint64_t c = part[k]; part[k] = run; run += c; }
-        *total = failed ? 0ull : run;  // 0: the host reports the failure instead of copying anything
-    }
-    __syncthreads();
-    uint64_t at = part[tid];
-    for (uint32_t k = lo; k < hi; k++) { member_off[k] = at; at += (uint64_t)out_size[k] + 26u; }
-}
-
-// member k = 18 bytes of header (BSIZE in the BC subfield), the payload, CRC32, ISIZE — packed one after the other
-__global__ __launch_bounds__(256) void bgzf_pack_kernel(const uint8_t *slots, const uint32_t *out_size, const uint32_t *out_crc,
-                                                        const uint64_t *member_off, uint64_t n_bytes, uint32_t n_blocks, uint8_t *dst) {
-    const uint32_t blk = blockIdx.x;
-    if (blk >= n_blocks) return;
-    const uint32_t sz = out_size[blk];
-    if (sz > (uint32_t)MAX_PAYLOAD) return;  // (a failed block: nothing is packed, the scan has zeroed the total)
-    uint8_t *d = dst + member_off[blk];
-    const uint8_t *s = slots + (uint64_t)blk * SLOT;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        const uint32_t bsize = sz + 25u;  // total member size - 1
-        const uint8_t h[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255u), (uint8_t)(bsize >> 8)};
-        for (int k = 0; k < 18; k++) d[k] = h[k];
-        const uint64_t off = (uint64_t)blk * BLOCK;
-        const uint32_t isize = (uint32_t)(n_bytes - off < (uint64_t)BLOCK ? n_bytes - off : (uint64_t)BLOCK), crc = out_crc[blk];
-        uint8_t *t = d + 18 + sz;
-        for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(isize >> (8 * k)); }
-    }
-    // payload: destination-aligned dwords assembled from the (aligned) slot, the ragged ends byte by byte
-    uint8_t *p = d + 18;
-    const uint32_t mis = (uint32_t)((4u - ((uintptr_t)p & 3u)) & 3u), headn = mis < sz ? mis : sz;
-    if ((uint32_t)tid < headn) p[tid] = s[tid];
-    const uint32_t body = (sz - headn) >> 2;
-    uint32_t *p32 = reinterpret_cast<uint32_t *>(p + headn);
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s);
-    for (uint32_t k = tid; k < body; k += 256) {
-        const uint32_t so = headn + 4u * k;  // source byte offset of this destination word
-        p32[k] = __builtin_amdgcn_alignbyte(s32[(so >> 2) + 1], s32[so >> 2], so & 3u);
-    }
-    const uint32_t done = headn + 4u * body;
-    if ((uint32_t)tid < sz - done) p[done + tid] = s[done + tid];
-}
-
-}  // namespace bgzf
 }  // namespace fadehip

@@ -290,6 +290,34 @@ __device__ __forceinline__ uint32_t inflate_member(InfWave *w, const uint8_t *sr
         // ---- the block's symbols
         bool eob = false;
         while (!eob && !err) {
+            // Literal runs first, in a loop of their own with one exit: a table entry e is a literal with a short code iff
+            // 1 <= e < 4096 (symbol << 4 | length, length >= 1).  The run ends when the literal line is full, so the line's
+            // room in the output is checked once, not per literal; 32 valid bits serve three codes of at most 10 bits.
+            if (pos - pn + 64u <= isize) {
+                bool lit = true;
+#define FADEHIP_INF_LITERAL()                                                                       \
+    {                                                                                               \
+        const uint32_t e_ = uni((uint32_t)lit_tab[(uint32_t)br.bb & ((1u << LIT_BITS) - 1u)]);      \
+        if (e_ - 1u >= 4095u) { lit = false; break; }                                               \
+        br.bits((int)(e_ & 15u));                                                                   \
+        lane_write(pend, e_ >> 4, pn);                                                              \
+        pn++;                                                                                       \
+        pos++;                                                                                      \
+        if (pn == 64u) break;                                                                       \
+    }
+                for (;;) {
+                    br.refill();
+                    FADEHIP_INF_LITERAL()
+                    FADEHIP_INF_LITERAL()
+                    FADEHIP_INF_LITERAL()
+                }
+#undef FADEHIP_INF_LITERAL
+                if (pn == 64u) {
+                    out[pos - 64u + (uint32_t)lane] = (uint8_t)pend;
+                    pn = 0;
+                    if (lit) continue;
+                }
+            }
             br.refill();
             uint32_t e = uni((uint32_t)lit_tab[(uint32_t)br.bb & ((1u << LIT_BITS) - 1u)]);
             if ((e & 15u) == 0u) {

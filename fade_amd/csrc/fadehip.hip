@@ -12,6 +12,7 @@
 #include "bam_device.hpp"
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -157,6 +158,7 @@ struct BgzfLane {
     uint64_t *h_total = nullptr;  // pinned
     size_t n_bytes = 0;
     uint32_t n_blocks = 0;
+    int geom = 64;  // block geometry of the submission in flight (bgzf_deflate.hpp)
     int state = 0;  // 0 idle, 1 submitted
 };
 
@@ -197,6 +199,8 @@ struct fadehip_ctx {
     BgzfLane bgzf[FADEHIP_BGZF_LANES];
     InflateLane inf;
     bool bgzf_ready = false;           // the compressor's LDS size has been declared to the runtime
+    int bgzf_geom_fixed = 0;           // FADEHIP_BGZF_GEOM: 32 / 64 (0: by the ratio of the previous call)
+    double bgzf_last_ratio = 0;        // compressed / raw bytes of the ctx's previous compression
     std::map<uint64_t, int> resident;  // (class, mode, LDS bytes) -> waves of that kernel the device holds at once
     std::mutex resident_mu;
 };
@@ -261,11 +265,17 @@ int reserve_run(fadehip_ctx *ctx, std::vector<void *> &trash, DevBuf &b, size_t 
     if (b.p) trash.push_back(b.p);
     b.p = nullptr;
     b.cap = 0;
-    size_t want = std::max<size_t>(bytes, 256);
+    size_t want = std::max<size_t>(bytes + bytes / 8, 256);  // (headroom: a stream's batches differ a little in size)
     want = (want + 255) & ~(size_t)255;
     HIPCHK(ctx, hipMalloc(&b.p, want));
     b.cap = want;
     return 0;
+}
+
+// buffers of a stream whose sizes differ a little from call to call: a quarter of headroom, so that they settle
+int reserve_roomy(fadehip_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    return reserve(ctx, b, bytes + bytes / 4 + 4096);
 }
 
 void release(DevBuf &b) {
@@ -719,9 +729,8 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int m
 
 // streams, events and the pinned counter block of a slot, made when the slot is first used
 int ensure_slot(fadehip_ctx *ctx, Slot &s) {
-    if (s.stream) return 0;
-    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (s.h_zb) return 0;
+    if (!s.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));  // (the file path lends slot 0 the ctx's copy stream)
     HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming));
     HIPCHK(ctx, hipHostMalloc((void **)&s.h_zb, Slot::ZB_BYTES));
     memset(s.h_zb, 0, Slot::ZB_BYTES);
@@ -833,19 +842,21 @@ int enqueue_run(fadehip_ctx *ctx, Slot &s) {
     s.tickets_used = 0;
     memset(s.prof_counts, 0, sizeof s.prof_counts);
     int rc;
+    // (the file path's batches differ a little in size from call to call: its buffers get headroom so that they settle)
+    auto rsv = [&](DevBuf &b, size_t bytes) { return s.device_only ? reserve_roomy(ctx, b, bytes) : reserve(ctx, b, bytes); };
     // one result array for all lists: an alignment reports into the entry the gate hands it (Work::out)
     uint32_t total_bound = 0;
     for (int c = 0; c < NUM_LISTS; c++) total_bound += s.bound[c];
     total_bound = std::min(total_bound, s.out_bound);
     s.out_cap = total_bound;
     s.res_aln_off = ((size_t)n + 255) & ~(size_t)255;
-    if ((rc = reserve(ctx, s.rs, (size_t)n)) || (rc = reserve(ctx, s.aln, sizeof(fadehip_aln) * (size_t)std::max<uint32_t>(total_bound, 1))) ||
+    if ((rc = rsv(s.rs, (size_t)n)) || (rc = rsv(s.aln, sizeof(fadehip_aln) * (size_t)std::max<uint32_t>(total_bound, 1))) ||
         (rc = reserve(ctx, s.zblock, Slot::ZB_BYTES)) ||
         (!s.device_only && (rc = reserve_pinned(ctx, s.res, s.res_aln_off + sizeof(fadehip_aln) * (size_t)total_bound))))
         return rc;
     for (int c = 0; c < NUM_LISTS; c++) {
         if (!s.bound[c]) continue;
-        if ((rc = reserve(ctx, s.work[c], sizeof(Work) * (size_t)s.bound[c])) || (rc = reserve(ctx, s.meta[c], sizeof(Meta) * (size_t)s.bound[c])))
+        if ((rc = rsv(s.work[c], sizeof(Work) * (size_t)s.bound[c])) || (rc = rsv(s.meta[c], sizeof(Meta) * (size_t)s.bound[c])))
             return rc;
     }
     const int64_t budget = ctx->prm.trace_bytes > 0 ? ctx->prm.trace_bytes : ((int64_t)16 << 30);
@@ -1215,7 +1226,7 @@ void fadehip_destroy(fadehip_ctx *ctx) {
         for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
         if (s.h_zb) (void)hipHostFree(s.h_zb);
         if (s.score_stream) (void)hipStreamDestroy(s.score_stream);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.stream && s.stream != ctx->copy_stream) (void)hipStreamDestroy(s.stream);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (BgzfLane &l : ctx->bgzf) {
@@ -1469,6 +1480,7 @@ int fadehip_annotate_upload(fadehip_ctx *ctx, int slot, const fadehip_read_batch
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Slot &s = ctx->slots[slot];
     if ((rc = ensure_slot(ctx, s))) return rc;
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));  // (made on first use: the file path never uploads)
     // The batch goes to the input buffer the run in flight (if any) does not use, on the ctx's copy stream: upload never
     // waits for that run, and the run's results stay valid until the slot is RUN again.
     Slot::Pending &nx = s.next;
@@ -1688,57 +1700,105 @@ int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t co
 
 // ------------------------------------------------------------------------------- BGZF compression
 // the compressor's launches for n_bytes at d_src (device memory with 64 readable bytes behind the end) on the lane's stream
-static int bgzf_lane_ready(fadehip_ctx *ctx, int lane) {
+static int bgzf_lane_ready(fadehip_ctx *ctx, int lane, bool one_stream = false) {
     BgzfLane &l = ctx->bgzf[lane];
     if (!l.stream) {
         // (every stream is an HSA queue with a 173 MB context-save area to set up and to give back: FADEHIP_BGZF_ONE_STREAM=1
-        // lets the lanes share one — their copies then no longer overlap each other's kernels)
-        if (lane > 0 && getenv("FADEHIP_BGZF_ONE_STREAM") && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
+        // lets the lanes share one — their copies then no longer overlap each other's kernels; the file path's back half
+        // uses the lanes one after the other anyway)
+        if (lane > 0 && (one_stream || getenv("FADEHIP_BGZF_ONE_STREAM")) && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
         else HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
     }
     if (!ctx->bgzf_ready) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)bgzf::bgzf_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bgzf::LDS_BYTES));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)bgzf64::bgzf_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bgzf64::LDS_BYTES));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)bgzf32::bgzf_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bgzf32::LDS_BYTES));
         ctx->bgzf_ready = true;
+        if (const char *g = getenv("FADEHIP_BGZF_GEOM")) ctx->bgzf_geom_fixed = atoi(g) == 32 ? 32 : 64;  // (A/B runs; default: by the stream's ratio)
+        if (getenv("FADEHIP_BGZF_PROF")) {
+            int p64 = 0, p32 = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&p64, (const void *)bgzf64::bgzf_deflate_kernel, bgzf64::WG, bgzf64::LDS_BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&p32, (const void *)bgzf32::bgzf_deflate_kernel, bgzf32::WG, bgzf32::LDS_BYTES);
+            fprintf(stderr, "[fadehip bgzf] compressor workgroups per CU: %d (0xff00-byte blocks, %d B of LDS), %d (0x7f00-byte blocks, %d B)\n", p64, bgzf64::LDS_BYTES, p32, bgzf32::LDS_BYTES);
+        }
     }
     if (l.state == 1) HIPCHK(ctx, hipStreamSynchronize(l.stream));  // never waited for: its buffers are still in use
     l.state = 0;
     return 0;
 }
-static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t n_bytes) {
+// Which geometry (bgzf_deflate.hpp): small blocks, two per CU, while the stream is mostly incompressible (packed bases,
+// uniform qualities: ratio above 0.45, where the smaller blocks cost 0.5 %); htslib's block size where it compresses well
+// (runs of qualities: a member shrinks to a few KB and a second header per 64 KB would show).  From the ratio of the ctx's
+// previous call; the first call takes the large blocks.
+static int bgzf_pick_geom(const fadehip_ctx *ctx) {
+    if (ctx->bgzf_geom_fixed) return ctx->bgzf_geom_fixed;
+    return ctx->bgzf_last_ratio > 0.45 ? 32 : 64;
+}
+// The same choice for bytes the host can look at (fadehip_bgzf_deflate_submit): the share of bytes equal to their
+// predecessor over 64 windows of 4 KB.  Packed bases and uniform qualities: a few per cent; qualities in runs: a third.
+static int bgzf_pick_geom_host(const fadehip_ctx *ctx, const uint8_t *p, size_t n) {
+    if (ctx->bgzf_geom_fixed) return ctx->bgzf_geom_fixed;
+    const size_t win = 4096, nwin = 64;
+    size_t eq = 0, seen = 0;
+    for (size_t w = 0; w < nwin; w++) {
+        const size_t lo = n > win ? (n - win) / nwin * w : 0, hi = std::min(n, lo + win);
+        for (size_t k = lo + 1; k < hi; k++) eq += p[k] == p[k - 1];
+        seen += hi > lo ? hi - lo - 1 : 0;
+        if (n <= win) break;
+    }
+    return seen && (double)eq < 0.15 * (double)seen ? 32 : 64;
+}
+static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t n_bytes, int geom) {
     BgzfLane &l = ctx->bgzf[lane];
-    const uint32_t nb = (uint32_t)((n_bytes + bgzf::BLOCK - 1) / bgzf::BLOCK);
+    const size_t block = geom == 32 ? (size_t)bgzf32::BLOCK : (size_t)bgzf64::BLOCK;
+    const uint32_t nb = (uint32_t)((n_bytes + block - 1) / block);
     int rc;
-    if ((rc = reserve(ctx, l.slots, (size_t)nb * bgzf::SLOT)) || (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 1024)) ||
-        (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) || (rc = reserve(ctx, l.packed, (size_t)nb * bgzf::SLOT)))
+    if ((rc = reserve(ctx, l.slots, (size_t)nb * bgzf64::SLOT)) || (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 1024)) ||
+        (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) || (rc = reserve(ctx, l.packed, (size_t)nb * bgzf64::SLOT)))
         return rc;
     uint32_t *d_size = (uint32_t *)l.meta.p, *d_crc = d_size + nb, *d_ticket = d_crc + nb;
     uint64_t *d_total = (uint64_t *)(((uintptr_t)(d_ticket + 2) + 7) & ~(uintptr_t)7);
     HIPCHK(ctx, hipMemsetAsync(d_ticket, 0, 8, l.stream));
-    bgzf::DeflateArgs a;
-    a.src = d_src;
-    a.n_bytes = n_bytes;
-    a.n_blocks = nb;
-    a.slots = (uint8_t *)l.slots.p;
-    a.out_size = d_size;
-    a.out_crc = d_crc;
-    a.ticket = d_ticket;
-    a.prof = nullptr;
+    unsigned long long *prof = nullptr;
     if (getenv("FADEHIP_BGZF_PROF")) {  // shader clocks per phase, printed by wait (development aid)
-        a.prof = (unsigned long long *)(d_total + 1);
-        HIPCHK(ctx, hipMemsetAsync(a.prof, 0, 64 + 8 * 72, l.stream));
+        prof = (unsigned long long *)(d_total + 1);
+        HIPCHK(ctx, hipMemsetAsync(prof, 0, 64 + 8 * 72, l.stream));
     }
-    const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(ctx->cu_count, 1));
-    hipLaunchKernelGGL(bgzf::bgzf_deflate_kernel, dim3(grid), dim3(bgzf::WG), bgzf::LDS_BYTES, l.stream, a);
-    HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(bgzf::bgzf_scan_kernel, dim3(1), dim3(1024), 0, l.stream, (const uint32_t *)d_size, nb, (uint64_t *)l.member_off.p, d_total);
-    HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(bgzf::bgzf_pack_kernel, dim3(nb), dim3(256), 0, l.stream, (const uint8_t *)l.slots.p, (const uint32_t *)d_size,
-                       (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, (uint8_t *)l.packed.p);
+    const unsigned cus = (unsigned)std::max(ctx->cu_count, 1);
+    auto fill = [&](auto &a) {
+        a.src = d_src;
+        a.n_bytes = n_bytes;
+        a.n_blocks = nb;
+        a.slots = (uint8_t *)l.slots.p;
+        a.out_size = d_size;
+        a.out_crc = d_crc;
+        a.ticket = d_ticket;
+        a.prof = prof;
+    };
+    if (geom == 32) {
+        bgzf32::DeflateArgs a;
+        fill(a);
+        hipLaunchKernelGGL(bgzf32::bgzf_deflate_kernel, dim3(std::min<unsigned>(nb, 2u * cus)), dim3(bgzf32::WG), bgzf32::LDS_BYTES, l.stream, a);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(bgzf32::bgzf_scan_kernel, dim3(1), dim3(1024), 0, l.stream, (const uint32_t *)d_size, nb, (uint64_t *)l.member_off.p, d_total);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(bgzf32::bgzf_pack_kernel, dim3(nb), dim3(256), 0, l.stream, (const uint8_t *)l.slots.p, (const uint32_t *)d_size,
+                           (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, (uint8_t *)l.packed.p);
+    } else {
+        bgzf64::DeflateArgs a;
+        fill(a);
+        hipLaunchKernelGGL(bgzf64::bgzf_deflate_kernel, dim3(std::min<unsigned>(nb, cus)), dim3(bgzf64::WG), bgzf64::LDS_BYTES, l.stream, a);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(bgzf64::bgzf_scan_kernel, dim3(1), dim3(1024), 0, l.stream, (const uint32_t *)d_size, nb, (uint64_t *)l.member_off.p, d_total);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(bgzf64::bgzf_pack_kernel, dim3(nb), dim3(256), 0, l.stream, (const uint8_t *)l.slots.p, (const uint32_t *)d_size,
+                           (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, (uint8_t *)l.packed.p);
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(l.h_total, d_total, 8, hipMemcpyDeviceToHost, l.stream));
     l.n_bytes = n_bytes;
     l.n_blocks = nb;
+    l.geom = geom;
     l.state = 1;
     return 0;
 }
@@ -1753,7 +1813,7 @@ int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, siz
     BgzfLane &l = ctx->bgzf[lane];
     if ((rc = reserve(ctx, l.src, n_bytes + 64))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(l.src.p, src, n_bytes, hipMemcpyHostToDevice, l.stream));
-    return bgzf_enqueue(ctx, lane, (const uint8_t *)l.src.p, n_bytes);
+    return bgzf_enqueue(ctx, lane, (const uint8_t *)l.src.p, n_bytes, bgzf_pick_geom_host(ctx, (const uint8_t *)src, n_bytes));
 }
 
 int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, size_t *out_bytes) {
@@ -1788,7 +1848,7 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
                     (double)pr[60] / l.n_blocks, (double)pr[61] / l.n_blocks, (double)pr[62] / l.n_blocks, (double)pr[63] / l.n_blocks, (double)pr[64] / l.n_blocks, (double)pr[65] / l.n_blocks);
         }
     }
-    if (total == 0 || total > (uint64_t)l.n_blocks * bgzf::SLOT) {
+    if (total == 0 || total > (uint64_t)l.n_blocks * bgzf64::SLOT) {
         // a block whose pipeline timed out reports size ~0 and, as its CRC, the wait that gave up (role << 28 | piece)
         std::vector<uint32_t> meta(2 * (size_t)l.n_blocks);
         unsigned bad = 0, why = 0;
@@ -1797,6 +1857,7 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
                 if (meta[k] == 0xffffffffu) { if (!bad) why = meta[l.n_blocks + k]; bad++; }
         return set_err(ctx, FADEHIP_E_STATE, "internal: bgzf members add up to %llu bytes (%u blocks timed out, first wait 0x%08x)", (unsigned long long)total, bad, why);
     }
+    ctx->bgzf_last_ratio = (double)total / (double)std::max<size_t>(l.n_bytes, 1);
     int rc = reserve_pinned(ctx, l.out, (size_t)total);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(l.out.p, l.packed.p, (size_t)total, hipMemcpyDeviceToHost, l.stream));
@@ -1893,32 +1954,42 @@ int bam_fail(fadehip_bam_stream *st, int rc) {
     return rc;
 }
 
-int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_bytes, int last) {
+int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_bytes, int last, bool raw) {
     fadehip_ctx *ctx = st->ctx;
     Slot &s = ctx->slots[0];
     int rc;
+    // every stream is an HSA queue to set up and to give back (tens of ms each): a slot that has none yet works on the
+    // ctx's copy stream, which exists anyway and which the file path does not use otherwise
+    if (!s.stream && !s.h_zb && ctx->copy_stream) s.stream = ctx->copy_stream;
     if ((rc = ensure_slot(ctx, s))) return rc;
     hipStream_t q = s.stream;
     const uint64_t k = st->k_front;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     // ---- the members, and where their payloads go
     std::vector<bgzf::InflateBlock> blocks;
     size_t consumed = 0;
     uint64_t total = 0;
     std::string msg;
-    if (n_bytes && !scan_bgzf_members(members, n_bytes, blocks, &consumed, &total, msg)) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: %s", msg.c_str());
-    if (consumed != n_bytes) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: front takes whole BGZF members (%zu of %zu bytes are)", consumed, n_bytes);
+    if (raw) {
+        total = n_bytes;  // the caller has inflated the members: these are their payloads
+    } else {
+        if (n_bytes && !scan_bgzf_members(members, n_bytes, blocks, &consumed, &total, msg)) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: %s", msg.c_str());
+        if (consumed != n_bytes) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: front takes whole BGZF members (%zu of %zu bytes are)", consumed, n_bytes);
+    }
     const uint32_t carry = st->prev_len - st->prev_consumed;
     if ((uint64_t)carry + total > (uint64_t)bam::MAX_U) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu inflated bytes in one call (at most %u)", (unsigned long long)total + carry, bam::MAX_U);
     const uint32_t u_len = carry + (uint32_t)total;
     DevBuf &ub = st->u[k & 1];
-    if ((rc = reserve(ctx, ub, (size_t)u_len + 256))) return rc;
+    if ((rc = reserve_roomy(ctx, ub, (size_t)u_len + 256))) return rc;
     uint8_t *u = (uint8_t *)ub.p;
     if (carry) HIPCHK(ctx, hipMemcpyAsync(u, (const uint8_t *)st->u[(k + 1) & 1].p + st->prev_consumed, carry, hipMemcpyDeviceToDevice, q));
     const uint32_t nb = (uint32_t)blocks.size();
+    if (raw && n_bytes) HIPCHK(ctx, hipMemcpyAsync(u + carry, members, n_bytes, hipMemcpyHostToDevice, q));
     if (nb) {
         for (auto &b : blocks) b.dst_off += carry;
-        if ((rc = reserve(ctx, st->comp, n_bytes + 16)) || (rc = reserve(ctx, st->blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
-            (rc = reserve(ctx, st->status, 4 * (size_t)nb)) || (rc = reserve(ctx, st->ticket, 64)) ||
+        if ((rc = reserve_roomy(ctx, st->comp, n_bytes + 16)) || (rc = reserve_roomy(ctx, st->blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
+            (rc = reserve_roomy(ctx, st->status, 4 * (size_t)nb)) || (rc = reserve_roomy(ctx, st->ticket, 64)) ||
             (rc = reserve_pinned(ctx, st->h_blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)))
             return rc;
         memcpy(st->h_blocks.p, blocks.data(), sizeof(bgzf::InflateBlock) * (size_t)nb);
@@ -1938,8 +2009,8 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     // ---- framing
     const uint32_t n_seg = (u_len + bam::SEG - 1) / bam::SEG;
     const uint32_t rec_cap = u_len / 36u + 2u;
-    if ((rc = reserve(ctx, st->seg, 16 * (size_t)std::max(n_seg, 1u))) || (rc = reserve(ctx, st->slots, 4 * (size_t)bam::SEG_SLOTS * std::max(n_seg, 1u))) ||
-        (rc = reserve(ctx, st->rec_off, 4 * (size_t)rec_cap)) || (rc = reserve(ctx, st->counts, sizeof(bam::ChunkCounts))) ||
+    if ((rc = reserve_roomy(ctx, st->seg, 16 * (size_t)std::max(n_seg, 1u))) || (rc = reserve_roomy(ctx, st->slots, 4 * (size_t)bam::SEG_SLOTS * std::max(n_seg, 1u))) ||
+        (rc = reserve_roomy(ctx, st->rec_off, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, st->counts, sizeof(bam::ChunkCounts))) ||
         (rc = reserve_pinned(ctx, st->h_counts, sizeof(bam::ChunkCounts) + 16)))
         return rc;
     bam::ChunkCounts *d_counts = (bam::ChunkCounts *)st->counts.p;
@@ -1972,7 +2043,11 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     uint32_t *h_tick = (uint32_t *)(st->h_counts.p + sizeof(bam::ChunkCounts));
     h_tick[0] = h_tick[1] = 0;
     if (nb) HIPCHK(ctx, hipMemcpyAsync(h_tick, st->ticket.p, 8, hipMemcpyDeviceToHost, q));
+    const double t1 = now();
     HIPCHK(ctx, hipStreamSynchronize(q));  // (1) the records of this call
+    const double t2 = now();
+    st->t_inflate += t1 - t0;
+    st->t_frame += t2 - t1;
     if (nb && h_tick[1]) {
         std::vector<uint32_t> stt(nb);
         HIPCHK(ctx, hipMemcpy(stt.data(), st->status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
@@ -1999,8 +2074,8 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     if (n_rec) {
         // ---- the batch: which records go to the device's gate, their arrays
         const uint32_t nblk = (n_rec + bam::PACK_BLOCK - 1) / bam::PACK_BLOCK, ntb = (n_rec + bam::TAG_BLOCK - 1) / bam::TAG_BLOCK;
-        if ((rc = reserve(ctx, st->info, 4 * (size_t)n_rec)) || (rc = reserve(ctx, st->sent_of, 4 * (size_t)n_rec)) ||
-            (rc = reserve(ctx, st->out_size, 4 * (size_t)n_rec)) || (rc = reserve(ctx, st->blk32, 24 * (size_t)nblk)) || (rc = reserve(ctx, st->blk64, 16 * (size_t)ntb)))
+        if ((rc = reserve_roomy(ctx, st->info, 4 * (size_t)n_rec)) || (rc = reserve_roomy(ctx, st->sent_of, 4 * (size_t)n_rec)) ||
+            (rc = reserve_roomy(ctx, st->out_size, 4 * (size_t)n_rec)) || (rc = reserve_roomy(ctx, st->blk32, 24 * (size_t)nblk)) || (rc = reserve_roomy(ctx, st->blk64, 16 * (size_t)ntb)))
             return rc;
         bam::PackArgs pa;
         memset(&pa, 0, sizeof pa);
@@ -2019,7 +2094,11 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
+        const double t3 = now();
         HIPCHK(ctx, hipStreamSynchronize(q));  // (2) the sizes of the batch
+        const double t4 = now();
+        st->t_pack += t4 - t2;
+        (void)t3;
         if (h_counts->n_bad_layout)
             return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu: %u records whose fields do not fit their block_size or whose tags are not whole fields (corrupt BAM)", (unsigned long long)k, h_counts->n_bad_layout);
         const uint32_t n_sent = h_counts->n_sent;
@@ -2031,7 +2110,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         s.have_batch = false;
         s.cur = 0;
         s.L = batch_layout(n_sent, h_counts->n_cig, h_counts->n_seq);
-        if ((rc = reserve(ctx, s.in[0], s.L.total))) return rc;
+        if ((rc = reserve_roomy(ctx, s.in[0], s.L.total))) return rc;
         uint8_t *ib = (uint8_t *)s.in[0].p;
         pa.tid = (int32_t *)(ib + s.L.off[A_TID]);
         pa.pos = (int32_t *)(ib + s.L.off[A_POS]);
@@ -2072,7 +2151,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
             s.state = 2;
         }
         // ---- what anno.d:94-107 adds: sizes, offsets
-        if ((rc = reserve(ctx, st->art_of, 4 * (size_t)std::max(n_sent, 1u)))) return rc;
+        if ((rc = reserve_roomy(ctx, st->art_of, 4 * (size_t)std::max(n_sent, 1u)))) return rc;
         if (n_sent) {
             HIPCHK(ctx, hipMemsetAsync(st->art_of.p, 0xff, 4 * (size_t)n_sent, q));
             if (s.out_cap) {
@@ -2114,14 +2193,16 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
             HIPCHK(ctx, hipStreamSynchronize(q));
             st->stats[0] += n_rec;
         }
+        st->t_run += now() - t4;
         const uint64_t out_bytes = h_counts->out_bytes;
         if (out_bytes > ((uint64_t)1 << 31)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu output bytes in one call (at most 2^31)", (unsigned long long)out_bytes);
-        if ((rc = reserve(ctx, out->o, (size_t)out_bytes + 256))) return rc;
+        if ((rc = reserve_roomy(ctx, out->o, (size_t)out_bytes + 256))) return rc;
         ta.o = (uint8_t *)out->o.p;
         hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(ntb), dim3(bam::TAG_BLOCK), 0, q, ta);
         HIPCHK(ctx, hipGetLastError());
         out->bytes = (size_t)out_bytes;
         st->n_records += n_rec;
+        st->t_tags += now() - t4;
     }
     if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(out->ready, q));
@@ -2178,7 +2259,22 @@ int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_byte
     if (st->failed) return set_err(ctx, FADEHIP_E_STATE, "bam stream: an earlier call failed");
     if (st->ended) return set_err(ctx, FADEHIP_E_STATE, "bam stream: front after the last call");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int rc = bam_front_impl(st, (const uint8_t *)members, n_bytes, last);
+    const int rc = bam_front_impl(st, (const uint8_t *)members, n_bytes, last, false);
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->slots[0].stream);
+        return bam_fail(st, rc);
+    }
+    return 0;
+}
+
+int fadehip_bam_front_raw(fadehip_bam_stream *st, const void *payload, size_t n_bytes, int last) {
+    if (!st) return set_err(nullptr, FADEHIP_E_INVALID, "stream is NULL");
+    fadehip_ctx *ctx = st->ctx;
+    if (n_bytes && !payload) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
+    if (st->failed) return set_err(ctx, FADEHIP_E_STATE, "bam stream: an earlier call failed");
+    if (st->ended) return set_err(ctx, FADEHIP_E_STATE, "bam stream: front after the last call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = bam_front_impl(st, (const uint8_t *)payload, n_bytes, last, true);
     if (rc) {
         (void)hipStreamSynchronize(ctx->slots[0].stream);
         return bam_fail(st, rc);
@@ -2202,10 +2298,10 @@ int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_by
     int rc = 0;
     if (o->bytes) {
         const int lane = (int)(st->k_back & 1);  // the lanes in turn: a call's bytes stay valid during the next call
-        if ((rc = bgzf_lane_ready(ctx, lane))) return bam_fail(st, rc);
+        if ((rc = bgzf_lane_ready(ctx, lane, true))) return bam_fail(st, rc);
         BgzfLane &l = ctx->bgzf[lane];
         if (hipStreamWaitEvent(l.stream, o->ready, 0) != hipSuccess) return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: hipStreamWaitEvent failed"));
-        if ((rc = bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes)) || (rc = fadehip_bgzf_deflate_wait(ctx, lane, out, out_bytes))) return bam_fail(st, rc);
+        if ((rc = bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes, bgzf_pick_geom(ctx))) || (rc = fadehip_bgzf_deflate_wait(ctx, lane, out, out_bytes))) return bam_fail(st, rc);
     } else if (o->ready) {
         (void)hipEventSynchronize(o->ready);
     }
@@ -2235,6 +2331,10 @@ void fadehip_bam_close(fadehip_bam_stream *st) {
     }
     st->cv.notify_all();
     fadehip_ctx *ctx = st->ctx;
+    if (getenv("FADEHIP_BAM_PROF"))
+        fprintf(stderr, "[fadehip bam] %llu front calls: enqueue inflate+frame %.3f s, wait (1) %.3f | pack count + wait (2) %.3f | enqueue write+run+sizes, wait (3) %.3f, "
+                        "of front after (2) in all %.3f | segments walked again %lld\n", (unsigned long long)st->k_front, st->t_inflate, st->t_frame, st->t_pack, st->t_run, st->t_tags,
+                (long long)st->n_redone);
     (void)hipSetDevice(ctx->device);
     if (ctx->slots[0].stream) (void)hipStreamSynchronize(ctx->slots[0].stream);
     for (BgzfLane &l : ctx->bgzf)

@@ -782,10 +782,15 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     const std::string &path = o.pos[1];
     struct stat sb;
     if (!o.bam || path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
-    StageClock ck_total, ck_fasta, ck_upload, ck_front, ck_back, ck_fwrite, ck_fread;
+    StageClock ck_total, ck_fasta, ck_upload, ck_front, ck_back, ck_fwrite, ck_fread, ck_inflate;
     ck_total.start();
     const int nthreads = o.threads > 0 ? o.threads : default_threads();
-    Pool pool(std::min(nthreads, 4));
+    // Who inflates: the device (FADE_BAM_INFLATE=device: only compressed bytes cross PCIe, the host cores stay free) or this
+    // process's pool (host, the default with 8 threads or more: the cores have nothing else to do here, and the device then
+    // spends its time on the compressor, which is its slowest kernel).
+    const char *inf_env = getenv("FADE_BAM_INFLATE");
+    const bool host_inflate = inf_env ? strcmp(inf_env, "host") == 0 : nthreads >= 8;
+    Pool pool(host_inflate ? nthreads : std::min(nthreads, 4));
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return 1;
     struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
@@ -881,20 +886,36 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
             hw.close();
         }
         // ---- the stages
-        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : 64) << 20;
+        // FADE_BAM_CHUNK_MB: bytes per front call — compressed when the device inflates (default 128), inflated when the
+        // host does (default 64: the first call starts earlier and the last one drains sooner).  Compressed bytes are read
+        // by a thread of their own, HEAD bytes into a buffer, so that a member cut by the end of one read is completed by
+        // copying its beginning in front of the next.
+        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : host_inflate ? 64 : 128) << 20;
+        const size_t ccap = host_inflate ? std::max<size_t>(chunk / 2, 1 << 20) : chunk, HEAD = 65536 + 64;
         constexpr int NBUF = 3;
-        struct In { uint8_t *p = nullptr; size_t n = 0; bool last = false; };
+        struct CBuf { uint8_t *p = nullptr; size_t n = 0; bool eof = false; std::vector<uint8_t> own; };
+        struct In { uint8_t *p = nullptr; size_t n = 0; bool last = false; int cbuf = -1; };
+        CBuf cbufs[NBUF];
         In bufs[NBUF];
+        auto pinned = [&](size_t bytes) -> uint8_t * {
+            void *q = nullptr;
+            if (fadehip_host_alloc(ctx, bytes, &q)) throw std::runtime_error(fadehip_last_error(ctx));
+            guard.pinned.push_back(q);
+            return (uint8_t *)q;
+        };
         for (int k = 0; k < NBUF; k++) {
-            void *p = nullptr;
-            if (fadehip_host_alloc(ctx, chunk + 65536 + 64, &p)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
-            guard.pinned.push_back(p);
-            bufs[k].p = (uint8_t *)p;
+            if (host_inflate) {
+                cbufs[k].own.resize(HEAD + ccap + 64);
+                cbufs[k].p = cbufs[k].own.data();
+                bufs[k].p = pinned(chunk + 65536 + 64);
+            } else {
+                cbufs[k].p = pinned(HEAD + ccap + 64);  // (handed to front as they are: pinned)
+            }
         }
-        BoundedQueue<int> q_free(NBUF + 1), q_full(NBUF + 1), q_done(FADEHIP_BAM_CHUNKS + 1);
+        BoundedQueue<int> q_cfree(NBUF + 1), q_cfull(NBUF + 1), q_free(NBUF + 1), q_full(NBUF + 1), q_done(FADEHIP_BAM_CHUNKS + 1);
         struct OutRef { const uint8_t *p; size_t n; };
         BoundedQueue<OutRef> q_write(1);  // (a call's bytes stay valid during the next back call only)
-        for (int k = 0; k < NBUF; k++) q_free.push(k);
+        for (int k = 0; k < NBUF; k++) { q_cfree.push(k); q_free.push(k); }
         std::string stage_err;
         std::mutex err_m;
         auto set_err = [&](const std::string &e) {
@@ -905,54 +926,135 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         StageThreads stages;
         stages.unblock = [&] {
             abort_all = true;
-            q_free.close(); q_full.close(); q_done.close(); q_write.close();
+            q_cfree.close(); q_cfull.close(); q_free.close(); q_full.close(); q_done.close(); q_write.close();
         };
-        stages.th.emplace_back([&] {  // reader: whole members per buffer, the cut-off tail moves to the next buffer
+        // the members of buf[0, got): (offset, size, header length); stops in front of one that is not whole
+        struct Mem { size_t off, size, hl; uint32_t isz; };
+        auto scan_members = [&](const uint8_t *buf, size_t got, std::vector<Mem> &ms) -> size_t {
+            size_t w = 0;
+            ms.clear();
+            while (w + 18 <= got) {
+                const uint8_t *m = buf + w;
+                if (m[0] != 0x1f || m[1] != 0x8b) throw std::runtime_error("not a BGZF member in " + path);
+                const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
+                if (w + 12 + xlen > got) break;
+                size_t bs = 0;
+                for (size_t x = 12; x + 4 <= 12 + xlen;) {
+                    const size_t sl = (size_t)m[x + 2] | ((size_t)m[x + 3] << 8);
+                    if (m[x] == 'B' && m[x + 1] == 'C' && sl == 2 && x + 6 <= 12 + xlen) bs = ((size_t)m[x + 4] | ((size_t)m[x + 5] << 8)) + 1;
+                    x += 4 + sl;
+                }
+                if (bs < 12 + xlen + 10) throw std::runtime_error("BGZF member without a usable BC subfield in " + path);
+                if (w + bs > got) break;
+                uint32_t isz;
+                memcpy(&isz, m + bs - 4, 4);
+                if (isz > 65536) throw std::runtime_error("corrupt BGZF block (ISIZE beyond 64 KiB) in " + path);
+                ms.push_back(Mem{w, bs, 12 + xlen, isz});
+                w += bs;
+            }
+            return w;
+        };
+        stages.th.emplace_back([&] {  // file reader
             try {
                 uint64_t at = coff;
-                size_t tail_n = 0;
-                std::vector<uint8_t> tail;
                 int k;
                 bool eof = false;
-                while (!eof && !abort_all && q_free.pop(k)) {
-                    In &b = bufs[k];
-                    if (tail_n) memcpy(b.p, tail.data(), tail_n);
+                while (!eof && !abort_all && q_cfree.pop(k)) {
+                    CBuf &c = cbufs[k];
                     ck_fread.start();
-                    size_t got = tail_n;
-                    while (got < chunk) {
-                        const ssize_t r = pread(fileno(f), b.p + got, chunk - got, (off_t)at);
+                    size_t got = 0;
+                    while (got < ccap) {
+                        const ssize_t r = pread(fileno(f), c.p + HEAD + got, ccap - got, (off_t)at);
                         if (r < 0) throw std::runtime_error("read error on " + path);
                         if (r == 0) { eof = true; break; }
                         got += (size_t)r;
                         at += (uint64_t)r;
                     }
                     ck_fread.stop();
-                    // whole members
-                    size_t w = 0;
-                    while (w + 18 <= got) {
-                        const uint8_t *m = b.p + w;
-                        if (m[0] != 0x1f || m[1] != 0x8b) throw std::runtime_error("not a BGZF member in " + path);
-                        const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
-                        if (w + 12 + xlen > got) break;
-                        size_t bs = 0;
-                        for (size_t x = 12; x + 4 <= 12 + xlen;) {
-                            const size_t sl = (size_t)m[x + 2] | ((size_t)m[x + 3] << 8);
-                            if (m[x] == 'B' && m[x + 1] == 'C' && sl == 2 && x + 6 <= 12 + xlen) bs = ((size_t)m[x + 4] | ((size_t)m[x + 5] << 8)) + 1;
-                            x += 4 + sl;
-                        }
-                        if (bs < 12 + xlen + 10) throw std::runtime_error("BGZF member without a usable BC subfield in " + path);
-                        if (w + bs > got) break;
-                        w += bs;
-                    }
-                    if (eof && w != got) throw std::runtime_error("the file ends inside a BGZF member: " + path);
-                    tail_n = got - w;
-                    tail.assign(b.p + w, b.p + got);
-                    b.n = w;
-                    b.last = eof;
-                    q_full.push(k);
+                    c.n = got;
+                    c.eof = eof;
+                    q_cfull.push(k);
                 }
             } catch (const std::exception &e) {
                 set_err(e.what());
+            }
+            q_cfull.close();
+        });
+        stages.th.emplace_back([&] {  // members: cut (and, in host mode, inflated on the pool) into the calls' buffers
+            try {
+                std::vector<uint8_t> tail;
+                std::vector<Mem> ms;
+                int ck;
+                bool ended = false;
+                while (!ended && !abort_all && q_cfull.pop(ck)) {
+                    CBuf &c = cbufs[ck];
+                    if (tail.size() > HEAD) throw std::runtime_error("BGZF member larger than 64 KiB in " + path);
+                    uint8_t *cb = c.p + HEAD - tail.size();
+                    if (!tail.empty()) memcpy(cb, tail.data(), tail.size());
+                    const size_t got = tail.size() + c.n;
+                    const size_t w = scan_members(cb, got, ms);
+                    tail.assign(cb + w, cb + got);
+                    if (c.eof && !tail.empty()) throw std::runtime_error("the file ends inside a BGZF member: " + path);
+                    ended = c.eof;
+                    if (!host_inflate) {
+                        // the compressed bytes go to the device as they lie; the buffer comes back when front is done with it
+                        In in;
+                        in.p = cb; in.n = w; in.last = ended; in.cbuf = ck;
+                        int slot;
+                        if (!q_free.pop(slot)) break;
+                        bufs[slot] = in;
+                        q_full.push(slot);
+                        continue;
+                    }
+                    // host mode: batches of members whose payloads fill a pinned buffer
+                    size_t m0 = 0;
+                    do {
+                        size_t total = 0, m1 = m0;
+                        while (m1 < ms.size() && total + ms[m1].isz <= chunk) total += ms[m1++].isz;
+                        int slot;
+                        if (!q_free.pop(slot)) { ended = true; break; }
+                        In &b = bufs[slot];
+                        std::vector<size_t> ooff(m1 - m0 + 1, 0);
+                        for (size_t j = m0; j < m1; j++) ooff[j - m0 + 1] = ooff[j - m0] + ms[j].isz;
+                        std::atomic<bool> bad{false};
+                        ck_inflate.start();
+                        pool.parallel_for((m1 - m0 + 1) / 2, [&](size_t t) {
+                            static thread_local std::unique_ptr<FastInflate> fi[2];
+                            if (!fi[0]) { fi[0].reset(new FastInflate()); fi[1].reset(new FastInflate()); }
+                            const uint8_t *src[2] = {nullptr, nullptr};
+                            size_t slen[2] = {0, 0}, jj[2] = {0, 0};
+                            int n = 0;
+                            for (size_t j = m0 + 2 * t; j < std::min(m1, m0 + 2 * t + 2); j++) {
+                                if (ms[j].isz == 0) continue;
+                                src[n] = cb + ms[j].off + ms[j].hl;
+                                slen[n] = ms[j].size - ms[j].hl - 8;
+                                jj[n++] = j;
+                            }
+                            if (n == 2) {
+                                if (!FastInflate::inflate2(*fi[0], src[0], slen[0], b.p + ooff[jj[0] - m0], ms[jj[0]].isz, *fi[1], src[1], slen[1], b.p + ooff[jj[1] - m0], ms[jj[1]].isz)) bad = true;
+                            } else if (n == 1) {
+                                if (!fi[0]->inflate(src[0], slen[0], b.p + ooff[jj[0] - m0], ms[jj[0]].isz)) bad = true;
+                            }
+                            for (int q = 0; q < n; q++) {  // the members' CRC32 (RFC 1952 trailer), as htslib checks it
+                                uint32_t crc;
+                                memcpy(&crc, cb + ms[jj[q]].off + ms[jj[q]].size - 8, 4);
+                                if (crc32_fast(0, b.p + ooff[jj[q] - m0], ms[jj[q]].isz) != crc) bad = true;
+                            }
+                        }, CPU_INFLATE);
+                        ck_inflate.stop();
+                        if (bad) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
+                        b.n = total;
+                        b.last = ended && m1 == ms.size();
+                        b.cbuf = -1;
+                        q_full.push(slot);
+                        m0 = m1;
+                    } while (m0 < ms.size());
+                    q_cfree.push(ck);  // (inflated: the compressed bytes are done with)
+                }
+            } catch (const std::exception &e) {
+                set_err(e.what());
+                abort_all = true;
+                q_cfree.close();
             }
             q_full.close();
         });
@@ -989,14 +1091,16 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         bool failed = false;
         while (!failed && !abort_all && q_full.pop(k)) {
             ck_front.start();
-            const int rc = fadehip_bam_front(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0);
+            const int rc = host_inflate ? fadehip_bam_front_raw(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0)
+                                        : fadehip_bam_front(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0);
             ck_front.stop();
             if (rc) { set_err(std::string("device: ") + fadehip_last_error(ctx)); failed = true; break; }
+            if (bufs[k].cbuf >= 0) q_cfree.push(bufs[k].cbuf);  // (device mode: the compressed bytes have been copied up)
             q_free.push(k);
             q_done.push(0);
         }
         q_done.close();
-        if (failed) { abort_all = true; q_free.close(); while (q_full.pop(k)) {} }
+        if (failed) { abort_all = true; q_free.close(); q_cfree.close(); while (q_full.pop(k)) {} }
         for (auto &t : stages.th) t.join();
         stages.unblock = nullptr;
         if (!stage_err.empty()) { fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str()); return 1; }
@@ -1014,10 +1118,11 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         }
         ck_total.stop();
         if (o.timing) {
-            fprintf(stderr, "[timing] total %.3f s: fasta %.3f, create+genome upload %.3f | reader: file reads %.3f | front (inflate, frame, annotate, tags) %.3f | "
+            fprintf(stderr, "[timing] total %.3f s: fasta %.3f, create+genome upload %.3f | reader: file reads %.3f, inflate on %d host threads %.3f | front (%sframe, annotate, tags) %.3f | "
                             "back (deflate, copy out) %.3f | fwrite %.3f (stages overlap); %lld records\n",
-                    ck_total.t, ck_fasta.t, ck_upload.t, ck_fread.t, ck_front.t, ck_back.t, ck_fwrite.t, (long long)n_rec);
+                    ck_total.t, ck_fasta.t, ck_upload.t, ck_fread.t, host_inflate ? pool.size() : 0, ck_inflate.t, host_inflate ? "" : "inflate, ", ck_front.t, ck_back.t, ck_fwrite.t, (long long)n_rec);
         }
+        if (getenv("FADEHIP_BAM_PROF")) { fadehip_bam_close(st); st = nullptr; }  // (prints the library's own clocks)
         if (!(getenv("FADE_FAST_EXIT") && atoi(getenv("FADE_FAST_EXIT")) == 0)) {
             if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (leaving by _exit)\n", since_process_start());
             fflush(stdout);

@@ -1713,7 +1713,7 @@ private:
         io_.put(std::move(outs));
     }
     void flush_blocks_device(bool all) {
-        const size_t B = 0xff00;
+        const size_t B = 0xff00;  // (the device cuts a submission into blocks of this size or half of it)
         size_t used = all ? raw_.size() : raw_.size() / B * B;
         if (!used) return;
         if (dev_busy_.empty()) dev_busy_.assign((size_t)dev_->lanes(), false);

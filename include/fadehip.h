@@ -254,7 +254,11 @@ int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t co
  *   submit : H2D of src[0, n_bytes) (host memory; pinned memory from fadehip_host_alloc copies at PCIe speed), the
  *            kernels; returns at once.  src must stay unchanged until wait returns.
  *   wait   : the members' bytes in a pinned buffer of the lane, valid until the lane's next submit.
- * Two lanes, each with its own stream: one compresses while the other's result is copied back. */
+ * Two lanes, each with its own stream: one compresses while the other's result is copied back.
+ * A call's input is cut into blocks of FADEHIP_BGZF_BLOCK bytes (htslib's block size; the block fills a CU's LDS), or —
+ * while the stream is mostly incompressible (the previous call's ratio above 0.45: packed bases, uniform qualities) —
+ * of half that (0x7f00): two blocks then share a CU and the rate is 1.5x, for 0.5 % more output.  Either way the
+ * stream stays smaller than zlib -6's over 0xff00-byte blocks (tests/test_gpu_bgzf.py).  FADEHIP_BGZF_GEOM=64|32 pins it. */
 #define FADEHIP_BGZF_BLOCK 0xff00
 #define FADEHIP_BGZF_LANES 2
 int fadehip_bgzf_deflate_submit(fadehip_ctx *ctx, int lane, const void *src, size_t n_bytes);
@@ -304,6 +308,9 @@ typedef struct fadehip_bam_config {
 #define FADEHIP_BAM_CHUNKS 3
 int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out);
 int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_bytes, int last);
+/* front for a caller that inflates itself (host cores otherwise idle; the device then spends its time on the rest):
+ * payload = the members' inflated bytes, any cut, pinned memory for PCIe speed.  Calls of both kinds may alternate. */
+int fadehip_bam_front_raw(fadehip_bam_stream *st, const void *payload, size_t n_bytes, int last);
 int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_bytes);
 /* totals so far: the eight Stats.parse counters (stats.d:45-54), records, reads beyond the kernels' limits */
 int fadehip_bam_totals(fadehip_bam_stream *st, int64_t stats[8], int64_t *n_records, int64_t *n_oversize);

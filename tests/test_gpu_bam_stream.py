@@ -56,7 +56,7 @@ def test_device_file_path_equals_the_host_pipeline_on_the_golden_inputs(tmp_path
     bam = tmp_path / "in.bam"
     _bam_of(os.path.join(GOLD, tag + ".sam"), bam)
     base = ["annotate", "--stats", "--timing", "--min-length", str(floor_len), "-w", str(window), "-b", str(bam), os.path.join(GOLD, tag + ".fa")]
-    dev = _run(base)
+    dev = _run(base, {"FADE_BAM_INFLATE": "device"})
     host = _run(base, {"FADE_BAM_DEVICE": "0"})
     assert dev.returncode == 0, dev.stderr.decode()[-2000:]
     assert host.returncode == 0, host.stderr.decode()[-2000:]
@@ -70,7 +70,7 @@ def test_device_file_path_equals_the_host_pipeline_on_the_golden_inputs(tmp_path
     again = tmp_path / "anno.bam"
     again.write_bytes(dev.stdout)
     base2 = base[:-2] + [str(again), base[-1]]
-    dev2 = _run(base2)
+    dev2 = _run(base2, {"FADE_BAM_INFLATE": "host"})
     host2 = _run(base2, {"FADE_BAM_DEVICE": "0"})
     assert dev2.returncode == 0 and host2.returncode == 0, dev2.stderr.decode()[-2000:]
     assert gzip.decompress(dev2.stdout) == gzip.decompress(host2.stdout)
@@ -98,9 +98,13 @@ def big(tmp_path_factory):
     return dict(bam=bam, fa=fa, host=host, g=g)
 
 
+@pytest.mark.parametrize("inflate", ["device", "host"])
 @pytest.mark.parametrize("chunk_mb", ["1", "64"])
-def test_records_that_straddle_members_and_calls(big, chunk_mb):
-    dev = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", str(big["bam"]), str(big["fa"])], {"FADE_BAM_CHUNK_MB": chunk_mb})
+def test_records_that_straddle_members_and_calls(big, chunk_mb, inflate):
+    """Small calls (1 MB: records straddle members AND calls; the tail of one call is carried to the next on the device) and
+    one large call; the members inflated by the device, or by this process's pool (fadehip_bam_front_raw)."""
+    dev = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", str(big["bam"]), str(big["fa"])], {"FADE_BAM_CHUNK_MB": chunk_mb, "FADE_BAM_INFLATE": inflate})
+    assert (b"inflate on 0 host threads" in dev.stderr) == (inflate == "device")
     assert dev.returncode == 0, dev.stderr.decode()[-2000:]
     assert b"file path on the device" in dev.stderr
     assert gzip.decompress(dev.stdout) == gzip.decompress(big["host"].stdout)
@@ -169,8 +173,9 @@ def test_corrupt_inputs_fail_the_run(tmp_path, big):
     raw[at] ^= 0x10
     bad = tmp_path / "bad.bam"
     bad.write_bytes(bytes(raw))
-    p = _run(["annotate", "-b", "-w", "100", str(bad), str(big["fa"])])
-    assert p.returncode != 0 and b"[E::fade annotate]" in p.stderr
+    for mode in ("device", "host"):
+        p = _run(["annotate", "-b", "-w", "100", str(bad), str(big["fa"])], {"FADE_BAM_INFLATE": mode})
+        assert p.returncode != 0 and b"[E::fade annotate]" in p.stderr, mode
     # a file cut inside a member, and one cut between members but inside a record
     whole = big["bam"].read_bytes()
     cut1 = tmp_path / "cut1.bam"

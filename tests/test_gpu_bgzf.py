@@ -15,7 +15,9 @@ from fade_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
-BLOCK = _lib.BGZF_BLOCK
+BLOCK = _lib.BGZF_BLOCK  # htslib's block size: what the zlib -6 comparator is cut into, and the device's larger geometry
+HTS_BLOCK = BLOCK
+SMALL = 0x7f00           # the device's smaller geometry (two blocks per CU), taken while the stream hardly compresses
 EOF_MARK = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 
 
@@ -34,9 +36,9 @@ def members(buf):
 
 def zlib6_size(data):
     total = 0
-    for o in range(0, len(data), BLOCK):
+    for o in range(0, len(data), HTS_BLOCK):
         c = zlib.compressobj(6, zlib.DEFLATED, -15)
-        total += len(c.compress(data[o:o + BLOCK]) + c.flush()) + 26
+        total += len(c.compress(data[o:o + HTS_BLOCK]) + c.flush()) + 26
     return total
 
 
@@ -88,11 +90,12 @@ def test_members_inflate_to_the_input_and_are_no_larger_than_zlib6(ctx, payloads
     for name, data in payloads.items():
         out = ctx.bgzf_deflate(data)
         ms = members(out)
-        assert len(ms) == (len(data) + BLOCK - 1) // BLOCK, name
+        assert len(ms) in ((len(data) + BLOCK - 1) // BLOCK, (len(data) + SMALL - 1) // SMALL), name
+        cut = BLOCK if len(ms) == (len(data) + BLOCK - 1) // BLOCK else SMALL
         at = 0
         for payload, crc, isize in ms:  # each member on its own: raw DEFLATE, CRC32 and ISIZE of its block
             raw = zlib.decompress(payload, -15)
-            assert raw == data[at:at + isize] and zlib.crc32(raw) == crc and isize == min(BLOCK, len(data) - at), (name, at)
+            assert raw == data[at:at + isize] and zlib.crc32(raw) == crc and isize == min(cut, len(data) - at), (name, at)
             at += isize
         assert gzip.decompress(out + EOF_MARK) == data, name  # and as the file a BAM reader sees
         if name.startswith("bam"):
