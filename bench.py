@@ -130,7 +130,7 @@ def e2e_legs(bam, fa, n_reads, cfg, threads, tmp):
     cpu = os.path.join(ROOT, "tools", "cpu_annotate")
     res = {}
 
-    def run(tag, exe, reps):
+    def run(tag, exe, reps, env=None):
         best = None
         out = os.path.join(tmp, "bench_e2e.%s.bam" % tag)
         for _ in range(reps):
@@ -139,7 +139,7 @@ def e2e_legs(bam, fa, n_reads, cfg, threads, tmp):
             t1 = time.perf_counter()
             with open(out, "wb") as fo:
                 p = subprocess.run([exe, "annotate", "--timing", "-t", str(threads), "-w", str(cfg["window"]), "--min-length",
-                                    str(cfg["floor_len"]), "-b", bam, fa], stdout=fo, stderr=subprocess.PIPE)
+                                    str(cfg["floor_len"]), "-b", bam, fa], stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
             dt = time.perf_counter() - t1
             if p.returncode != 0:
                 return dict(error=p.stderr.decode(errors="replace")[-400:])
@@ -150,7 +150,10 @@ def e2e_legs(bam, fa, n_reads, cfg, threads, tmp):
         os.remove(out)
         return best
 
+    # default: the file path on the device (framing, annotate, tags, deflate as kernels), BGZF inflate on the host pool
     res["gpu"] = run("gpu", fade, 2)
+    res["gpu_device_inflate"] = run("gpu_di", fade, 2, {"FADE_BAM_INFLATE": "device"})  # ... inflate on the device too
+    res["gpu_host_pipeline"] = run("gpu_hp", fade, 1, {"FADE_BAM_DEVICE": "0"})  # round 2's pipeline (+ device deflate)
     res["cpu"] = run("cpu", cpu, 1)
     return res
 
@@ -408,11 +411,16 @@ def main():
         if do_e2e:
             e = e2e_legs(bam_path, fa_path, e2e_written, cfg, usable_cpus(), tmp)
             g, c = e.get("gpu") or {}, e.get("cpu") or {}
-            out["e2e"] = {"what": "`fade annotate -b` BAM -> BAM on a %d-read file of this workload, wall time of the whole process, %d host threads; "
+            out["e2e"] = {"what": "`fade annotate -b` BAM -> BAM on a %d-read file of this workload, wall time of the whole process, %d host threads.  gpu = the "
+                                  "default: the file path on the device (record framing, annotate, tags, BGZF deflate as kernels; BGZF inflate on the host pool); "
+                                  "gpu_device_inflate = FADE_BAM_INFLATE=device (inflate as a kernel too: only compressed bytes cross PCIe); gpu_host_pipeline = "
+                                  "FADE_BAM_DEVICE=0 (records handled by the host pool, level-2 batches to the device, deflate on the device); "
                                   "cpu = tools/cpu_annotate: the same reader / writer / codec around the CPU oracle" % (e2e_written, usable_cpus()),
                           "gpu_reads_per_s": g.get("reads_per_s"), "cpu_reads_per_s": c.get("reads_per_s"),
                           "gpu_over_cpu": (g["reads_per_s"] / c["reads_per_s"]) if g.get("reads_per_s") and c.get("reads_per_s") else None,
-                          "gpu": g, "cpu": c}
+                          "gpu_device_inflate_reads_per_s": (e.get("gpu_device_inflate") or {}).get("reads_per_s"),
+                          "gpu_host_pipeline_reads_per_s": (e.get("gpu_host_pipeline") or {}).get("reads_per_s"),
+                          "gpu": g, "gpu_device_inflate": e.get("gpu_device_inflate"), "gpu_host_pipeline": e.get("gpu_host_pipeline"), "cpu": c}
             for pth in (bam_path, fa_path):
                 if os.path.exists(pth):
                     os.remove(pth)

@@ -239,6 +239,11 @@ __device__ __forceinline__ uint32_t aux_field_size(const uint8_t *p, uint32_t q,
     if (s) return q + 1u + (uint32_t)s <= end ? 1u + (uint32_t)s : 0u;
     if (t == 'Z' || t == 'H') {
         uint32_t k = q + 1u;
+        while (k + 4u <= end) {  // four bytes per load: stop at the dword that holds a zero byte
+            const uint32_t v = ld32(p + k);
+            if ((v - 0x01010101u) & ~v & 0x80808080u) break;
+            k += 4u;
+        }
         while (k < end && p[k]) k++;
         return k < end ? k - q + 1u : 0u;
     }

@@ -2243,8 +2243,10 @@ int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_ba
     off[(size_t)cfg->n_ref] = (uint32_t)text.size();
     int rc;
     if ((rc = reserve(ctx, st->names_text, text.size() + 1)) || (rc = reserve(ctx, st->names_off, 4 * off.size()))) { fadehip_bam_close(st); return rc; }
-    if (hipMemcpy(st->names_text.p, text.data(), text.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(st->names_off.p, off.data(), 4 * off.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    // (on the ctx's copy stream: a synchronous hipMemcpy would bring up the null stream, one more queue to set up and to give back)
+    if (hipMemcpyAsync(st->names_text.p, text.data(), text.size(), hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+        hipMemcpyAsync(st->names_off.p, off.data(), 4 * off.size(), hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->copy_stream) != hipSuccess) {
         fadehip_bam_close(st);
         return set_err(ctx, FADEHIP_E_HIP, "bam stream: copying the contig names failed");
     }

@@ -866,31 +866,13 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         if (hdr.names.empty()) { fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n"); return 1; }
         ck_upload.start();
         if (creating.get()) { fprintf(stderr, "[E::fade annotate] cannot open the GPU path: %s\n", create_err.c_str()); return 1; }
-        if (fadehip_genome_upload(ctx, (int)lens.size(), lens.data(), ptrs.data())) { fprintf(stderr, "[E::fade annotate] genome upload: %s\n", fadehip_last_error(ctx)); return 1; }
-        std::vector<const char *> names;
-        for (auto &n : hdr.names) names.push_back(n.c_str());
-        fadehip_bam_config cfg;
-        memset(&cfg, 0, sizeof cfg);
-        cfg.floor_len = o.floor_len;
-        cfg.window = o.window;
-        cfg.n_ref = (int32_t)names.size();
-        cfg.ref_names = names.data();
-        cfg.first_record = first_rec;
-        if (fadehip_bam_open(ctx, &cfg, &st)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
         ck_upload.stop();
-        fa.seqs.clear();
-        fa.seqs.shrink_to_fit();
-        // the header goes out through the CPU writer (its members only: no end-of-file block yet)
-        {
-            Writer hw(stdout, OutFmt::BAM, out_hdr, &pool, nullptr, true, false);
-            hw.close();
-        }
         // ---- the stages
         // FADE_BAM_CHUNK_MB: bytes per front call — compressed when the device inflates (default 128), inflated when the
-        // host does (default 64: the first call starts earlier and the last one drains sooner).  Compressed bytes are read
+        // host does (default 32: the first call starts earlier and the last one drains sooner; 64 and 128 measured slower).  Compressed bytes are read
         // by a thread of their own, HEAD bytes into a buffer, so that a member cut by the end of one read is completed by
         // copying its beginning in front of the next.
-        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : host_inflate ? 64 : 128) << 20;
+        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : host_inflate ? 32 : 128) << 20;
         const size_t ccap = host_inflate ? std::max<size_t>(chunk / 2, 1 << 20) : chunk, HEAD = 65536 + 64;
         constexpr int NBUF = 3;
         struct CBuf { uint8_t *p = nullptr; size_t n = 0; bool eof = false; std::vector<uint8_t> own; };
@@ -1087,6 +1069,27 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                 ck_fwrite.stop();
             }
         });
+        // (the reader and the inflating pool are at work by now: the genome goes up beside them)
+        ck_upload.start();
+        if (fadehip_genome_upload(ctx, (int)lens.size(), lens.data(), ptrs.data())) { fprintf(stderr, "[E::fade annotate] genome upload: %s\n", fadehip_last_error(ctx)); return 1; }
+        std::vector<const char *> names;
+        for (auto &n : hdr.names) names.push_back(n.c_str());
+        fadehip_bam_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.floor_len = o.floor_len;
+        cfg.window = o.window;
+        cfg.n_ref = (int32_t)names.size();
+        cfg.ref_names = names.data();
+        cfg.first_record = first_rec;
+        if (fadehip_bam_open(ctx, &cfg, &st)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
+        ck_upload.stop();
+        fa.seqs.clear();
+        fa.seqs.shrink_to_fit();
+        // the header goes out through the CPU writer (its members only: no end-of-file block yet)
+        {
+            Writer hw(stdout, OutFmt::BAM, out_hdr, &pool, nullptr, true, false);
+            hw.close();
+        }
         int k;
         bool failed = false;
         while (!failed && !abort_all && q_full.pop(k)) {
