@@ -148,3 +148,24 @@ enum FADEHIP_BGZF_BLOCK = 0xff00;
 enum FADEHIP_BGZF_LANES = 2;
 int fadehip_bgzf_deflate_submit(fadehip_ctx* ctx, int lane, const(void)* src, size_t n_bytes);
 int fadehip_bgzf_deflate_wait(fadehip_ctx* ctx, int lane, const(ubyte)** out_, size_t* out_bytes);
+/// whole BGZF members in, their payloads out (one wavefront per member; CRC32 and ISIZE checked)
+int fadehip_bgzf_inflate(fadehip_ctx* ctx, const(void)* members, size_t n_bytes, void* out_, size_t out_cap, size_t* out_bytes);
+
+/// The file path on the device: anno.d:44-50 as a byte stream (fadehip.h, "the file path on the device")
+struct fadehip_bam_stream;
+struct fadehip_bam_config {
+    int floor_len;               /// --min-length
+    int window;                  /// -w
+    int n_ref;                   /// contigs of the BAM header
+    int reserved;
+    const(char*)* ref_names;     /// [n_ref]
+    uint first_record;           /// payload bytes of the first member passed that precede the first record
+    uint reserved2;
+}
+enum FADEHIP_BAM_CHUNKS = 3;
+int fadehip_bam_open(fadehip_ctx* ctx, const(fadehip_bam_config)* cfg, fadehip_bam_stream** out_);
+int fadehip_bam_front(fadehip_bam_stream* st, const(void)* members, size_t n_bytes, int last);
+int fadehip_bam_front_raw(fadehip_bam_stream* st, const(void)* payload, size_t n_bytes, int last);
+int fadehip_bam_back(fadehip_bam_stream* st, const(ubyte)** out_, size_t* out_bytes);
+int fadehip_bam_totals(fadehip_bam_stream* st, long* stats8, long* n_records, long* n_oversize);
+void fadehip_bam_close(fadehip_bam_stream* st);
