@@ -779,6 +779,7 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
 // output that is not BAM, --gpus N) takes the host pipeline of annotate_main instead.
 static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall_back) {
     *fall_back = true;
+    const LaneEnv lane = lane_env();  // set when this process is one lane of a `--gpus N` run (annotate_lanes_main): a range of the file
     const std::string &path = o.pos[1];
     struct stat sb;
     if (!o.bam || path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
@@ -789,7 +790,8 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     // process's pool (host, the default with 8 threads or more: the cores have nothing else to do here, and the device then
     // spends its time on the compressor, which is its slowest kernel).
     const char *inf_env = getenv("FADE_BAM_INFLATE");
-    const bool host_inflate = inf_env ? strcmp(inf_env, "host") == 0 : nthreads >= 8;
+    // (a lane's last member is cut where the next lane's first record starts: done on the inflated bytes, so lanes inflate here)
+    const bool host_inflate = lane.on || (inf_env ? strcmp(inf_env, "host") == 0 : nthreads >= 8);
     Pool pool(host_inflate ? nthreads : std::min(nthreads, 4));
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return 1;
@@ -804,7 +806,11 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         hdr = rd.header();
         const size_t hdr_bytes = rd.bam_header_bytes();
         uint64_t at = 0, cum = 0;
-        for (;;) {
+        if (lane.on) {
+            coff = lane.range.coff_start;
+            first_rec = (uint32_t)lane.range.first_rec;
+        }
+        while (!lane.on) {
             uint8_t h[18], t[4];
             if (pread(fileno(f), h, 18, (off_t)at) != 18) return 1;
             if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') return 1;  // (other gzip subfields first: the host path reads it)
@@ -821,7 +827,19 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     }
     *fall_back = false;
     if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (annotate begins; file path on the device)\n", since_process_start());
-    fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+    if (!lane.on) fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
+    // a lane reads the members in front of coff_end whole and, of the member AT coff_end, the end_rec bytes in front of the next
+    // lane's first record
+    uint64_t read_end = (uint64_t)sb.st_size;
+    const bool limited = lane.on && lane.range.coff_end != 0;
+    if (limited) {
+        read_end = lane.range.coff_end;
+        if (lane.range.end_rec > 0) {
+            uint8_t h[18];
+            if (pread(fileno(f), h, 18, (off_t)lane.range.coff_end) != 18 || h[12] != 'B' || h[13] != 'C') { fprintf(stderr, "[E::fade annotate] lane range ends at no BGZF member\n"); return 1; }
+            read_end += (uint64_t)(h[16] | (h[17] << 8)) + 1u;
+        }
+    }
     fadehip_ctx *ctx = nullptr;
     fadehip_bam_stream *st = nullptr;
     struct Guard {
@@ -839,7 +857,8 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         fadehip_params_default(&prm);
         setenv("FADEHIP_TAIL_CUS", "0", 0);  // one batch at a time: no CU-masked stream, fewer queues
         int device = 0;
-        if (const char *dm = getenv("FADE_DEVICE_MAP")) device = atoi(dm);
+        if (lane.on) device = lane.device;
+        else if (const char *dm = getenv("FADE_DEVICE_MAP")) device = atoi(dm);
         std::string create_err;
         std::future<int> creating = std::async(std::launch::async, [&]() -> int {
             if (fadehip_create(&ctx, device, &prm)) { create_err = fadehip_last_error(nullptr); return 1; }
@@ -849,7 +868,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
         ck_fasta.stop();
         Header out_hdr = hdr;
-        out_hdr.add_pg("fade-annotate", "fade", FADE_VERSION, cl);  // anno.d:25-32
+        out_hdr.add_pg("fade-annotate", "fade", FADE_VERSION, lane.on ? lane.cl : cl);  // anno.d:25-32
         std::vector<int64_t> lens(hdr.names.size());
         std::vector<const uint8_t *> ptrs(hdr.names.size());
         for (size_t k = 0; k < hdr.names.size(); k++) {
@@ -875,7 +894,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : host_inflate ? 32 : 128) << 20;
         const size_t ccap = host_inflate ? std::max<size_t>(chunk / 2, 1 << 20) : chunk, HEAD = 65536 + 64;
         constexpr int NBUF = 3;
-        struct CBuf { uint8_t *p = nullptr; size_t n = 0; bool eof = false; std::vector<uint8_t> own; };
+        struct CBuf { uint8_t *p = nullptr; size_t n = 0; uint64_t off = 0; bool eof = false; std::vector<uint8_t> own; };
         struct In { uint8_t *p = nullptr; size_t n = 0; bool last = false; int cbuf = -1; };
         CBuf cbufs[NBUF];
         In bufs[NBUF];
@@ -945,8 +964,10 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                     CBuf &c = cbufs[k];
                     ck_fread.start();
                     size_t got = 0;
+                    c.off = at;
                     while (got < ccap) {
-                        const ssize_t r = pread(fileno(f), c.p + HEAD + got, ccap - got, (off_t)at);
+                        const size_t want = (size_t)std::min<uint64_t>(ccap - got, read_end - at);
+                        const ssize_t r = want ? pread(fileno(f), c.p + HEAD + got, want, (off_t)at) : 0;
                         if (r < 0) throw std::runtime_error("read error on " + path);
                         if (r == 0) { eof = true; break; }
                         got += (size_t)r;
@@ -974,6 +995,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                     uint8_t *cb = c.p + HEAD - tail.size();
                     if (!tail.empty()) memcpy(cb, tail.data(), tail.size());
                     const size_t got = tail.size() + c.n;
+                    const uint64_t cb_off = c.off - tail.size();  // file offset of cb[0]
                     const size_t w = scan_members(cb, got, ms);
                     tail.assign(cb + w, cb + got);
                     if (c.eof && !tail.empty()) throw std::runtime_error("the file ends inside a BGZF member: " + path);
@@ -1025,6 +1047,11 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                         }, CPU_INFLATE);
                         ck_inflate.stop();
                         if (bad) throw std::runtime_error("BGZF block does not inflate to its ISIZE / CRC32 (corrupt input)");
+                        // a lane's last member: only the bytes in front of the next lane's first record are this lane's
+                        if (limited && m1 == ms.size() && m1 > m0 && cb_off + ms[m1 - 1].off == lane.range.coff_end) {
+                            if (lane.range.end_rec > ms[m1 - 1].isz) throw std::runtime_error("lane range ends beyond its last block");
+                            total -= ms[m1 - 1].isz - (size_t)lane.range.end_rec;
+                        }
                         b.n = total;
                         b.last = ended && m1 == ms.size();
                         b.cbuf = -1;
@@ -1087,7 +1114,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         fa.seqs.shrink_to_fit();
         // the header goes out through the CPU writer (its members only: no end-of-file block yet)
         {
-            Writer hw(stdout, OutFmt::BAM, out_hdr, &pool, nullptr, true, false);
+            Writer hw(stdout, OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0, false);
             hw.close();
         }
         int k;
@@ -1107,13 +1134,35 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         for (auto &t : stages.th) t.join();
         stages.unblock = nullptr;
         if (!stage_err.empty()) { fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str()); return 1; }
-        fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout);
+        if (!lane.on) fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout);
         fflush(stdout);
         int64_t totals[8], n_rec = 0, n_over = 0;
         fadehip_bam_totals(st, totals, &n_rec, &n_over);
-        if (n_over) fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read longer than %d bases or window longer than %d\n",
+        if (lane.on) {
+            // the lane's report for the parent; lanes on distinct devices first sum their counters among themselves (the one
+            // collective of the path: ncclAllReduce over xGMI, one rank per process)
+            long long red[8];
+            bool have_red = false;
+            if (lane.rccl && lane.n > 1) {
+                int64_t t[8];
+                std::copy(totals, totals + 8, t);
+                if (fadehip_stats_allreduce_rank(ctx, lane.k, lane.n, lane.id_path.c_str(), t, 8)) { fprintf(stderr, "[E::fade annotate] stats all-reduce (lanes): %s\n", fadehip_last_error(ctx)); return 1; }
+                for (int q = 0; q < 8; q++) red[q] = (long long)t[q];
+                have_red = true;
+            }
+            FILE *sf = fopen(lane.status_path.c_str(), "w");
+            if (!sf) { fprintf(stderr, "[E::fade annotate] cannot write %s\n", lane.status_path.c_str()); return 1; }
+            for (int q = 0; q < 8; q++) fprintf(sf, "%lld ", (long long)totals[q]);
+            fprintf(sf, "%lld\n", (long long)n_over);
+            if (have_red) {
+                for (int q = 0; q < 8; q++) fprintf(sf, "%lld ", red[q]);
+                fprintf(sf, "\n");
+            }
+            fclose(sf);
+        }
+        if (n_over && !lane.on) fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read longer than %d bases or window longer than %d\n",
                             (long long)n_over, FADEHIP_MAX_LONG_QUERY, prm.max_ref_len);
-        if (o.stats) {  // stats.d:56-72 layout
+        if (o.stats && !lane.on) {  // stats.d:56-72 layout
             const double rc = (double)std::max<int64_t>(totals[0], 1);
             fprintf(stderr, "read count:\t%lld\nClipped %%:\t%g\n%% With Supplementary alns:\t%g\nArtifact rate:\t%g\n"
                             "%% With Supplementary alns and artifacts:\t%g\nArtifact rate left only:\t%g\nArtifact rate right only:\t%g\n",
@@ -1924,7 +1973,7 @@ int main(int argc, char **argv) {
             if (lrc == 0 || !fall_back) return lrc;
         }
         // BAM file in, BAM out, one device: the file path on the device (FADE_BAM_DEVICE=0: the host pipeline)
-        if (o.bam && o.gpus <= 1 && !lane_env().on && !(getenv("FADE_BAM_DEVICE") && atoi(getenv("FADE_BAM_DEVICE")) == 0)) {
+        if (o.bam && (o.gpus <= 1 || lane_env().on) && !(getenv("FADE_BAM_DEVICE") && atoi(getenv("FADE_BAM_DEVICE")) == 0)) {
             bool fall_back = true;
             const int src = annotate_stream_main(cl, o, &fall_back);
             if (src == 0 || !fall_back) return src;

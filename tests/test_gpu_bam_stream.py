@@ -7,6 +7,7 @@ import gzip
 import os
 import struct
 import subprocess
+import zlib
 
 import numpy as np
 import pytest
@@ -186,3 +187,39 @@ def test_corrupt_inputs_fail_the_run(tmp_path, big):
     cut2.write_bytes(b"".join(ms[:50]))
     p = _run(["annotate", "-b", "-w", "100", str(cut2), str(big["fa"])])
     assert p.returncode != 0 and b"inside a record" in p.stderr
+
+
+def test_header_only_bam_and_lanes_take_the_file_path(tmp_path, big):
+    """A BAM without records gives header + end-of-file block; `--gpus 2` on a BAM file runs the file path in every lane
+    (both on this box's one GPU), records and order as with one lane."""
+    raw = big["bam"].read_bytes()
+    payload = gzip.decompress(raw)
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<i", payload, at)[0] + 4
+    hdr_only = tmp_path / "hdr.bam"
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(payload[:at]) + co.flush()
+    bsize = 18 + len(body) + 8 - 1
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    hdr_only.write_bytes(struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, bsize) + body +
+                         struct.pack("<II", zlib.crc32(payload[:at]) & 0xffffffff, at) + eof)
+    p = _run(["annotate", "--timing", "-b", "-w", "100", str(hdr_only), str(big["fa"])])
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    assert b"file path on the device" in p.stderr
+    out = gzip.decompress(p.stdout)
+    assert out[:4] == b"BAM\1" and p.stdout.endswith(eof)
+    _, _, recs = samutil.bam_to_sam_records(p.stdout)
+    assert recs == []
+    one = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", str(big["bam"]), str(big["fa"])])
+    two = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", "--gpus", "2", str(big["bam"]), str(big["fa"])], {"FADE_DEVICE_MAP": "0,0"})
+    assert one.returncode == 0 and two.returncode == 0, two.stderr.decode()[-2000:]
+    assert two.stderr.count(b"file path on the device") == 2 and b"lane 1 of 2" in two.stderr
+    _, _, r1 = samutil.bam_to_sam_records(one.stdout)
+    _, _, r2 = samutil.bam_to_sam_records(two.stdout)
+    assert r1 == r2 and len(r1) == 30000
+    stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
+    assert stats(one.stderr) == stats(two.stderr)
