@@ -2187,10 +2187,12 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
         if (n_sent) {
             if ((rc = finish_run(ctx, s, 0))) return rc;  // (3) waits for the stream: run and sizes
+            std::lock_guard<std::mutex> l(st->mu);
             for (int t = 0; t < 8; t++) st->stats[t] += s.stats[t];
             st->n_oversize += s.n_oversize;
         } else {
             HIPCHK(ctx, hipStreamSynchronize(q));
+            std::lock_guard<std::mutex> l(st->mu);
             st->stats[0] += n_rec;
         }
         st->t_run += now() - t4;
@@ -2201,7 +2203,10 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(ntb), dim3(bam::TAG_BLOCK), 0, q, ta);
         HIPCHK(ctx, hipGetLastError());
         out->bytes = (size_t)out_bytes;
-        st->n_records += n_rec;
+        {
+            std::lock_guard<std::mutex> l(st->mu);
+            st->n_records += n_rec;
+        }
         st->t_tags += now() - t4;
     }
     if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
