@@ -63,6 +63,24 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.ReadBatch) == 8 + 9 * 8 + 8 + 16 and ctypes.sizeof(_lib.Params) == 40
     assert ctypes.sizeof(_lib.AnnoView) == 16 + 8 + 64 + 8 and ctypes.sizeof(_lib.AnnoOut) == 16 + 8 + 64 + 8
     assert _lib.ALN_DTYPE.fields["sw"][1] == 32
+    assert ctypes.sizeof(_lib.BamConfig) == 16 + 8 + 8  # fadehip_bam_config: four ints, the names pointer, two uints
+
+
+def test_file_path_entry_points_fail_loudly_without_a_context():
+    """The file path (fadehip_bam_*) and the codec calls check their arguments before they touch a device: NULL contexts and
+    streams are errors with a message, not crashes — and there is no host fallback behind them."""
+    from fade_amd import _lib
+    L = _lib.load()
+    n = ctypes.c_size_t(0)
+    p = ctypes.c_void_p()
+    assert L.fadehip_bgzf_inflate(None, b"x", 1, None, 0, ctypes.byref(n)) == -1
+    assert L.fadehip_bgzf_deflate_submit(None, 0, b"x", 1) == -1
+    assert L.fadehip_bam_open(None, None, ctypes.byref(p)) == -1
+    assert L.fadehip_bam_front(None, b"x", 1, 0) == -1 and L.fadehip_bam_front_raw(None, b"x", 1, 0) == -1
+    assert L.fadehip_bam_back(None, ctypes.byref(p), ctypes.byref(n)) == -1
+    assert L.fadehip_bam_totals(None, None, None, None) == -1
+    L.fadehip_bam_close(None)
+    assert b"NULL" in L.fadehip_last_error(None)
 
 
 def test_create_fails_loudly_without_gpu():
