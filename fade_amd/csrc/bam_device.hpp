@@ -100,14 +100,16 @@ struct FrameArgs {
     ChunkCounts *counts;
 };
 
-// one wave per 64 segments: the lanes look for each segment's first plausible record together, then each lane walks one
+// one wave per WALK_SEGS segments: the lanes look for each segment's first plausible record together, then WALK_SEGS lanes walk
+// one segment each (a walk is a chain of ~200 dependent loads: the more waves share the segments, the sooner it is over)
+constexpr uint32_t WALK_SEGS = 16;
 __global__ __launch_bounds__(64) void bam_frame_walk_kernel(FrameArgs a) {
     const uint32_t u_len = a.u_len;
     const uint32_t n_seg = (u_len + SEG - 1) / SEG;
     const int lane = threadIdx.x;
-    const uint32_t s0 = blockIdx.x * 64u;
+    const uint32_t s0 = blockIdx.x * WALK_SEGS;
     uint32_t my_cand = 0xffffffffu;
-    for (uint32_t j = 0; j < 64u; j++) {
+    for (uint32_t j = 0; j < WALK_SEGS; j++) {
         const uint32_t s = s0 + j;
         if (s >= n_seg) break;  // (uniform)
         uint32_t found = 0xffffffffu;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64) void bam_frame_walk_kernel(FrameArgs a) {
         if ((uint32_t)lane == j) my_cand = found;
     }
     const uint32_t s = s0 + (uint32_t)lane;
-    if (s < n_seg && s < a.n_seg_cap) {
+    if ((uint32_t)lane < WALK_SEGS && s < n_seg && s < a.n_seg_cap) {
         uint32_t n = 0, ex = 0xffffffffu;
         if (my_cand != 0xffffffffu) ex = walk_segment(a.u, u_len, my_cand, min((s + 1u) * SEG, 0xffffffffu - SEG), a.slots + (size_t)s * SEG_SLOTS, &n);
         a.cand[s] = my_cand;
@@ -699,51 +701,51 @@ __global__ __launch_bounds__(1024) void bam_tag_scan_kernel(TagArgs a, uint32_t 
     for (uint32_t k = lo; k < hi; k++) { a.blk_base[k] = at; at += a.blk_sums[k]; }
 }
 
-// a wave per record: the body moved by all lanes, the tags written by lane 0
-__global__ __launch_bounds__(TAG_BLOCK) void bam_rewrite_kernel(TagArgs a) {
-    __shared__ uint64_t wave_base[TAG_BLOCK / 64 + 1];
+// a wave per record: the body moved by all lanes, the tags written by lane 0.  A block serves the TAG_BLOCK records of one
+// tag-size block (whose base applies) with REWRITE_WAVES waves, each taking its share of them in turn.
+constexpr int REWRITE_WAVES = 16;
+__global__ __launch_bounds__(REWRITE_WAVES * 64) void bam_rewrite_kernel(TagArgs a) {
+    __shared__ uint64_t off[TAG_BLOCK];
+    __shared__ uint64_t wave_sum[TAG_BLOCK / 64 + 1];
     const uint32_t r1 = min(a.r1_cap, a.counts_in->n_records);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // records of this block: TAG_BLOCK consecutive ones (the tag-size kernel's block), so its base applies; each wave takes
-    // 64 of them in turn and needs the sizes in front: a scan over the block's out_size
     const uint32_t i0 = a.r0 + blockIdx.x * TAG_BLOCK;
-    const uint32_t i = i0 + threadIdx.x;
-    uint64_t sz = i < r1 ? (uint64_t)a.out_size[i - a.r0] : 0ull;
-    uint64_t inc = sz;
+    // offsets of the block's records: a scan of out_size by the first TAG_BLOCK threads
+    uint64_t sz = 0, inc = 0;
+    if (threadIdx.x < TAG_BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        sz = i < r1 ? (uint64_t)a.out_size[i - a.r0] : 0ull;
+        inc = sz;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t o = (uint64_t)__shfl_up((long long)inc, d, 64);
-        if (lane >= d) inc += o;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = (uint64_t)__shfl_up((long long)inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_sum[wave + 1] = inc;
     }
-    if (lane == 63) wave_base[wave + 1] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        wave_base[0] = 0;
-        for (int w = 1; w <= TAG_BLOCK / 64; w++) wave_base[w] += wave_base[w - 1];
+        wave_sum[0] = 0;
+        for (int w = 1; w <= TAG_BLOCK / 64; w++) wave_sum[w] += wave_sum[w - 1];
     }
     __syncthreads();
-    const uint64_t my_off = a.out_base + a.blk_base[blockIdx.x] + wave_base[wave] + inc - sz;  // of record i
-    // the wave's 64 records, one after the other
-    for (int j = 0; j < 64; j++) {
-        const uint32_t ij = i0 + (uint32_t)wave * 64u + (uint32_t)j;
+    if (threadIdx.x < TAG_BLOCK) off[threadIdx.x] = a.out_base + a.blk_base[blockIdx.x] + wave_sum[wave] + inc - sz;
+    __syncthreads();
+    constexpr int PER_WAVE = TAG_BLOCK / REWRITE_WAVES;
+    for (int j = 0; j < PER_WAVE; j++) {
+        const uint32_t k = (uint32_t)wave * PER_WAVE + (uint32_t)j, ij = i0 + k;
         if (ij >= r1) break;  // (uniform)
-        const uint64_t off = (uint64_t)__shfl((long long)my_off, j, 64);
         const uint32_t info = a.info[ij - a.r0];
         if (info & INFO_BAD) continue;
         const RecHdr r = rec_header(a.u + a.rec_off[ij]);
-        uint8_t *dst = a.o + off;
+        uint8_t *dst = a.o + off[k];
         if (!(info & INFO_OURS)) {
-            for (uint32_t k = 4u + (uint32_t)lane; k < r.end; k += 64u) dst[k] = r.p[k];
+            for (uint32_t q = 4u + (uint32_t)lane; q < r.end; q += 64u) dst[q] = r.p[q];
         }
         if (lane == 0) {
             uint8_t rs;
             const fadehip_aln *al = aln_of(a, a.sent_of[ij - a.r0], &rs);
-            if (!(info & INFO_OURS)) {
-                // tags behind the body: emit_record's tail, with the body counted but not written
-                emit_record(r, info, rs, al, &a.names, dst);
-            } else {
-                emit_record(r, info, rs, al, &a.names, dst);
-            }
+            emit_record(r, info, rs, al, &a.names, dst);  // (a record without our tags: its body is counted, not written, here)
         }
     }
 }

@@ -2032,19 +2032,41 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     fa.rec_cap = rec_cap;
     fa.counts = d_counts;
     if (n_seg) {
-        hipLaunchKernelGGL(bam::bam_frame_walk_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, q, fa);
+        hipLaunchKernelGGL(bam::bam_frame_walk_kernel, dim3((n_seg + bam::WALK_SEGS - 1) / bam::WALK_SEGS), dim3(64), 0, q, fa);
         HIPCHK(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(bam::bam_frame_resolve_kernel, dim3(1), dim3(64), 0, q, fa);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(bam::bam_frame_compact_kernel, dim3(std::max(1u, (n_seg + 3) / 4)), dim3(256), 0, q, fa);
     HIPCHK(ctx, hipGetLastError());
+    // which records go to the device's gate, their sizes: enqueued behind the framing for as many records as the bytes could
+    // hold at most (threads beyond the records that are there return at once), so that ONE wait brings back both counts
+    const uint32_t nblk_cap = (rec_cap + bam::PACK_BLOCK - 1) / bam::PACK_BLOCK;
+    if ((rc = reserve_roomy(ctx, st->info, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, st->sent_of, 4 * (size_t)rec_cap)) ||
+        (rc = reserve_roomy(ctx, st->out_size, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, st->blk32, 24 * (size_t)nblk_cap)))
+        return rc;
+    bam::PackArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.u = u;
+    pa.rec_off = fa.rec_off;
+    pa.counts_in = d_counts;
+    pa.r0 = 0;
+    pa.r1_cap = rec_cap;
+    pa.info = (uint32_t *)st->info.p;
+    pa.blk_sums = (uint32_t *)st->blk32.p;
+    pa.blk_base = pa.blk_sums + 3 * (size_t)nblk_cap;
+    pa.counts = d_counts;
+    pa.sent_of = (int32_t *)st->sent_of.p;
+    hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(nblk_cap), dim3(bam::PACK_BLOCK), 0, q, pa);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk_cap);
+    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
     uint32_t *h_tick = (uint32_t *)(st->h_counts.p + sizeof(bam::ChunkCounts));
     h_tick[0] = h_tick[1] = 0;
     if (nb) HIPCHK(ctx, hipMemcpyAsync(h_tick, st->ticket.p, 8, hipMemcpyDeviceToHost, q));
     const double t1 = now();
-    HIPCHK(ctx, hipStreamSynchronize(q));  // (1) the records of this call
+    HIPCHK(ctx, hipStreamSynchronize(q));  // (1) the records of this call and the sizes of their batch
     const double t2 = now();
     st->t_inflate += t1 - t0;
     st->t_frame += t2 - t1;
@@ -2072,33 +2094,9 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     }
     out->bytes = 0;
     if (n_rec) {
-        // ---- the batch: which records go to the device's gate, their arrays
         const uint32_t nblk = (n_rec + bam::PACK_BLOCK - 1) / bam::PACK_BLOCK, ntb = (n_rec + bam::TAG_BLOCK - 1) / bam::TAG_BLOCK;
-        if ((rc = reserve_roomy(ctx, st->info, 4 * (size_t)n_rec)) || (rc = reserve_roomy(ctx, st->sent_of, 4 * (size_t)n_rec)) ||
-            (rc = reserve_roomy(ctx, st->out_size, 4 * (size_t)n_rec)) || (rc = reserve_roomy(ctx, st->blk32, 24 * (size_t)nblk)) || (rc = reserve_roomy(ctx, st->blk64, 16 * (size_t)ntb)))
-            return rc;
-        bam::PackArgs pa;
-        memset(&pa, 0, sizeof pa);
-        pa.u = u;
-        pa.rec_off = fa.rec_off;
-        pa.counts_in = d_counts;
-        pa.r0 = 0;
-        pa.r1_cap = n_rec;
-        pa.info = (uint32_t *)st->info.p;
-        pa.blk_sums = (uint32_t *)st->blk32.p;
-        pa.blk_base = pa.blk_sums + 3 * (size_t)nblk;
-        pa.counts = d_counts;
-        pa.sent_of = (int32_t *)st->sent_of.p;
-        hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(nblk), dim3(bam::PACK_BLOCK), 0, q, pa);
-        HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
-        const double t3 = now();
-        HIPCHK(ctx, hipStreamSynchronize(q));  // (2) the sizes of the batch
-        const double t4 = now();
-        st->t_pack += t4 - t2;
-        (void)t3;
+        if ((rc = reserve_roomy(ctx, st->blk64, 16 * (size_t)ntb))) return rc;
+        const double t4 = t2;
         if (h_counts->n_bad_layout)
             return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu: %u records whose fields do not fit their block_size or whose tags are not whole fields (corrupt BAM)", (unsigned long long)k, h_counts->n_bad_layout);
         const uint32_t n_sent = h_counts->n_sent;
@@ -2200,7 +2198,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         if (out_bytes > ((uint64_t)1 << 31)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu output bytes in one call (at most 2^31)", (unsigned long long)out_bytes);
         if ((rc = reserve_roomy(ctx, out->o, (size_t)out_bytes + 256))) return rc;
         ta.o = (uint8_t *)out->o.p;
-        hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(ntb), dim3(bam::TAG_BLOCK), 0, q, ta);
+        hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(ntb), dim3(bam::REWRITE_WAVES * 64), 0, q, ta);
         HIPCHK(ctx, hipGetLastError());
         out->bytes = (size_t)out_bytes;
         {
