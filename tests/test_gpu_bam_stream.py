@@ -223,3 +223,60 @@ def test_header_only_bam_and_lanes_take_the_file_path(tmp_path, big):
     assert r1 == r2 and len(r1) == 30000
     stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
     assert stats(one.stderr) == stats(two.stderr)
+
+
+def _rec(name, tid=-1, pos=-1, flag=4, seq=b"", qual=b"", cigar=(), aux=b"", mtid=-1, mpos=-1):
+    """One BAM record (block_size included); seq as nt16 codes per base."""
+    qn = name + b"\0"
+    packed = bytes(((seq[k] << 4) | (seq[k + 1] if k + 1 < len(seq) else 0)) for k in range(0, len(seq), 2))
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), 0, 4680, len(cigar), flag, len(seq), mtid, mpos, 0) + qn + \
+        b"".join(struct.pack("<I", c) for c in cigar) + packed + bytes(qual) + aux
+    return struct.pack("<I", len(body)) + body
+
+
+def test_a_record_lookalike_inside_a_tag_does_not_derail_the_framing(tmp_path, big):
+    """Framing is speculative per 64 KB segment: a wave assumes the first position that looks like a record.  Here a B:C
+    array that straddles a segment boundary holds byte-perfect copies of small records right behind the boundary, so the
+    segment's wave starts on a lookalike; the resolving wave must notice (the true chain enters elsewhere), walk the
+    segment again, and the output must equal the host pipeline's."""
+    raw = big["bam"].read_bytes()
+    payload = gzip.decompress(raw)
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<i", payload, at)[0] + 4
+    header = payload[:at]
+    out = bytearray(header)
+    k = 0
+    small = lambda j: _rec(b"r%07d" % j, seq=bytes([1, 2, 4, 8] * 5), qual=bytes([30] * 20))
+    for boundary in (1, 3):
+        # small records up to ~300 bytes in front of the boundary, then the straddler
+        while len(out) + len(small(k)) < 65536 * boundary - 300:
+            out += small(k)
+            k += 1
+        fake = b"".join(_rec(b"fake%03d" % j, seq=bytes([1, 2] * 8), qual=bytes([20] * 16)) for j in range(12))
+        lead = 65536 * boundary - len(out)  # bytes of the straddler in front of the boundary
+        # straddler: fixed part 36 + name 9 + aux header 8 (tag, 'B', 'C', count); the array = filler up to the boundary (+ 7), then the lookalikes
+        fill = lead - (36 + 9 + 8) + 7
+        assert fill > 0
+        arr = bytes([0xff] * fill) + fake + bytes([0xff] * 50)
+        out += _rec(b"straddle", aux=b"zzBC" + struct.pack("<I", len(arr)) + arr)
+        for _ in range(40):
+            out += small(k)
+            k += 1
+    blocks = [bytes(out[o:o + 0xff00]) for o in range(0, len(out), 0xff00)]
+    from test_gpu_inflate import member, EOF_MARK
+    bam = tmp_path / "lookalike.bam"
+    bam.write_bytes(b"".join(member(b) for b in blocks) + EOF_MARK)
+    args = ["annotate", "--timing", "-w", "100", "-b", str(bam), str(big["fa"])]
+    for mode in ("host", "device"):
+        dev = _run(args, {"FADE_BAM_INFLATE": mode, "FADEHIP_BAM_PROF": "1"})
+        host = _run(args, {"FADE_BAM_DEVICE": "0"})
+        assert dev.returncode == 0 and host.returncode == 0, dev.stderr.decode()[-2000:]
+        assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
+        walked_again = int(dev.stderr.decode().split("segments walked again")[1].split()[0])
+        assert walked_again >= 2, dev.stderr.decode()[-600:]
+    _, _, recs = samutil.bam_to_sam_records(dev.stdout)
+    assert len(recs) == k + 2 and sum(r["qname"] == "straddle" for r in recs) == 2 and not any(r["qname"].startswith("fake") for r in recs)
