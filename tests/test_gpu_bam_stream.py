@@ -280,3 +280,33 @@ def test_a_record_lookalike_inside_a_tag_does_not_derail_the_framing(tmp_path, b
         assert walked_again >= 2, dev.stderr.decode()[-600:]
     _, _, recs = samutil.bam_to_sam_records(dev.stdout)
     assert len(recs) == k + 2 and sum(r["qname"] == "straddle" for r in recs) == 2 and not any(r["qname"].startswith("fake") for r in recs)
+
+
+@pytest.mark.parametrize("read_len,window", [(700, 300), (150, 17000), (251, 300)])
+def test_long_reads_and_wide_windows_through_the_file_path(tmp_path, read_len, window):
+    """Reads beyond 512 bases (the thread-per-alignment kernel), windows beyond 32,000 columns (likewise), and a row class
+    other than C2's: the file path sizes its launches from what the device finds (l_seq range, longest alignedLength), and its
+    output must equal the host pipeline's, whose bounds come from the host's own pass over the records."""
+    from fade_amd import synth
+    cfg = synth.config("C5")
+    cfg.update(read_len=read_len, contig_len=300_000, insert_mu=max(cfg["insert_mu"], read_len + 200))
+    g = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"])
+    b = synth.make_reads(g, 1500, 11, **cfg)
+    names = ["q%d" % (i // 2) for i in range(len(b["pos"]))]
+    b["qname"] = names
+    sam, fa, bam = tmp_path / "in.sam", tmp_path / "ref.fa", tmp_path / "in.bam"
+    sam.write_text(samutil.batch_to_sam(b, g.names, [int(x) for x in g.lengths], names))
+    fa.write_bytes(g.fasta_bytes())
+    p = _run(["out", "-b", str(sam)])
+    assert p.returncode == 0, p.stderr.decode()
+    bam.write_bytes(p.stdout)
+    args = ["annotate", "--stats", "--timing", "-w", str(window), "-b", str(bam), str(fa)]
+    host = _run(args, {"FADE_BAM_DEVICE": "0"})
+    assert host.returncode == 0, host.stderr.decode()[-1500:]
+    for mode in ("host", "device"):
+        dev = _run(args, {"FADE_BAM_INFLATE": mode})
+        assert dev.returncode == 0, dev.stderr.decode()[-1500:]
+        assert b"file path on the device" in dev.stderr
+        assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout), mode
+    _, _, recs = samutil.bam_to_sam_records(dev.stdout)
+    assert len(recs) == 1500 and any("am" in r["tags"] for r in recs)
