@@ -310,3 +310,37 @@ def test_long_reads_and_wide_windows_through_the_file_path(tmp_path, read_len, w
         assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout), mode
     _, _, recs = samutil.bam_to_sam_records(dev.stdout)
     assert len(recs) == 1500 and any("am" in r["tags"] for r in recs)
+
+
+def test_spliced_reads_through_the_file_path(tmp_path, big):
+    """Reads with an N op (alignedLength of tens of thousands): the device finds the longest span itself and sizes the
+    long-window launches from it (no per-read list as the host's upload keeps): same bytes as the host pipeline."""
+    import re
+    # back to SAM text through the CLI, a few CIGARs spliced, to BAM again
+    p = _run(["out", str(big["bam"])])
+    assert p.returncode == 0, p.stderr.decode()
+    lines = p.stdout.decode().splitlines()
+    done = 0
+    for k, l in enumerate(lines):
+        if l.startswith("@"):
+            continue
+        f = l.split("\t")
+        m = re.fullmatch(r"(\d+)M(\d+)S", f[5])
+        if m and int(m.group(1)) >= 60 and int(f[3]) < 300000 and done < 24:
+            a = int(m.group(1))
+            gap = 31000 if done % 2 == 0 else 41000  # windows of ~31,300 (wave kernels) and ~41,300 columns (thread kernel)
+            f[5] = "%dM%dN%dM%sS" % (a // 2, gap, a - a // 2, m.group(2))
+            lines[k] = "\t".join(f)
+            done += 1
+    assert done == 24
+    sam, bam = tmp_path / "spliced.sam", tmp_path / "spliced.bam"
+    sam.write_text("\n".join(lines) + "\n")
+    p = _run(["out", "-b", str(sam)])
+    assert p.returncode == 0, p.stderr.decode()
+    bam.write_bytes(p.stdout)
+    args = ["annotate", "--stats", "--timing", "-w", "100", "-b", str(bam), str(big["fa"])]
+    host = _run(args, {"FADE_BAM_DEVICE": "0"})
+    dev = _run(args)
+    assert host.returncode == 0 and dev.returncode == 0, dev.stderr.decode()[-1500:]
+    assert b"file path on the device" in dev.stderr
+    assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
