@@ -157,7 +157,7 @@ struct fadehip_bam_config {
     int floor_len;               /// --min-length
     int window;                  /// -w
     int n_ref;                   /// contigs of the BAM header
-    int reserved;
+    int flags;                   /// 1 (FADEHIP_BAM_STORED): uncompressed BGZF out
     const(char*)* ref_names;     /// [n_ref]
     uint first_record;           /// payload bytes of the first member passed that precede the first record
     uint reserved2;

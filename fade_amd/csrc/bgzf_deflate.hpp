@@ -47,5 +47,57 @@
 namespace fadehip {
 namespace bgzf {
 using bgzf64::claim_ticket;  // (the inflater draws its tickets the same way)
+
+// Uncompressed BGZF (`fade annotate -u`, what htslib writes at level 0): a member = 18 bytes of header, one stored DEFLATE
+// block (5 bytes + the payload), CRC32, ISIZE.  Sizes are known in advance, so member k of a stream cut into STORE_BLOCK
+// bytes lies at k * STORE_MEMBER; a workgroup per member sums the CRC (a segment per thread, slicing by 4, combined by
+// x^(8n) mod P) and moves the bytes.
+constexpr int STORE_BLOCK = 0xff00, STORE_MEMBER = 18 + 5 + STORE_BLOCK + 8, STORE_WG = 256;
+__global__ __launch_bounds__(STORE_WG) void bgzf_store_kernel(const uint8_t *src, uint64_t n_bytes, uint32_t n_blocks, uint8_t *dst) {
+    __shared__ uint32_t crct[1024];
+    __shared__ uint32_t x2n[32];
+    __shared__ uint32_t part[STORE_WG / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t blk = blockIdx.x;
+    if (blk >= n_blocks) return;
+    crct[tid] = crc_table_entry((uint32_t)tid);
+    if (tid == 0) crc_x2n_table(x2n);
+    __syncthreads();
+    for (int t = 1; t < 4; t++) {
+        crct[256 * t + tid] = (crct[256 * (t - 1) + tid] >> 8) ^ crct[crct[256 * (t - 1) + tid] & 255u];
+        __syncthreads();
+    }
+    const uint64_t off = (uint64_t)blk * STORE_BLOCK;
+    const uint32_t n = (uint32_t)(n_bytes - off < (uint64_t)STORE_BLOCK ? n_bytes - off : (uint64_t)STORE_BLOCK);
+    const uint8_t *p = src + off;  // (16-byte aligned: the stream starts aligned and STORE_BLOCK is a multiple of 16)
+    uint8_t *m = dst + (uint64_t)blk * STORE_MEMBER;
+    const uint32_t seg = (((n + STORE_WG - 1) / STORE_WG) + 3u) & ~3u;
+    const uint32_t lo = min(seg * (uint32_t)tid, n), hi = min(lo + seg, n);
+    uint32_t c_part = 0;
+    if (lo < hi) {
+        uint32_t c = 0xffffffffu, k = lo;
+        for (; k + 4u <= hi; k += 4u) {
+            c ^= *reinterpret_cast<const uint32_t *>(p + k);
+            c = crct[768u + (c & 255u)] ^ crct[512u + ((c >> 8) & 255u)] ^ crct[256u + ((c >> 16) & 255u)] ^ crct[c >> 24];
+        }
+        for (; k < hi; k++) c = crct[(c ^ p[k]) & 255u] ^ (c >> 8);
+        c_part = crc_mulmod(crc_x8n(n - hi, x2n), ~c);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) c_part ^= (uint32_t)__shfl_xor((int)c_part, s, 64);
+    if (lane == 0) part[wave] = c_part;
+    for (uint32_t k = (uint32_t)tid; k < n; k += STORE_WG) m[23 + k] = p[k];
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t crc = 0;
+        for (int w = 0; w < STORE_WG / 64; w++) crc ^= part[w];
+        const uint32_t bsize = 18u + 5u + n + 8u - 1u;
+        const uint8_t h[23] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 255u), (uint8_t)(bsize >> 8),
+                               1, (uint8_t)(n & 255u), (uint8_t)(n >> 8), (uint8_t)(~n & 255u), (uint8_t)((~n >> 8) & 255u)};
+        for (int k = 0; k < 23; k++) m[k] = h[k];
+        uint8_t *t = m + 23 + n;
+        for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(n >> (8 * k)); }
+    }
 }
+}  // namespace bgzf
 }  // namespace fadehip

@@ -1921,6 +1921,7 @@ struct fadehip_bam_stream {
     fadehip_ctx *ctx = nullptr;
     int32_t floor_len = 0, window = 0, n_ref = 0;
     uint32_t first_record = 0;
+    bool stored = false;  // uncompressed BGZF out
     DevBuf names_text, names_off;
     // front half (one call at a time)
     DevBuf comp, blocks, status, ticket;
@@ -2225,7 +2226,8 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
 
 int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out) {
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
-    if (!cfg || !out || cfg->n_ref < 0 || (cfg->n_ref && !cfg->ref_names) || cfg->window < 0) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: bad configuration");
+    if (!cfg || !out || cfg->n_ref < 0 || (cfg->n_ref && !cfg->ref_names) || cfg->window < 0 || (cfg->flags & ~FADEHIP_BAM_STORED))
+        return set_err(ctx, FADEHIP_E_INVALID, "bam stream: bad configuration");
     if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
     if (!ctx->two_pass) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: needs the default kernels (FADEHIP_KERNEL unset)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -2236,6 +2238,7 @@ int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_ba
     st->window = cfg->window;
     st->n_ref = cfg->n_ref;
     st->first_record = cfg->first_record;
+    st->stored = (cfg->flags & FADEHIP_BAM_STORED) != 0;
     std::string text;
     std::vector<uint32_t> off((size_t)cfg->n_ref + 1, 0);
     for (int k = 0; k < cfg->n_ref; k++) {
@@ -2306,6 +2309,18 @@ int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_by
         if ((rc = bgzf_lane_ready(ctx, lane, true))) return bam_fail(st, rc);
         BgzfLane &l = ctx->bgzf[lane];
         if (hipStreamWaitEvent(l.stream, o->ready, 0) != hipSuccess) return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: hipStreamWaitEvent failed"));
+        if (st->stored) {
+            // uncompressed BGZF: the members' sizes are known here, nothing has to come back before the copy
+            const uint32_t nb = (uint32_t)((o->bytes + bgzf::STORE_BLOCK - 1) / bgzf::STORE_BLOCK);
+            const size_t total = o->bytes + (size_t)nb * (bgzf::STORE_MEMBER - bgzf::STORE_BLOCK);
+            if ((rc = reserve_roomy(ctx, l.packed, (size_t)nb * bgzf::STORE_MEMBER)) || (rc = reserve_pinned(ctx, l.out, total))) return bam_fail(st, rc);
+            hipLaunchKernelGGL(bgzf::bgzf_store_kernel, dim3(nb), dim3(bgzf::STORE_WG), 0, l.stream, (const uint8_t *)o->o.p, (uint64_t)o->bytes, nb, (uint8_t *)l.packed.p);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(l.out.p, l.packed.p, total, hipMemcpyDeviceToHost, l.stream) != hipSuccess ||
+                hipStreamSynchronize(l.stream) != hipSuccess)
+                return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: storing the members failed"));
+            *out = l.out.p;
+            *out_bytes = total;
+        } else
         if ((rc = bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes, bgzf_pick_geom(ctx))) || (rc = fadehip_bgzf_deflate_wait(ctx, lane, out, out_bytes))) return bam_fail(st, rc);
     } else if (o->ready) {
         (void)hipEventSynchronize(o->ready);

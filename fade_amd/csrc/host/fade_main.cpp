@@ -782,7 +782,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     const LaneEnv lane = lane_env();  // set when this process is one lane of a `--gpus N` run (annotate_lanes_main): a range of the file
     const std::string &path = o.pos[1];
     struct stat sb;
-    if (!o.bam || path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
+    if (!(o.bam || o.ubam) || path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
     StageClock ck_total, ck_fasta, ck_upload, ck_front, ck_back, ck_fwrite, ck_fread, ck_inflate;
     ck_total.start();
     const int nthreads = o.threads > 0 ? o.threads : default_threads();
@@ -1108,13 +1108,14 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         cfg.n_ref = (int32_t)names.size();
         cfg.ref_names = names.data();
         cfg.first_record = first_rec;
+        cfg.flags = o.ubam ? FADEHIP_BAM_STORED : 0;  // -u: uncompressed BGZF (util.d:65-76, SAMWriterTypes.UBAM)
         if (fadehip_bam_open(ctx, &cfg, &st)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
         ck_upload.stop();
         fa.seqs.clear();
         fa.seqs.shrink_to_fit();
         // the header goes out through the CPU writer (its members only: no end-of-file block yet)
         {
-            Writer hw(stdout, OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0, false);
+            Writer hw(stdout, o.ubam ? OutFmt::UBAM : OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0, false);
             hw.close();
         }
         int k;
@@ -1972,8 +1973,8 @@ int main(int argc, char **argv) {
             const int lrc = annotate_lanes_main(cl, o, &fall_back);
             if (lrc == 0 || !fall_back) return lrc;
         }
-        // BAM file in, BAM out, one device: the file path on the device (FADE_BAM_DEVICE=0: the host pipeline)
-        if (o.bam && (o.gpus <= 1 || lane_env().on) && !(getenv("FADE_BAM_DEVICE") && atoi(getenv("FADE_BAM_DEVICE")) == 0)) {
+        // BAM file in, BAM or uBAM out: the file path on the device (FADE_BAM_DEVICE=0: the host pipeline)
+        if ((o.bam || o.ubam) && (o.gpus <= 1 || lane_env().on) && !(getenv("FADE_BAM_DEVICE") && atoi(getenv("FADE_BAM_DEVICE")) == 0)) {
             bool fall_back = true;
             const int src = annotate_stream_main(cl, o, &fall_back);
             if (src == 0 || !fall_back) return src;

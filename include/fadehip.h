@@ -300,12 +300,13 @@ typedef struct fadehip_bam_config {
     int32_t floor_len;            /* --min-length (anno.d: artifact_floor_length) */
     int32_t window;               /* -w (align_buffer_size) */
     int32_t n_ref;                /* contigs of the BAM header: refID is checked against it, ref_names[refID] goes into am */
-    int32_t reserved;
+    int32_t flags;                /* FADEHIP_BAM_STORED: uncompressed BGZF out (`fade annotate -u`, htslib's level 0) */
     const char *const *ref_names; /* [n_ref] NUL-terminated */
     uint32_t first_record;        /* payload bytes of the first member passed to front that precede the first record */
     uint32_t reserved2;
 } fadehip_bam_config;
 #define FADEHIP_BAM_CHUNKS 3
+#define FADEHIP_BAM_STORED 1
 int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out);
 int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_bytes, int last);
 /* front for a caller that inflates itself (host cores otherwise idle; the device then spends its time on the rest):

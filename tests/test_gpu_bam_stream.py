@@ -344,3 +344,22 @@ def test_spliced_reads_through_the_file_path(tmp_path, big):
     assert host.returncode == 0 and dev.returncode == 0, dev.stderr.decode()[-1500:]
     assert b"file path on the device" in dev.stderr
     assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
+
+
+def test_ubam_output_through_the_file_path(big):
+    """`fade annotate -u`: uncompressed BGZF (stored DEFLATE blocks, what htslib writes at level 0) made on the device; the
+    bytes inside are the host pipeline's."""
+    args = ["annotate", "--stats", "--timing", "-w", "100", "-u", str(big["bam"]), str(big["fa"])]
+    dev = _run(args)
+    host = _run(args, {"FADE_BAM_DEVICE": "0"})
+    assert dev.returncode == 0 and host.returncode == 0, dev.stderr.decode()[-1500:]
+    assert b"file path on the device" in dev.stderr and b"file path on the device" not in host.stderr
+    assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
+    ms = _members(dev.stdout)
+    body = [m for m in ms[1:-1]]  # (the header's member comes from the CPU writer, the last is the end-of-file block)
+    assert len(body) > 100 and all(m[18] == 1 for m in body)  # BFINAL = 1, BTYPE = 00: stored
+    assert all(struct.unpack_from("<H", m, 19)[0] == len(m) - 18 - 5 - 8 for m in body)  # LEN = the payload
+    assert len(dev.stdout) > len(gzip.decompress(dev.stdout))
+    two = _run(args[:1] + ["--gpus", "2"] + args[1:], {"FADE_DEVICE_MAP": "0,0"})
+    assert two.returncode == 0, two.stderr.decode()[-1500:]
+    assert samutil.bam_to_sam_records(two.stdout)[2] == samutil.bam_to_sam_records(dev.stdout)[2]

@@ -40,7 +40,8 @@ for v in variants:
             os.remove(out)
         t0 = time.perf_counter()
         with open(out, "wb") as fo:
-            p = subprocess.run([exe, "annotate", "--timing", "-t", "16", "-w", str(cfg["window"]), "-b"] + extra.split() + [bam, fa], stdout=fo,
+            fmt = [] if "-u" in extra.split() else ["-b"]  # (-u: uncompressed BGZF instead)
+            p = subprocess.run([exe, "annotate", "--timing", "-t", "16", "-w", str(cfg["window"])] + fmt + extra.split() + [bam, fa], stdout=fo,
                                stderr=subprocess.PIPE, env=env)
         dt = time.perf_counter() - t0
         r = dict(seconds=dt, reads_per_s=n / dt, rc=p.returncode, out_bytes=os.path.getsize(out),
