@@ -1941,7 +1941,7 @@ struct fadehip_bam_stream {
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_records = 0, n_oversize = 0, n_redone = 0;
     bool failed = false, ended = false, closing = false;
-    double t_inflate = 0, t_frame = 0, t_pack = 0, t_run = 0, t_tags = 0;
+    double t_inflate = 0, t_frame = 0, t_run = 0, t_tags = 0;
 };
 
 namespace {
@@ -2185,7 +2185,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
         if (n_sent) {
-            if ((rc = finish_run(ctx, s, 0))) return rc;  // (3) waits for the stream: run and sizes
+            if ((rc = finish_run(ctx, s, 0))) return rc;  // (2) waits for the stream: run and sizes
             std::lock_guard<std::mutex> l(st->mu);
             for (int t = 0; t < 8; t++) st->stats[t] += s.stats[t];
             st->n_oversize += s.n_oversize;
@@ -2352,8 +2352,8 @@ void fadehip_bam_close(fadehip_bam_stream *st) {
     st->cv.notify_all();
     fadehip_ctx *ctx = st->ctx;
     if (getenv("FADEHIP_BAM_PROF"))
-        fprintf(stderr, "[fadehip bam] %llu front calls: enqueue inflate+frame %.3f s, wait (1) %.3f | pack count + wait (2) %.3f | enqueue write+run+sizes, wait (3) %.3f, "
-                        "of front after (2) in all %.3f | segments walked again %lld\n", (unsigned long long)st->k_front, st->t_inflate, st->t_frame, st->t_pack, st->t_run, st->t_tags,
+        fprintf(stderr, "[fadehip bam] %llu front calls: enqueue copy / inflate + frame + pack count %.3f s, wait (1) %.3f | enqueue pack + run + sizes, wait (2) %.3f, "
+                        "front after (1) in all %.3f | segments walked again %lld\n", (unsigned long long)st->k_front, st->t_inflate, st->t_frame, st->t_run, st->t_tags,
                 (long long)st->n_redone);
     (void)hipSetDevice(ctx->device);
     if (ctx->slots[0].stream) (void)hipStreamSynchronize(ctx->slots[0].stream);

@@ -286,7 +286,7 @@ int fadehip_bgzf_inflate(fadehip_ctx *ctx, const void *members, size_t n_bytes, 
  *   front : whole BGZF members of the input (any number; cut where the caller likes — records may span members and
  *           calls).  Inflates, frames, annotates and rewrites the records that are complete; the tail of a record cut by
  *           the end of the call is kept for the next one.  Returns when the records' new bytes are on the device (the call
- *           waits for the device three times: sizes come back, buffers are sized, the next kernels go out).
+ *           waits for the device twice: sizes come back, buffers are sized, the next kernels go out).
  *   back  : compresses what the oldest finished front call produced and returns the BGZF members in pinned memory, valid
  *           until the back call AFTER the next (a writer thread may still be writing them while the next call compresses).  Outputs come in input order.  Without a finished front call waiting: FADEHIP_E_STATE
  *           (it never blocks for one).
