@@ -64,6 +64,9 @@ def test_device_file_path_equals_the_host_pipeline_on_the_golden_inputs(tmp_path
     assert b"file path on the device" in dev.stderr and b"file path on the device" not in host.stderr
     assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
     assert dev.stdout.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    few = _run(base[:1] + ["-t", "2"] + base[1:])  # (with fewer than 8 threads the device inflates: nothing is said about it here)
+    assert few.returncode == 0 and b"inflate on 0 host threads" in few.stderr, few.stderr.decode()[-800:]
+    assert samutil.bam_to_sam_records(few.stdout)[2] == samutil.bam_to_sam_records(dev.stdout)[2]
     stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
     assert stats(dev.stderr) == stats(host.stderr) and len(stats(dev.stderr)) == 7
     # a second pass over the annotated file: every record carries rs (and some am / as / ar / ab) already — htslib's
