@@ -658,8 +658,80 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
 
 // Queries longer than 512 bases (or windows beyond the wave kernels' LDS): sw_long_kernel (thread per alignment, full
 // trace) + the common traceback.  n_bound / max_lq / max_lr are upper bounds, the live count stays on the device.
+// Long list on the wave kernel with one alignment per wavefront (sw_forward64_kernel): reads of up to 2,048 bases, windows
+// of up to LONG_WAVE_MAX_WINDOW columns, under the default end-cell and gap-tie rules (the kernel's flags are those rules').
+constexpr int LONG_WAVE_MAX_QUERY = 2048, LONG_WAVE_MAX_WINDOW = 65000;
+int run_long_wave(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int max_lq) {
+    const int n_items = c.n_bound, max_lr = c.max_lr;
+    const int R = max_lq <= 1024 ? 16 : 32;
+    const int n_blocks = (max_lr + 63 + 3) / 4;
+    const uint64_t quad_stride = (uint64_t)n_blocks * (R / 2) * 64;  // dwords of trace per alignment
+    const size_t lds = (size_t)(((n_blocks * 4) + 15) / 16) * 16;
+    const int64_t item_bytes = (int64_t)quad_stride * 4;
+    const int64_t chunk = std::min<int64_t>(n_items, std::max<int64_t>(1, c.budget / item_bytes));
+    int rc;
+    if ((rc = reserve_run(ctx, s.trash, s.fwd, (size_t)n_items * sizeof(Fwd))) || (rc = reserve_run(ctx, s.trash, s.trace, (size_t)(chunk * item_bytes)))) return rc;
+    for (int64_t i0 = 0; i0 < n_items; i0 += chunk) {
+        const int n = (int)std::min<int64_t>(chunk, n_items - i0);
+        SwArgs a;
+        memset(&a, 0, sizeof a);
+        a.work = c.work + i0;
+        a.n_items = n;
+        a.q_nib = c.q_nib;
+        a.r_nib = c.r_nib;
+        a.trace = (uint32_t *)s.trace.p;
+        a.quad_stride = quad_stride;
+        a.ref_stride = (int32_t)lds;
+        a.fwd = (Fwd *)s.fwd.p + i0;
+        a.sc = ctx->sc;
+        a.count_dev = c.count_dev;
+        a.item_base = (uint32_t)i0;
+        int e0 = -1, e1 = -1, e2 = -1;
+        if (c.timed && (rc = record(ctx, s, &e0))) return rc;
+        if (R == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<16>), dim3(n), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<32>), dim3(n), dim3(64), lds, st, a);
+        HIPCHK(ctx, hipGetLastError());
+        if (c.timed && (rc = record(ctx, s, &e1))) return rc;
+        TbArgs t;
+        memset(&t, 0, sizeof t);
+        t.work = c.work + i0;
+        t.meta = c.meta ? c.meta + i0 : nullptr;
+        t.fwd = (Fwd *)s.fwd.p + i0;
+        t.n_items = n;
+        t.R = R;
+        t.q_nib = c.q_nib;
+        t.r_nib = c.r_nib;
+        t.trace = (const uint32_t *)s.trace.p;
+        t.quad_stride = quad_stride;
+        t.sc = ctx->sc;
+        t.out = c.out;
+        t.rs = c.rs;
+        t.stats = (c.rs && c.gate) ? s.d_stats() : nullptr;
+        t.floor_len = c.floor_len;
+        t.gate = c.gate;
+        t.early_out = 0;
+        t.packed = 3;
+        t.count_dev = c.count_dev;
+        t.item_base = (uint32_t)i0;
+        hipLaunchKernelGGL(traceback_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t);
+        HIPCHK(ctx, hipGetLastError());
+        if (c.timed) {
+            if ((rc = record(ctx, s, &e2))) return rc;
+            s.fwd_spans.push_back({e0, e1});
+            s.tb_spans.push_back({e1, e2});
+        }
+        s.prof_counts[2] += (int64_t)n * item_bytes;
+    }
+    return 0;
+}
+
 int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int max_lq) {
     const int n_items = c.n_bound, max_lr = c.max_lr;
+    // what the one-alignment-per-wave kernel holds goes there; the thread-per-alignment kernel below keeps the rest (longer
+    // reads, wider windows, the non-default end-cell / gap-tie rules: FADEHIP_LONG_THREAD=1 sends everything to it, for A/B runs)
+    const uint32_t need_rules = FADEHIP_RULE_END_MIN_REF_THEN_QUERY | FADEHIP_RULE_GAP_TIE_EXTENDS;
+    if (max_lq <= LONG_WAVE_MAX_QUERY && max_lr <= LONG_WAVE_MAX_WINDOW && (ctx->sc.rules & need_rules) == need_rules && !getenv("FADEHIP_LONG_THREAD"))
+        return run_long_wave(ctx, s, st, c, max_lq);
     const int lhalf = (max_lr + 1) / 2;
     const int64_t per_item = (int64_t)max_lq * lhalf + 8 * (int64_t)max_lr;
     const int64_t chunk = std::min<int64_t>(n_items, c.budget / std::max<int64_t>(per_item, 1));

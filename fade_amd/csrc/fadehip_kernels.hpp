@@ -545,6 +545,145 @@ __global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
     }
 }
 
+// The same sweep with ONE alignment per wavefront: the 64 lanes own 64 * R consecutive query rows (R = 16: up to 1,024 bases,
+// R = 32: up to 2,048), the hand-off between lanes is a DPP wave_shr:1 instead of row_shr:1 (lane 0 takes the boundary
+// zeros), the skew is 63 steps.  For the reads the 16-lane kernels cannot hold (longer than 512 bases) and the windows
+// they cannot stage (beyond WAVE_MAX_WINDOW): analysis.d:45-59 sets no limit on either.  int32 arithmetic (scores reach
+// 2 * 2,048), four trace flags per cell in the layout of sw_forward_kernel with g = 0 and 64 lanes of rows — the
+// traceback reads it with the same function.
+#define DPP_WAVE_SHR1 0x138
+template <int R>
+__global__ __launch_bounds__(64) void sw_forward64_kernel(SwArgs a) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int lane = threadIdx.x;
+    const int lig = lane;
+    const int quad = blockIdx.x;
+    const int item = quad;
+    int n_live = a.n_items;
+    if (a.count_dev) n_live = min(n_live, max(0, (int)*a.count_dev - (int)a.item_base));
+    const bool have = item < n_live;
+    Work w;
+    if (have) w = a.work[item];
+    else { w.r_base = 0; w.q_base = 0; w.lq = 0; w.lr = 0; w.idx = 0; w.flags = 0; w.out = 0; }
+    const int lq = (int)w.lq, lr = (int)w.lr;
+
+    // steps this wave needs: the window + 63 lanes of skew, in blocks of 4
+    const int n_blocks = have ? (lr + 63 + 3) >> 2 : 0;
+
+    // ---- stage the reference window into LDS as class*4 bytes; pad columns get PAD_CLASS*4
+    uint8_t *lref = lds;
+    const int n_cols = n_blocks * 4;
+    for (int k = lig; k < n_cols; k += 64) {
+        uint32_t c4 = PAD_CLASS * 4;
+        if (k < lr) c4 = lut4(CLASS_LUT, nib_at(a.r_nib, w.r_base + (uint64_t)k)) * 4u;
+        lref[k] = (uint8_t)c4;
+    }
+
+    // ---- per-row score profiles from the (reverse-complemented) query
+    uint32_t prof[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = lig * R + r;
+        uint32_t p = a.sc.prof[PAD_CLASS];
+        if (row < lq) {
+            uint32_t code;
+            if (w.flags & 1u) code = lut4(COMP_LUT, nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)(lq - 1 - row)));
+            else code = nib_at(a.q_nib, (uint64_t)w.q_base + (uint32_t)row);
+            p = a.sc.prof[lut4(CLASS_LUT, code)];
+        }
+        prof[r] = p;
+    }
+    __syncthreads();
+
+    int32_t Hl[R], Eh[R];
+    uint32_t best[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { Hl[r] = 0; Eh[r] = 0; best[r] = 0; }
+    int32_t hu_out = 0, fu_out = 0, hu_prev = 0;
+    uint32_t rc = PAD_CLASS * 4;
+    const int32_t open = a.sc.open, ext = a.sc.ext;
+    uint32_t *tq = a.trace + (uint64_t)quad * a.quad_stride + lane;
+    constexpr int ND = R / 2;  // trace dwords per lane per 4-step block
+
+    for (int blk = 0; blk < n_blocks; blk++) {
+        const uint32_t rw = *reinterpret_cast<const uint32_t *>(lref + blk * 4);
+        uint32_t acc[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) acc[k] = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int t = blk * 4 + s;
+            const uint32_t fresh = (rw >> (8 * s)) & 0xffu;
+            // shift the column state one lane to the right; lane 0 of each 16-lane row takes the
+            // next reference column / the DP boundary zeros.
+            rc = (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)rc, DPP_WAVE_SHR1, 0xf, 0xf, false);
+            int32_t hu = __builtin_amdgcn_update_dpp(0, hu_out, DPP_WAVE_SHR1, 0xf, 0xf, true);
+            int32_t fu = __builtin_amdgcn_update_dpp(0, fu_out, DPP_WAVE_SHR1, 0xf, 0xf, true);
+            const bool valid = (uint32_t)(t - lig) < (uint32_t)lr;
+            const uint32_t vmul = valid ? 65536u : 0u;
+            const uint32_t ctv = valid ? (uint32_t)(0xffff - t) : 0u;
+            int32_t hd = hu_prev;
+            hu_prev = hu;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int32_t wq = (int32_t)__builtin_amdgcn_ubfe(prof[r], rc, 4);
+                const int32_t Dp = hd + wq;
+                const int32_t hl = Hl[r];
+                const int32_t Ee = Eh[r] - ext;
+                const int32_t En = max(hl, Ee);
+                const int32_t Fe = fu - ext;
+                const int32_t Fn = max(hu, Fe);
+                const int32_t T = max(max(Dp, En), Fn);
+                const int32_t H = (int32_t)__builtin_elementwise_sub_sat((uint32_t)T, (uint32_t)open);
+                // each flag is the sign bit of a difference, shifted into the accumulator by one
+                // v_alignbit: nd (D < H), nf (F < H), eo (E opened), fo (F opened)
+                const int k0 = (s * R + r) * 4;  // flag index of `nd`; nf, eo, fo follow
+                uint32_t &ac = acc[k0 >> 5];
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Dp - T), 31);
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Fn - T), 31);
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Ee - hl), 31);
+                ac = __builtin_amdgcn_alignbit(ac, (uint32_t)(Fe - hu), 31);
+                const uint32_t key = __umul24((uint32_t)H, vmul) + ctv;
+                best[r] = max(best[r], key);
+                hd = hl;
+                Hl[r] = H;
+                Eh[r] = En;
+                hu = H;
+                fu = Fn;
+            }
+            hu_out = hu;
+            fu_out = fu;
+        }
+        uint32_t *tp = tq + (uint64_t)blk * (ND * 64);
+#pragma unroll
+        for (int k = 0; k < ND; k++) tp[k * 64] = acc[k];
+    }
+
+    // ---- end cell: max H, then smallest ref index, then smallest query index (Appendix A.3)
+    uint32_t bk = 0;
+    int brow = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = lig * R + r;
+        if (row < lq && best[r] > bk) { bk = best[r]; brow = row; }
+    }
+    // low half holds 0xffff - t; column j = t - lig
+    uint64_t comp = bk ? ((((uint64_t)(bk + (uint32_t)lig)) << 16) | (uint64_t)(0xffff - brow)) : 0ull;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t o = __shfl_xor(comp, m, 64);
+        comp = o > comp ? o : comp;
+    }
+    if (have && lig == 0) {
+        Fwd f;
+        f.score = (int32_t)(comp >> 32);
+        f.end_r = comp ? (int32_t)(0xffff - ((comp >> 16) & 0xffff)) : 0;
+        f.end_q = comp ? (int32_t)(0xffff - (comp & 0xffff)) : 0;
+        f.pad = 0;
+        a.fwd[item] = f;
+    }
+}
+
 // ---------------------------------------------------------------- traceback + artifact gates
 struct TbArgs {
     const Work *work;
@@ -562,7 +701,7 @@ struct TbArgs {
     int32_t floor_len;
     int32_t gate;           // 1: apply analysis.d:69-83,98-107
     int32_t early_out;      // 1: a path that leaves the traced steps with > 10 ops already is not re-run (see below)
-    int32_t packed;         // trace layout: 0 sw_forward_kernel (quads), 1 packed kernels (octets), 2 sw_long_kernel (per thread)
+    int32_t packed;         // trace layout: 0 sw_forward_kernel (quads), 1 packed kernels (octets), 2 sw_long_kernel (per thread), 3 sw_forward64_kernel (a wave each)
     const uint8_t *ltrace;  // packed == 2: cell (i, j) of item k is nibble j & 1 of ltrace[(i * lhalf + j / 2) * n_items + k]
     int32_t lhalf;          // packed == 2: bytes per trace row
     const uint32_t *count_dev;  // items on the list (nullptr = n_items is exact), as in SwArgs
@@ -654,7 +793,7 @@ __device__ __forceinline__ uint32_t traceback_path(const TbArgs &a, const int sr
             const uint32_t v = a.ltrace[((uint64_t)ii * (uint32_t)a.lhalf + (uint32_t)(jj >> 1)) * (uint32_t)a.n_items + (uint32_t)item];
             return (jj & 1) ? (v >> 4) : (v & 15u);
         }
-        return a.packed ? trace_nibble_pk(tq, R, g, half, ii, jj - c0) : trace_nibble(tq, R, g, ii, jj);
+        return (a.packed == 1) ? trace_nibble_pk(tq, R, g, half, ii, jj - c0) : trace_nibble(tq, R, g, ii, jj);  // (0 and 3 share a layout)
     };
     constexpr int DIAG_BATCH = 8;
     while (i >= 0 && j >= 0) {
@@ -1855,6 +1994,8 @@ __device__ __forceinline__ uint32_t traceback_one(const TbArgs &a, const int ite
     int n_items = a.n_items;
     if (a.count_dev) n_items = min(n_items, max(0, (int)*a.count_dev - (int)a.item_base));
     if (item >= n_items) return 0u;
+    if (a.packed == 3)  // sw_forward64_kernel: one alignment per wave, its 64 lanes in the place of a 16-lane group
+        return traceback_path(a, item, 0, a.trace + (uint64_t)item * a.quad_stride, 0, 0, item);
     const uint64_t trace_off = (uint64_t)(a.packed ? (item >> 3) : (item >> 2)) * a.quad_stride;
     return traceback_path(a, item, 0, a.trace + trace_off, a.packed ? ((item >> 1) & 3) : (item & 3), item & 1, item);
 }

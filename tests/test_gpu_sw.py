@@ -1,4 +1,6 @@
 """Level-1 parity: fadehip_sw_batch (analysis.d:67 replacement) vs the scalar oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,17 +78,36 @@ def test_sw_limits_fail_loudly(ctx):
 
 
 def test_sw_long_queries(ctx, oracle):
-    """Queries past the wave kernels' 512 bases take sw_long_kernel (a thread per alignment); same results."""
+    """Queries past the 16-lane kernels' 512 bases: one alignment per wavefront up to 1,024 bases (16 rows per lane) and up to
+    2,048 (32 rows per lane); beyond that, and whenever such a query shares its batch's long list, a thread per alignment.
+    Same results from all three, and from the thread kernel alone (FADEHIP_LONG_THREAD=1)."""
+    import fade_amd
     rng = np.random.default_rng(23)
-    qs, rs = [], []
-    for lq in (513, 514, 600, 777, 1024, 1500, 2049):
-        for kind in ("planted", "related", "random", "nrich", "tandem"):
-            q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(lq // 2, 2 * lq + 300), kinds=(kind,))
-            qs += q
-            rs += r
-    # mixed with short pairs in one batch: both kernels serve the same call
+    groups = {}
+    for name, lqs in (("r16", (513, 514, 600, 777, 1000, 1024)), ("r32", (1025, 1500, 2047, 2048)), ("thread", (2049, 2600))):
+        qs, rs = [], []
+        for lq in lqs:
+            for kind in ("planted", "related", "random", "nrich", "tandem"):
+                q, r = make_pairs(rng, 1, lq_range=(lq, lq), lr_range=(lq // 2, 2 * lq + 300), kinds=(kind,))
+                qs += q
+                rs += r
+        groups[name] = (qs, rs)
+    # mixed with short pairs in one batch: several kernels serve the same call
     q, r = make_pairs(rng, 40, lq_range=(30, 512), lr_range=(30, 900))
-    _compare(ctx, oracle, qs + q, rs + r)
+    for name, (qs, rs) in groups.items():
+        _compare(ctx, oracle, qs + q, rs + r)
+    allq = sum((g[0] for g in groups.values()), [])
+    allr = sum((g[1] for g in groups.values()), [])
+    _compare(ctx, oracle, allq + q, allr + r)
+    os.environ["FADEHIP_LONG_THREAD"] = "1"
+    try:
+        c2 = fade_amd.Context(device=0)
+        a = c2.sw_batch([x.tobytes() for x in groups["r16"][0] + groups["r32"][0]], [x.tobytes() for x in groups["r16"][1] + groups["r32"][1]])
+        c2.close()
+    finally:
+        del os.environ["FADEHIP_LONG_THREAD"]
+    b = ctx.sw_batch([x.tobytes() for x in groups["r16"][0] + groups["r32"][0]], [x.tobytes() for x in groups["r16"][1] + groups["r32"][1]])
+    assert a.tobytes() == b.tobytes()
 
 
 def test_sw_neighbour_independence(ctx, oracle):

@@ -1,6 +1,6 @@
-"""Rates at the edges of the wave kernels' ranges (level 2, resident batches, device time of the score pass):
-long windows (-w large: the window streams through LDS in chunks) and, for comparison, the thread-per-alignment kernel
-that still serves queries beyond 512 bases and windows beyond 32,000 columns (level 1, whole call).
+"""Rates at the edges of the wave kernels' ranges (level 2, resident batches, device time of the forward kernels):
+long windows (-w large: the window streams through LDS in chunks), long reads (one alignment per wavefront up to 2,048
+bases), and level-1 calls of long pairs as a whole (beyond 2,048 bases or 65,000 columns: a thread per alignment).
 GPU box: python tools/long_path_rate.py  -> gpurun_out/long_path_rate.json"""
 import json
 import os
@@ -35,8 +35,21 @@ for w in (100, 1000, 3900, 10000, 15900):  # windows of ~320, 2,100, 7,900, 20,1
                                 gcups=p["cells"] / (p["forward_ms"] * 1e-3) / 1e9, after_ms=p["traceback_ms"], candidates=p["candidates"])
     print("-w %5d  %6.0f columns  %6d alignments  score pass %8.3f ms  %7.0f GCUPS  (pass 2 + tracebacks %.3f ms, %d candidates)" % (
         w, out["window_%d" % w]["columns"], p["alignments"], p["forward_ms"], out["window_%d" % w]["gcups"], p["traceback_ms"], p["candidates"]), flush=True)
+# long reads (level 2, resident batch): every re-aligned read is on the long list — one alignment per wavefront
+for rl, w in ((700, 300), (1000, 300), (2000, 300)):
+    c3 = dict(cfg, read_len=rl, window=w, insert_mu=rl + 300)
+    b3 = sg.make_reads(g, 100_000, 9, c3)
+    pin3 = ctx.pinned_batch(sg.with_bounds(b3))
+    for rep in range(2):
+        ctx.annotate_upload(0, pin3)
+        ctx.annotate_run(0, cfg["floor_len"], w)
+        ctx.annotate_results(0)
+    p = ctx.last_profile(0)
+    out["long_reads_%d" % rl] = dict(alignments=p["alignments"], forward_ms=p["forward_ms"], gcups=p["cells"] / (p["forward_ms"] * 1e-3) / 1e9, after_ms=p["traceback_ms"])
+    print("%4d-base reads, -w %d: %6d alignments, forward %8.3f ms  %7.0f GCUPS  (tracebacks %.3f ms)" % (rl, w, p["alignments"], p["forward_ms"],
+          out["long_reads_%d" % rl]["gcups"], p["traceback_ms"]), flush=True)
 rng = np.random.default_rng(1)
-for n, lq, lr in ((1024, 600, 900), (1024, 1000, 1600), (256, 150, 36000)):
+for n, lq, lr in ((1024, 600, 900), (1024, 1000, 1600), (256, 150, 36000), (64, 2600, 4000)):  # (the last: beyond 2,048 bases, a thread per alignment)
     qs, rs = make_pairs(rng, n, lq_range=(lq, lq), lr_range=(lr, lr), kinds=("related", "random"))
     q = [x.tobytes() for x in qs]
     r = [x.tobytes() for x in rs]
@@ -46,7 +59,7 @@ for n, lq, lr in ((1024, 600, 900), (1024, 1000, 1600), (256, 150, 36000)):
     c2.sw_batch(q, r)
     dt = time.perf_counter() - t
     c2.close()
-    out["thread_per_alignment_%dx%d" % (lq, lr)] = dict(n=n, ms=dt * 1e3, gcups=n * lq * lr / dt / 1e9)
-    print("thread-per-alignment kernel: %d pairs of %d x %d: %.1f ms, %.2f GCUPS (whole level-1 call)" % (n, lq, lr, dt * 1e3, n * lq * lr / dt / 1e9), flush=True)
+    out["level1_%dx%d" % (lq, lr)] = dict(n=n, ms=dt * 1e3, gcups=n * lq * lr / dt / 1e9)
+    print("level 1 (whole call: upload, one alignment per wavefront, tracebacks, results): %d pairs of %d x %d: %.1f ms, %.2f GCUPS" % (n, lq, lr, dt * 1e3, n * lq * lr / dt / 1e9), flush=True)
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", "long_path_rate.json"), "w"), indent=1)
