@@ -658,12 +658,12 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
 
 // Queries longer than 512 bases (or windows beyond the wave kernels' LDS): sw_long_kernel (thread per alignment, full
 // trace) + the common traceback.  n_bound / max_lq / max_lr are upper bounds, the live count stays on the device.
-// Long list on the wave kernel with one alignment per wavefront (sw_forward64_kernel): reads of up to 2,048 bases, windows
+// Long list on the wave kernel with one alignment per wavefront (sw_forward64_kernel): reads of up to 4,096 bases, windows
 // of up to LONG_WAVE_MAX_WINDOW columns, under the default end-cell and gap-tie rules (the kernel's flags are those rules').
-constexpr int LONG_WAVE_MAX_QUERY = 2048, LONG_WAVE_MAX_WINDOW = 65000;
+constexpr int LONG_WAVE_MAX_QUERY = 4096, LONG_WAVE_MAX_WINDOW = 65000;
 int run_long_wave(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int max_lq) {
     const int n_items = c.n_bound, max_lr = c.max_lr;
-    const int R = max_lq <= 1024 ? 16 : 32;
+    const int R = max_lq <= 1024 ? 16 : max_lq <= 2048 ? 32 : 64;  // rows per lane (64: 256 VGPRs + 220 AGPRs, one wave per SIMD)
     const int n_blocks = (max_lr + 63 + 3) / 4;
     const uint64_t quad_stride = (uint64_t)n_blocks * (R / 2) * 64;  // dwords of trace per alignment
     const size_t lds = (size_t)(((n_blocks * 4) + 15) / 16) * 16;
@@ -689,7 +689,8 @@ int run_long_wave(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, 
         int e0 = -1, e1 = -1, e2 = -1;
         if (c.timed && (rc = record(ctx, s, &e0))) return rc;
         if (R == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<16>), dim3(n), dim3(64), lds, st, a);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<32>), dim3(n), dim3(64), lds, st, a);
+        else if (R == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<32>), dim3(n), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<64>), dim3(n), dim3(64), lds, st, a);
         HIPCHK(ctx, hipGetLastError());
         if (c.timed && (rc = record(ctx, s, &e1))) return rc;
         TbArgs t;

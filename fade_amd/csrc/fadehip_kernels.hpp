@@ -546,10 +546,10 @@ __global__ __launch_bounds__(64) void sw_forward_kernel(SwArgs a) {
 }
 
 // The same sweep with ONE alignment per wavefront: the 64 lanes own 64 * R consecutive query rows (R = 16: up to 1,024 bases,
-// R = 32: up to 2,048), the hand-off between lanes is a DPP wave_shr:1 instead of row_shr:1 (lane 0 takes the boundary
+// R = 32: up to 2,048, R = 64: up to 4,096), the hand-off between lanes is a DPP wave_shr:1 instead of row_shr:1 (lane 0 takes the boundary
 // zeros), the skew is 63 steps.  For the reads the 16-lane kernels cannot hold (longer than 512 bases) and the windows
 // they cannot stage (beyond WAVE_MAX_WINDOW): analysis.d:45-59 sets no limit on either.  int32 arithmetic (scores reach
-// 2 * 2,048), four trace flags per cell in the layout of sw_forward_kernel with g = 0 and 64 lanes of rows — the
+// 2 * 4,096), four trace flags per cell in the layout of sw_forward_kernel with g = 0 and 64 lanes of rows — the
 // traceback reads it with the same function.
 #define DPP_WAVE_SHR1 0x138
 template <int R>

@@ -105,9 +105,10 @@ def test_softmasked_and_iupac_reference(ctx, oracle):
 def test_mixed_read_lengths_and_classes(ctx, oracle):
     g = synth.Genome(2, 80_000, 5)
     parts = []
-    # 513+ bases: past the wave kernels, served by sw_long_kernel in the same batch
-    for k, lq in enumerate([36, 76, 101, 150, 151, 200, 250, 300, 400, 512, 513, 600, 1000]):
-        parts.append(synth.make_reads(g, 400 if lq <= 512 else 60, 50 + k, read_len=lq, window=120, p_sc=0.5, clip_min=6,
+    # 513+ bases: past the 16-lane kernels, served in the same batch by the one-alignment-per-wavefront kernel (here with 64
+    # rows per lane: the long list's longest read has 3,000 bases)
+    for k, lq in enumerate([36, 76, 101, 150, 151, 200, 250, 300, 400, 512, 513, 600, 1000, 2048, 3000]):
+        parts.append(synth.make_reads(g, 400 if lq <= 512 else 60 if lq <= 1000 else 24, 50 + k, read_len=lq, window=120, p_sc=0.5, clip_min=6,
                                       clip_max=min(30, lq // 3), insert_mu=max(350, lq + 100)))
     keys = ("tid", "pos", "flag", "has_sa", "l_seq")
     b = {k: np.concatenate([p[k] for p in parts]) for k in keys}

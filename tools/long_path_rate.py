@@ -1,6 +1,6 @@
 """Rates at the edges of the wave kernels' ranges (level 2, resident batches, device time of the forward kernels):
-long windows (-w large: the window streams through LDS in chunks), long reads (one alignment per wavefront up to 2,048
-bases), and level-1 calls of long pairs as a whole (beyond 2,048 bases or 65,000 columns: a thread per alignment).
+long windows (-w large: the window streams through LDS in chunks), long reads (one alignment per wavefront up to 4,096
+bases), and level-1 calls of long pairs as a whole (beyond 4,096 bases or 65,000 columns: a thread per alignment).
 GPU box: python tools/long_path_rate.py  -> gpurun_out/long_path_rate.json"""
 import json
 import os
@@ -36,7 +36,7 @@ for w in (100, 1000, 3900, 10000, 15900):  # windows of ~320, 2,100, 7,900, 20,1
     print("-w %5d  %6.0f columns  %6d alignments  score pass %8.3f ms  %7.0f GCUPS  (pass 2 + tracebacks %.3f ms, %d candidates)" % (
         w, out["window_%d" % w]["columns"], p["alignments"], p["forward_ms"], out["window_%d" % w]["gcups"], p["traceback_ms"], p["candidates"]), flush=True)
 # long reads (level 2, resident batch): every re-aligned read is on the long list — one alignment per wavefront
-for rl, w in ((700, 300), (1000, 300), (2000, 300)):
+for rl, w in ((700, 300), (1000, 300), (2000, 300), (4000, 300)):
     c3 = dict(cfg, read_len=rl, window=w, insert_mu=rl + 300)
     b3 = sg.make_reads(g, 100_000, 9, c3)
     pin3 = ctx.pinned_batch(sg.with_bounds(b3))
@@ -49,7 +49,7 @@ for rl, w in ((700, 300), (1000, 300), (2000, 300)):
     print("%4d-base reads, -w %d: %6d alignments, forward %8.3f ms  %7.0f GCUPS  (tracebacks %.3f ms)" % (rl, w, p["alignments"], p["forward_ms"],
           out["long_reads_%d" % rl]["gcups"], p["traceback_ms"]), flush=True)
 rng = np.random.default_rng(1)
-for n, lq, lr in ((1024, 600, 900), (1024, 1000, 1600), (256, 150, 36000), (64, 2600, 4000)):  # (the last: beyond 2,048 bases, a thread per alignment)
+for n, lq, lr in ((1024, 600, 900), (1024, 1000, 1600), (256, 150, 36000), (64, 4500, 6000)):  # (the last: beyond 4,096 bases, a thread per alignment)
     qs, rs = make_pairs(rng, n, lq_range=(lq, lq), lr_range=(lr, lr), kinds=("related", "random"))
     q = [x.tobytes() for x in qs]
     r = [x.tobytes() for x in rs]
