@@ -139,3 +139,40 @@ def test_large_stream_at_rate(ctx):
     dt = time.perf_counter() - t0
     print("bgzf deflate: %.1f MB in %.1f ms = %.2f GB/s (host memory pageable), ratio %.4f" % (len(data) / 1e6, dt * 1e3, len(data) / dt / 1e9, len(out) / len(data)))
     assert gzip.decompress(out + EOF_MARK) == data
+
+
+@pytest.mark.parametrize("geom", ["64", "32"])
+def test_round_trips_of_many_shapes_in_both_geometries(monkeypatch, geom):
+    """Both block geometries (FADEHIP_BGZF_GEOM pins one), 120 streams of mixed character — runs, text, noise, periodic
+    stretches, sizes around the block boundaries —: zlib inflates what the device wrote, the device inflates it too, and
+    both give the input back."""
+    monkeypatch.setenv("FADEHIP_BGZF_GEOM", geom)
+    c = fade_amd.Context(device=0)
+    try:
+        rng = np.random.default_rng(int(geom))
+        cut = 0xff00 if geom == "64" else 0x7f00
+        words = [b"chr1", b"\t", b"150M", b"=", b"NM:i:0", b"read", b"\x00\x00\x00", b"FFFFFFFF", b"ACGT"]
+        for trial in range(120):
+            parts = []
+            n_target = int(rng.choice([1, 2, 3, cut - 1, cut, cut + 1, 2 * cut - 3, int(rng.integers(1, 5 * cut))]))
+            while sum(len(p) for p in parts) < n_target:
+                kind = int(rng.integers(0, 5))
+                m = int(rng.integers(1, 3000))
+                if kind == 0:
+                    parts.append(bytes([int(rng.integers(0, 256))]) * m)
+                elif kind == 1:
+                    parts.append(rng.integers(0, 256, m, dtype=np.uint8).tobytes())
+                elif kind == 2:
+                    parts.append(b"".join(words[int(k)] for k in rng.integers(0, len(words), m // 4 + 1)))
+                elif kind == 3:
+                    period = rng.integers(0, 256, int(rng.integers(2, 40)), dtype=np.uint8).tobytes()
+                    parts.append((period * (m // len(period) + 1))[:m])
+                else:
+                    parts.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), m).tobytes())
+            data = b"".join(parts)[:n_target]
+            out = bytes(c.bgzf_deflate(data))
+            assert gzip.decompress(out + EOF_MARK) == data, (trial, len(data))
+            assert c.bgzf_inflate(out).tobytes() == data, (trial, len(data))
+            assert len(members(out)) == (len(data) + cut - 1) // cut
+    finally:
+        c.close()
