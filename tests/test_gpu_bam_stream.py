@@ -366,3 +366,44 @@ def test_ubam_output_through_the_file_path(big):
     two = _run(args[:1] + ["--gpus", "2"] + args[1:], {"FADE_DEVICE_MAP": "0,0"})
     assert two.returncode == 0, two.stderr.decode()[-1500:]
     assert samutil.bam_to_sam_records(two.stdout)[2] == samutil.bam_to_sam_records(dev.stdout)[2]
+
+
+def test_records_larger_than_a_framing_segment(tmp_path, big):
+    """Unmapped records of 100,000 and 300,000 bases (150 KB and 450 KB: several 64 KB framing segments without a record
+    start, several BGZF members, and — with 1 MB calls — a carry-over of most of a call) between ordinary ones."""
+    raw = big["bam"].read_bytes()
+    payload = gzip.decompress(raw)
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<i", payload, at)[0] + 4
+    rng = np.random.default_rng(4)
+    out = bytearray(payload[:at])
+    k = 0
+    small = lambda j: _rec(b"r%07d" % j, seq=bytes([1, 2, 4, 8] * 5), qual=bytes([30] * 20))
+    for n_big in (100_000, 300_000, 100_001):
+        for _ in range(300):
+            out += small(k)
+            k += 1
+        seq = rng.choice(np.array([1, 2, 4, 8], np.uint8), n_big).tobytes()
+        out += _rec(b"giant%d" % n_big, seq=seq, qual=bytes(rng.integers(2, 40, n_big, dtype=np.uint8)))
+    for _ in range(100):
+        out += small(k)
+        k += 1
+    from test_gpu_inflate import member, EOF_MARK
+    blocks = [bytes(out[o:o + 0xff00]) for o in range(0, len(out), 0xff00)]
+    bam = tmp_path / "giants.bam"
+    bam.write_bytes(b"".join(member(b, 1) for b in blocks) + EOF_MARK)
+    args = ["annotate", "--timing", "-w", "100", "-b", str(bam), str(big["fa"])]
+    host = _run(args, {"FADE_BAM_DEVICE": "0"})
+    assert host.returncode == 0, host.stderr.decode()[-1500:]
+    for env in ({"FADE_BAM_INFLATE": "host"}, {"FADE_BAM_INFLATE": "device"}, {"FADE_BAM_INFLATE": "host", "FADE_BAM_CHUNK_MB": "1"},
+                {"FADE_BAM_INFLATE": "device", "FADE_BAM_CHUNK_MB": "1"}):
+        dev = _run(args, env)
+        assert dev.returncode == 0, (env, dev.stderr.decode()[-1500:])
+        assert b"file path on the device" in dev.stderr
+        assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout), env
+    _, _, recs = samutil.bam_to_sam_records(dev.stdout)
+    assert len(recs) == k + 3 and sorted(len(r["seq"]) for r in recs)[-3:] == [100_000, 100_001, 300_000]
