@@ -1153,7 +1153,7 @@ const char *inflate_error_name(uint32_t e) {
     return e < sizeof nm / sizeof nm[0] ? nm[e] : "unknown";
 }
 
-// the inflate launch: as many waves as the device holds (8 per SIMD), each drawing members from the ticket
+// the inflate launch: as many waves as the device holds, each drawing members from the ticket
 int launch_inflate(fadehip_ctx *ctx, hipStream_t st, const bgzf::InflateArgs &a) {
     HIPCHK(ctx, hipMemsetAsync(a.ticket, 0, 8, st));
     const unsigned wgs = (a.n_blocks + bgzf::INF_WAVES - 1) / bgzf::INF_WAVES;
