@@ -407,3 +407,78 @@ def test_records_larger_than_a_framing_segment(tmp_path, big):
         assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout), env
     _, _, recs = samutil.bam_to_sam_records(dev.stdout)
     assert len(recs) == k + 3 and sorted(len(r["seq"]) for r in recs)[-3:] == [100_000, 100_001, 300_000]
+
+
+def _random_aux(rng, with_ours):
+    """A run of valid aux fields of every type; with_ours: some of rs / am / as / ar / ab among them, in odd types."""
+    out = b""
+    used = set()
+    n = int(rng.integers(0, 7))
+    ours = [b"rs", b"am", b"as", b"ar", b"ab"]
+    for _ in range(n):
+        if with_ours and rng.random() < 0.35:
+            tag = ours[int(rng.integers(0, 5))]
+        else:
+            tag = bytes([int(rng.integers(65, 91)), int(rng.integers(48, 58))])  # e.g. X7: never one of ours
+        if tag in used:
+            continue
+        used.add(tag)
+        t = "AcCsSiIfZHB"[int(rng.integers(0, 11))]
+        if tag == b"rs" and rng.random() < 0.7:
+            t = "cCsSiI"[int(rng.integers(0, 6))]
+        if t == "A":
+            v = bytes([int(rng.integers(33, 127))])
+        elif t in "cC":
+            v = bytes([int(rng.integers(0, 128))])
+        elif t in "sS":
+            v = struct.pack("<H", int(rng.integers(0, 30000)))
+        elif t in "iI":
+            v = struct.pack("<I", int(rng.integers(0, 2 ** 31 - 1)))
+        elif t == "f":
+            v = struct.pack("<f", float(rng.integers(-1000, 1000)) / 8)
+        elif t == "Z":
+            v = bytes(rng.integers(33, 127, int(rng.integers(0, 40)), dtype=np.uint8)) + b"\0"
+        elif t == "H":
+            v = bytes(rng.choice(np.frombuffer(b"0123456789ABCDEF", np.uint8), 2 * int(rng.integers(0, 10)))) + b"\0"
+        else:
+            sub = "cCsSiIf"[int(rng.integers(0, 7))]
+            cnt = int(rng.integers(0, 20))
+            es = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+            v = sub.encode() + struct.pack("<I", cnt) + bytes(rng.integers(0, 256, es * cnt, dtype=np.uint8))
+        out += tag + t.encode() + v
+    return out
+
+
+@pytest.mark.parametrize("with_ours", [False, True])
+def test_records_with_every_kind_of_tag(tmp_path, big, with_ours):
+    """Every aux type in front of where the new tags go (the device walks the aux area to check it and to look for SA and for
+    its own tags), and — with_ours — records that already carry rs / am / as / ar / ab in assorted types and positions:
+    htslib's update semantics field by field.  Same bytes as the host pipeline."""
+    rng = np.random.default_rng(12 + int(with_ours))
+    payload = gzip.decompress(big["bam"].read_bytes())
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<i", payload, at)[0] + 4
+    out = bytearray(payload[:at])
+    n = 0
+    while at < len(payload) and n < 12000:
+        bs = struct.unpack_from("<I", payload, at)[0]
+        body = payload[at + 4:at + 4 + bs] + _random_aux(rng, with_ours)
+        out += struct.pack("<I", len(body)) + body
+        at += 4 + bs
+        n += 1
+    from test_gpu_inflate import member, EOF_MARK
+    blocks = [bytes(out[o:o + 0xff00]) for o in range(0, len(out), 0xff00)]
+    bam = tmp_path / "tags.bam"
+    bam.write_bytes(b"".join(member(b, 1) for b in blocks) + EOF_MARK)
+    args = ["annotate", "--stats", "--timing", "-w", "100", "-b", str(bam), str(big["fa"])]
+    host = _run(args, {"FADE_BAM_DEVICE": "0"})
+    dev = _run(args)
+    assert host.returncode == 0 and dev.returncode == 0, dev.stderr.decode()[-1500:]
+    assert b"file path on the device" in dev.stderr
+    assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
+    _, _, recs = samutil.bam_to_sam_records(dev.stdout)
+    assert len(recs) == n and sum("am" in r["tags"] for r in recs) > 100
