@@ -94,6 +94,24 @@ def test_create_fails_loudly_without_gpu():
     assert e.value.code in (-2, -3)
 
 
+def test_cli_file_path_fails_loudly_without_gpu(tmp_path):
+    """`fade annotate -b in.bam` (the file path on the device) and the host pipeline alike: no device, no output — an error on
+    stderr, exit code 1, not a byte on stdout."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s", "sam2bam"])
+    gold = os.path.join(ROOT, "tests", "golden")
+    bam = tmp_path / "in.bam"
+    with open(bam, "wb") as fo:
+        subprocess.check_call([os.path.join(ROOT, "tools", "sam2bam"), os.path.join(gold, "anno_c1.sam")], stdout=fo)
+    for env in ({}, {"FADE_BAM_DEVICE": "0"}, {"FADE_BAM_INFLATE": "device"}):
+        p = subprocess.run([os.path.join(ROOT, "fade_amd", "fade"), "annotate", "-b", str(bam), os.path.join(gold, "anno_c1.fa")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, **env))
+        assert p.returncode == 1 and p.stdout == b"" and b"[E::fade annotate] cannot open the GPU path" in p.stderr, (env, p.stderr[-300:])
+
+
 def test_product_path_does_not_touch_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fade_amd")):
         for f in files:
