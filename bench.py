@@ -406,6 +406,32 @@ def main():
             "setup_s": t_setup,
         }
         assert out["stats"]["read_count"] == total_reads, (out["stats"], total_reads)
+        # beside the metric: the forward kernels' rates at the edges of the hot path (long windows, long reads), HIP-event times
+        if world == 1 and args.synth == "native" and not args.no_e2e:
+            try:
+                ex = {}
+                bw = sg.make_reads(genome, 400_000, 77, cfg)
+                pw = ctx.pinned_batch(sg.with_bounds(bw))
+                for _ in range(2):
+                    ctx.annotate_upload(0, pw)
+                    ctx.annotate_run(0, floor_len, 10000)
+                    ctx.annotate_results(0)
+                p = ctx.last_profile(0)
+                ex["windows_of_20100_columns_gcups"] = p["cells"] / (p["forward_ms"] * 1e-3) / 1e9
+                cl = dict(cfg, read_len=1000, window=300, insert_mu=1300)
+                bl = sg.make_reads(genome, 50_000, 78, cl)
+                pl = ctx.pinned_batch(sg.with_bounds(bl))
+                for _ in range(2):
+                    ctx.annotate_upload(0, pl)
+                    ctx.annotate_run(0, floor_len, 300)
+                    ctx.annotate_results(0)
+                p = ctx.last_profile(0)
+                ex["reads_of_1000_bases_gcups"] = p["cells"] / (p["forward_ms"] * 1e-3) / 1e9
+                ex["what"] = ("forward kernels alone (HIP events), resident batches: -w 10000 on the workload's reads (the window streams through LDS in "
+                              "chunks on the packed wave kernels); 1000-base reads at -w 300 (one alignment per wavefront, sw_forward64_kernel)")
+                out["extras"] = ex
+            except Exception as exc:  # (never at the expense of the metric's line)
+                out["extras"] = {"error": repr(exc)[:200]}
     ctx.close()
     if rank == 0:
         if do_e2e:
