@@ -455,9 +455,9 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         // see the pieces in order never hand a turn from wave to wave (a hand-over costs ~900 clocks, 2,040 of them a block):
         //   wave 0, the hasher, walks the pieces through the hash heads (a bucket's read, then its write, in LDS order) and
         //           leaves each position's four candidates in a small ring;
-        //   waves 1 .. 14, the extenders, claim pieces by ticket, take the candidates (the slot goes back at once), extend
+        //   waves 1 .. N_WAVES - 2, the extenders, claim pieces by ticket, take the candidates (the slot goes back at once), extend
         //           them and leave (length, distance) in a second ring;
-        //   wave 15, the parser, takes the pieces in order, carry and match count in registers.
+        //   the last wave, the parser, takes the pieces in order, carry and match count in registers.
         // Slots carry sequence numbers: a ring slot s is written for piece k only when `free` says k, read only when `seq`
         // says k + 1.  Every wait is for a lower-numbered piece's step, so the waits cannot form a cycle.
         const int n_pieces = (n + 63) >> 6;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
             if (tid == 0) ms->hdr_bits = fixed_bits + cl_bits_all;
         }
-        // ---- D: the bit counts of the 1024 position ranges
+        // ---- D: the bit counts of the threads' position ranges (WPT bitmap words each)
         uint32_t my_bits = 0;
 #pragma unroll
         for (int k = 0; k < WPT; k++) {
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         __syncthreads();
         stamp(5);
 
-        // ---- CRC-32 of the input: slicing-by-4 over 1024 pieces of 64 bytes, combined
+        // ---- CRC-32 of the input: slicing-by-4 over a piece per thread, combined
         if (tid < 256) crct[tid] = crc_table_entry((uint32_t)tid);
         __syncthreads();
         for (int t = 1; t < 4; t++) {
