@@ -160,7 +160,7 @@ struct fadehip_bam_config {
     int flags;                   /// 1 (FADEHIP_BAM_STORED): uncompressed BGZF out
     const(char*)* ref_names;     /// [n_ref]
     uint first_record;           /// payload bytes of the first member passed that precede the first record
-    uint reserved2;
+    uint tail_trim;              /// payload bytes at the end of the last member that belong to the next reader
 }
 enum FADEHIP_BAM_CHUNKS = 3;
 int fadehip_bam_open(fadehip_ctx* ctx, const(fadehip_bam_config)* cfg, fadehip_bam_stream** out_);

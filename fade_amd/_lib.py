@@ -81,7 +81,7 @@ class AnnoView(C.Structure):
 
 class BamConfig(C.Structure):
     _fields_ = [("floor_len", C.c_int32), ("window", C.c_int32), ("n_ref", C.c_int32), ("flags", C.c_int32),
-                ("ref_names", C.POINTER(C.c_char_p)), ("first_record", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("ref_names", C.POINTER(C.c_char_p)), ("first_record", C.c_uint32), ("tail_trim", C.c_uint32)]
 
 
 class FadeHipError(RuntimeError):

@@ -1993,7 +1993,7 @@ int fadehip_bgzf_inflate(fadehip_ctx *ctx, const void *members, size_t n_bytes, 
 struct fadehip_bam_stream {
     fadehip_ctx *ctx = nullptr;
     int32_t floor_len = 0, window = 0, n_ref = 0;
-    uint32_t first_record = 0;
+    uint32_t first_record = 0, tail_trim = 0;
     bool stored = false;  // uncompressed BGZF out
     DevBuf names_text, names_off;
     // front half (one call at a time)
@@ -2053,7 +2053,11 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     }
     const uint32_t carry = st->prev_len - st->prev_consumed;
     if ((uint64_t)carry + total > (uint64_t)bam::MAX_U) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu inflated bytes in one call (at most %u)", (unsigned long long)total + carry, bam::MAX_U);
-    const uint32_t u_len = carry + (uint32_t)total;
+    uint32_t u_len = carry + (uint32_t)total;
+    if (last && !raw && st->tail_trim) {  // (the bytes behind this stream's last record, in its last member, belong to another reader)
+        if ((uint64_t)st->tail_trim > total) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: tail_trim %u exceeds the last call's %llu bytes", st->tail_trim, (unsigned long long)total);
+        u_len -= st->tail_trim;
+    }
     DevBuf &ub = st->u[k & 1];
     if ((rc = reserve_roomy(ctx, ub, (size_t)u_len + 256))) return rc;
     uint8_t *u = (uint8_t *)ub.p;
@@ -2311,6 +2315,7 @@ int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_ba
     st->window = cfg->window;
     st->n_ref = cfg->n_ref;
     st->first_record = cfg->first_record;
+    st->tail_trim = cfg->tail_trim;
     st->stored = (cfg->flags & FADEHIP_BAM_STORED) != 0;
     std::string text;
     std::vector<uint32_t> off((size_t)cfg->n_ref + 1, 0);

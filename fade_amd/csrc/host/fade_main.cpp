@@ -790,8 +790,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     // process's pool (host, the default with 8 threads or more: the cores have nothing else to do here, and the device then
     // spends its time on the compressor, which is its slowest kernel).
     const char *inf_env = getenv("FADE_BAM_INFLATE");
-    // (a lane's last member is cut where the next lane's first record starts: done on the inflated bytes, so lanes inflate here)
-    const bool host_inflate = lane.on || (inf_env ? strcmp(inf_env, "host") == 0 : nthreads >= 8);
+    const bool host_inflate = inf_env ? strcmp(inf_env, "host") == 0 : nthreads >= 8;
     Pool pool(host_inflate ? nthreads : std::min(nthreads, 4));
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return 1;
@@ -831,13 +830,22 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     // a lane reads the members in front of coff_end whole and, of the member AT coff_end, the end_rec bytes in front of the next
     // lane's first record
     uint64_t read_end = (uint64_t)sb.st_size;
+    uint32_t tail_trim = 0;
     const bool limited = lane.on && lane.range.coff_end != 0;
     if (limited) {
         read_end = lane.range.coff_end;
         if (lane.range.end_rec > 0) {
             uint8_t h[18];
             if (pread(fileno(f), h, 18, (off_t)lane.range.coff_end) != 18 || h[12] != 'B' || h[13] != 'C') { fprintf(stderr, "[E::fade annotate] lane range ends at no BGZF member\n"); return 1; }
-            read_end += (uint64_t)(h[16] | (h[17] << 8)) + 1u;
+            const uint64_t bsz = (uint64_t)(h[16] | (h[17] << 8)) + 1u;
+            read_end += bsz;
+            // a lane's last member is cut where the next lane's first record starts: by this process when it inflates, by the
+            // library (tail_trim) when the device does
+            uint8_t t[4];
+            if (pread(fileno(f), t, 4, (off_t)(read_end - 4)) != 4) return 1;
+            const uint32_t isz = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (lane.range.end_rec > isz) { fprintf(stderr, "[E::fade annotate] lane range ends beyond its last block\n"); return 1; }
+            tail_trim = isz - (uint32_t)lane.range.end_rec;
         }
     }
     fadehip_ctx *ctx = nullptr;
@@ -1108,6 +1116,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         cfg.n_ref = (int32_t)names.size();
         cfg.ref_names = names.data();
         cfg.first_record = first_rec;
+        cfg.tail_trim = host_inflate ? 0 : tail_trim;
         cfg.flags = o.ubam ? FADEHIP_BAM_STORED : 0;  // -u: uncompressed BGZF (util.d:65-76, SAMWriterTypes.UBAM)
         if (fadehip_bam_open(ctx, &cfg, &st)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
         ck_upload.stop();

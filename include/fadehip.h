@@ -303,7 +303,8 @@ typedef struct fadehip_bam_config {
     int32_t flags;                /* FADEHIP_BAM_STORED: uncompressed BGZF out (`fade annotate -u`, htslib's level 0) */
     const char *const *ref_names; /* [n_ref] NUL-terminated */
     uint32_t first_record;        /* payload bytes of the first member passed to front that precede the first record */
-    uint32_t reserved2;
+    uint32_t tail_trim;           /* payload bytes at the END of the last member (front's last call) that are not this stream's:
+                                   * a reader of a range of the file stops where the next range's first record starts */
 } fadehip_bam_config;
 #define FADEHIP_BAM_CHUNKS 3
 #define FADEHIP_BAM_STORED 1

@@ -221,6 +221,11 @@ def test_header_only_bam_and_lanes_take_the_file_path(tmp_path, big):
     two = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", "--gpus", "2", str(big["bam"]), str(big["fa"])], {"FADE_DEVICE_MAP": "0,0"})
     assert one.returncode == 0 and two.returncode == 0, two.stderr.decode()[-2000:]
     assert two.stderr.count(b"file path on the device") == 2 and b"lane 1 of 2" in two.stderr
+    # the lanes with the device inflating: a lane's last member is cut by the library (tail_trim)
+    three = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", "--gpus", "3", str(big["bam"]), str(big["fa"])],
+                 {"FADE_DEVICE_MAP": "0,0,0", "FADE_BAM_INFLATE": "device"})
+    assert three.returncode == 0 and three.stderr.count(b"inflate on 0 host threads") == 3, three.stderr.decode()[-2000:]
+    assert samutil.bam_to_sam_records(three.stdout)[2] == samutil.bam_to_sam_records(one.stdout)[2]
     _, _, r1 = samutil.bam_to_sam_records(one.stdout)
     _, _, r2 = samutil.bam_to_sam_records(two.stdout)
     assert r1 == r2 and len(r1) == 30000
