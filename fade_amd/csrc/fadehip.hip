@@ -663,7 +663,8 @@ int run_class_single(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &
 constexpr int LONG_WAVE_MAX_QUERY = 4096, LONG_WAVE_MAX_WINDOW = 65000;
 int run_long_wave(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int max_lq) {
     const int n_items = c.n_bound, max_lr = c.max_lr;
-    const int R = max_lq <= 1024 ? 16 : max_lq <= 2048 ? 32 : 64;  // rows per lane (64: 256 VGPRs + 220 AGPRs, one wave per SIMD)
+    // rows per lane: the smallest of 12 / 16 / 24 / 32 / 48 / 64 that holds the list's longest read (64: 256 VGPRs + 220 AGPRs, one wave per SIMD)
+    const int R = max_lq <= 768 ? 12 : max_lq <= 1024 ? 16 : max_lq <= 1536 ? 24 : max_lq <= 2048 ? 32 : max_lq <= 3072 ? 48 : 64;
     const int n_blocks = (max_lr + 63 + 3) / 4;
     const uint64_t quad_stride = (uint64_t)n_blocks * (R / 2) * 64;  // dwords of trace per alignment
     const size_t lds = (size_t)(((n_blocks * 4) + 15) / 16) * 16;
@@ -688,8 +689,11 @@ int run_long_wave(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, 
         a.item_base = (uint32_t)i0;
         int e0 = -1, e1 = -1, e2 = -1;
         if (c.timed && (rc = record(ctx, s, &e0))) return rc;
-        if (R == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<16>), dim3(n), dim3(64), lds, st, a);
+        if (R == 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<12>), dim3(n), dim3(64), lds, st, a);
+        else if (R == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<16>), dim3(n), dim3(64), lds, st, a);
+        else if (R == 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<24>), dim3(n), dim3(64), lds, st, a);
         else if (R == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<32>), dim3(n), dim3(64), lds, st, a);
+        else if (R == 48) hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<48>), dim3(n), dim3(64), lds, st, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(sw_forward64_kernel<64>), dim3(n), dim3(64), lds, st, a);
         HIPCHK(ctx, hipGetLastError());
         if (c.timed && (rc = record(ctx, s, &e1))) return rc;

@@ -78,13 +78,14 @@ def test_sw_limits_fail_loudly(ctx):
 
 
 def test_sw_long_queries(ctx, oracle):
-    """Queries past the 16-lane kernels' 512 bases: one alignment per wavefront up to 1,024 bases (16 rows per lane), up to
-    2,048 (32) and up to 4,096 (64); beyond that, and whenever such a query shares its batch's long list, a thread per alignment.
+    """Queries past the 16-lane kernels' 512 bases: one alignment per wavefront with 12 / 16 / 24 / 32 / 48 / 64 rows per lane
+    (up to 768 / 1,024 / 1,536 / 2,048 / 3,072 / 4,096 bases); beyond that, and whenever such a query shares its batch's long list, a thread per alignment.
     Same results from all three, and from the thread kernel alone (FADEHIP_LONG_THREAD=1)."""
     import fade_amd
     rng = np.random.default_rng(23)
     groups = {}
-    for name, lqs in (("r16", (513, 514, 600, 777, 1000, 1024)), ("r32", (1025, 1500, 2047, 2048)), ("r64", (2049, 3000, 4096)), ("thread", (4097, 4500))):
+    for name, lqs in (("r12", (513, 514, 600, 768)), ("r16", (769, 777, 1000, 1024)), ("r24", (1025, 1536)), ("r32", (1537, 2047, 2048)), ("r48", (2049, 3072)), ("r64", (3073, 4096)),
+                      ("thread", (4097, 4500))):
         qs, rs = [], []
         for lq in lqs:
             for kind in ("planted", "related", "random", "nrich", "tandem"):
@@ -102,8 +103,8 @@ def test_sw_long_queries(ctx, oracle):
     os.environ["FADEHIP_LONG_THREAD"] = "1"
     try:
         c2 = fade_amd.Context(device=0)
-        wq = groups["r16"][0] + groups["r32"][0] + groups["r64"][0]
-        wr = groups["r16"][1] + groups["r32"][1] + groups["r64"][1]
+        wq = sum((groups[k][0] for k in ("r12", "r16", "r24", "r32", "r48", "r64")), [])
+        wr = sum((groups[k][1] for k in ("r12", "r16", "r24", "r32", "r48", "r64")), [])
         a = c2.sw_batch([x.tobytes() for x in wq], [x.tobytes() for x in wr])
         c2.close()
     finally:
