@@ -923,7 +923,13 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         }
         BoundedQueue<int> q_cfree(NBUF + 1), q_cfull(NBUF + 1), q_free(NBUF + 1), q_full(NBUF + 1), q_done(FADEHIP_BAM_CHUNKS + 1);
         struct OutRef { const uint8_t *p; size_t n; };
-        BoundedQueue<OutRef> q_write(1);  // (a call's bytes stay valid during the next back call only)
+        // A call's bytes stay valid during the next back call only (include/fadehip.h: two staging buffers in turn), so the
+        // back thread may run at most one call ahead of the call whose bytes the writer still holds: two credits, one taken
+        // before each back call and given back when its bytes have been written.
+        BoundedQueue<OutRef> q_write(2);
+        BoundedQueue<int> q_credit(2);
+        q_credit.push(0);
+        q_credit.push(0);
         for (int k = 0; k < NBUF; k++) { q_cfree.push(k); q_free.push(k); }
         std::string stage_err;
         std::mutex err_m;
@@ -935,7 +941,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         StageThreads stages;
         stages.unblock = [&] {
             abort_all = true;
-            q_cfree.close(); q_cfull.close(); q_free.close(); q_full.close(); q_done.close(); q_write.close();
+            q_cfree.close(); q_cfull.close(); q_free.close(); q_full.close(); q_done.close(); q_write.close(); q_credit.close();
         };
         // the members of buf[0, got): (offset, size, header length); stops in front of one that is not whole
         struct Mem { size_t off, size, hl; uint32_t isz; };
@@ -1081,6 +1087,8 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                 while (q_done.pop(tok)) {
                     const uint8_t *p = nullptr;
                     size_t n = 0;
+                    int credit;
+                    if (!q_credit.pop(credit)) break;  // (the run is being given up)
                     ck_back.start();
                     const int rc = fadehip_bam_back(st, &p, &n);
                     ck_back.stop();
@@ -1098,10 +1106,12 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
             OutRef r;
             bool ok = true;
             while (q_write.pop(r)) {
-                if (!ok || !r.n) continue;
-                ck_fwrite.start();
-                if (fwrite(r.p, 1, r.n, stdout) != r.n) { set_err("write error on the output stream"); ok = false; abort_all = true; }
-                ck_fwrite.stop();
+                if (ok && r.n) {
+                    ck_fwrite.start();
+                    if (fwrite(r.p, 1, r.n, stdout) != r.n) { set_err("write error on the output stream"); ok = false; abort_all = true; }
+                    ck_fwrite.stop();
+                }
+                q_credit.push(0);
             }
         });
         // (the reader and the inflating pool are at work by now: the genome goes up beside them)

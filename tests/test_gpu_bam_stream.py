@@ -116,6 +116,30 @@ def test_records_that_straddle_members_and_calls(big, chunk_mb, inflate):
     assert stats(dev.stderr) == stats(big["host"].stderr)
 
 
+@pytest.mark.parametrize("inflate", ["device", "host"])
+def test_a_slow_reader_of_the_output_gets_the_same_bytes(big, inflate):
+    """The output through a pipe that is drained slowly, in many small calls: the back half runs ahead of the writer, and
+    its two staging buffers (include/fadehip.h: a call's bytes stay valid during the next call only) must not be compressed
+    into again while the writer still holds them."""
+    import time
+    e = dict(os.environ, FADE_BAM_CHUNK_MB="1", FADE_BAM_INFLATE=inflate)
+    # (the fixture's command line: it is in the header's @PG)
+    p = subprocess.Popen([FADE, "annotate", "--stats", "--timing", "-w", "100", "-b", str(big["bam"]), str(big["fa"])], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=e)
+    got = bytearray()
+    while True:
+        piece = p.stdout.read(65536)
+        if not piece:
+            break
+        got += piece
+        time.sleep(0.004)
+    assert p.wait(timeout=120) == 0
+    for k, m in enumerate(_members(bytes(got))):
+        assert m[:4] == b"\x1f\x8b\x08\x04", "member %d does not begin with a BGZF header" % k
+        body = zlib.decompress(m[18:-8], -15)
+        assert struct.unpack("<II", m[-8:]) == (zlib.crc32(body) & 0xffffffff, len(body)), "member %d" % k
+    assert gzip.decompress(bytes(got)) == gzip.decompress(big["host"].stdout)
+
+
 def test_stream_api_one_member_per_call(big):
     """The C ABI itself, fed the smallest pieces it takes: one BGZF member per front call (most records then straddle calls),
     front and back alternating on one thread."""
