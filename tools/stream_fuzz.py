@@ -1,0 +1,142 @@
+"""Differential fuzz of the file path on the device against the host pipeline (the checker of tests/test_gpu_bam_stream.py,
+itself held to the oracle by tests/test_gpu_cli.py): random read mixes, random extra tags (ours among them), odd records,
+members of random sizes and levels with empty members between them, random call sizes, both inflate modes, random -w and
+--min-length.  The two outputs must inflate to the same bytes.
+    python tools/stream_fuzz.py [seconds] [first_seed]      (GPU box; progress lines go to stdout)"""
+import gzip
+import os
+import struct
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import samutil  # noqa: E402
+from fade_amd import synth  # noqa: E402
+from test_gpu_bam_stream import _random_aux, _rec  # noqa: E402
+from test_gpu_inflate import EOF_MARK, member  # noqa: E402
+
+FADE = os.path.join(ROOT, "fade_amd", "fade")
+TMP = os.environ.get("TMPDIR", "/tmp")
+
+
+def run(args, env):
+    return subprocess.run([FADE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env))
+
+
+def header_len(payload):
+    at = 8 + struct.unpack_from("<i", payload, 4)[0]
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<i", payload, at)[0] + 4
+    return at
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    cfg = synth.config("C5")
+    read_len = int(rng.choice([36, 76, 100, 151, 251, 400]))
+    cfg.update(read_len=read_len, contig_len=int(rng.choice([60_000, 200_000])), insert_mu=max(cfg["insert_mu"], read_len + 150))
+    g = synth.Genome(cfg["n_contigs"], cfg["contig_len"], cfg["genome_seed"] + seed)
+    n = int(rng.integers(200, 6000))
+    b = synth.make_reads(g, n, seed, **cfg)
+    names = ["q%d" % (i // 2) for i in range(len(b["pos"]))]
+    b["qname"] = names
+    sam, fa, bam = (os.path.join(TMP, "sfz." + x) for x in ("sam", "fa", "bam"))
+    open(sam, "w").write(samutil.batch_to_sam(b, g.names, [int(x) for x in g.lengths], names))
+    open(fa, "wb").write(g.fasta_bytes())
+    p = run(["out", "-b", sam], {})
+    assert p.returncode == 0, p.stderr.decode()
+    payload = gzip.decompress(p.stdout)
+    at = header_len(payload)
+    out = bytearray(payload[:at])
+    with_aux, with_ours, with_odd = rng.random() < 0.6, rng.random() < 0.5, rng.random() < 0.5
+    n_rec = 0
+    while at < len(payload):
+        bs = struct.unpack_from("<I", payload, at)[0]
+        body = payload[at + 4:at + 4 + bs]
+        if with_aux and rng.random() < 0.5:
+            body += _random_aux(rng, with_ours)
+        out += struct.pack("<I", len(body)) + body
+        at += 4 + bs
+        n_rec += 1
+        if with_odd and rng.random() < 0.01:
+            kind = int(rng.integers(0, 4))
+            if kind == 0:    # no sequence at all
+                out += _rec(b"odd_empty%d" % n_rec)
+            elif kind == 1:  # one base
+                out += _rec(b"odd_one%d" % n_rec, seq=bytes([4]), qual=bytes([20]))
+            elif kind == 2:  # long unmapped
+                m = int(rng.integers(1000, 90_000))
+                out += _rec(b"odd_long%d" % n_rec, seq=rng.choice(np.array([1, 2, 4, 8, 15], np.uint8), m).tobytes(), qual=bytes(rng.integers(0, 41, m, dtype=np.uint8)))
+            else:            # a name of the greatest length, and tags only
+                out += _rec(b"n" * 254, aux=_random_aux(rng, True))
+            n_rec += 1
+    # members
+    how = int(rng.integers(0, 4))
+    level = int(rng.choice([0, 1, 6, 9]))
+    cuts, o = [], 0
+    while o < len(out):
+        if how == 0:
+            sz = 0xff00
+        elif how == 1:
+            sz = int(rng.integers(1, 65281 if level else 65000))
+        elif how == 2:
+            sz = int(rng.integers(1, 3000)) if len(out) < 600_000 else int(rng.integers(20_000, 65000))
+        else:
+            sz = int(rng.choice([1, 37, 4096, 0xff00, 65280 if level else 60000]))
+        cuts.append((o, min(len(out), o + sz)))
+        o += sz
+    ms = []
+    for lo, hi in cuts:
+        ms.append(member(bytes(out[lo:hi]), level))
+        if rng.random() < 0.02:
+            ms.append(EOF_MARK)  # an empty member in the middle of the file
+    open(bam, "wb").write(b"".join(ms) + EOF_MARK)
+    w, floor = int(rng.choice([50, 100, 300])), int(rng.choice([0, 5, 20]))
+    args = ["annotate", "--stats", "--min-length", str(floor), "-w", str(w), "-b", bam, fa]
+    if rng.random() < 0.2:
+        args.insert(1, "-u")
+        args.remove("-b")
+    host = run(args, {"FADE_BAM_DEVICE": "0"})
+    assert host.returncode == 0, host.stderr.decode()[-1500:]
+    want = gzip.decompress(host.stdout)
+    env = {"FADE_BAM_INFLATE": str(rng.choice(["host", "device"])), "FADE_BAM_CHUNK_MB": str(rng.choice([1, 2, 64]))}
+    if rng.random() < 0.3:
+        args.insert(1, "2")
+        args.insert(1, "-t")
+        want = None  # (another command line in @PG: compare the records)
+    dev = run(args, env)
+    what = "seed %d: %d records, %d members (cut %d, level %d), %s, args %s" % (seed, n_rec, len(ms), how, level, env, " ".join(args[1:-2]))
+    assert dev.returncode == 0, what + "\n" + dev.stderr.decode()[-1500:]
+    assert b"file path on the device" in dev.stderr or b"[timing]" not in dev.stderr
+    got = gzip.decompress(dev.stdout)
+    if want is None:
+        full = gzip.decompress(host.stdout)
+        assert got[header_len(got):] == full[header_len(full):], what
+    else:
+        assert got == want, what
+    stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
+    assert stats(dev.stderr) == stats(host.stderr), what
+    return n_rec, len(ms)
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, done, recs, mems = time.time(), 0, 0, 0
+    while time.time() - t0 < budget:
+        r, m = one(seed)
+        seed += 1
+        done += 1
+        recs += r
+        mems += m
+        if done % 10 == 0:
+            print("%d cases, %d records, %d members, 0 mismatches (%.0f s)" % (done, recs, mems, time.time() - t0), flush=True)
+    print("stream fuzz: %d cases, %d records, %d members: 0 mismatches" % (done, recs, mems))
