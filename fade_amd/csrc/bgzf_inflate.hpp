@@ -430,10 +430,11 @@ __global__ __launch_bounds__(INF_WG) void bgzf_inflate_kernel(InflateArgs a) {
         } else {
             const InflateBlock blk = a.blocks[b];
             uint8_t *dst = a.out + blk.dst_off + shift;
-            uint32_t err = 0;
-            if (blk.isize) err = inflate_member(w, a.comp + blk.src_off, blk.src_len, dst, blk.isize, lane);
-            if (!err && a.check_crc && blk.isize) {
-                const uint32_t c = wave_crc32(&sh, dst, blk.isize, lane);
+            // (a member that claims ISIZE 0 goes through the decoder as well: any byte of output is an error there, and its
+            // CRC32 must be that of no bytes — a zeroed trailer must not make a member's records vanish without a word)
+            uint32_t err = inflate_member(w, a.comp + blk.src_off, blk.src_len, dst, blk.isize, lane);
+            if (!err && a.check_crc) {
+                const uint32_t c = blk.isize ? wave_crc32(&sh, dst, blk.isize, lane) : 0u;
                 if (c != blk.crc) err = INF_E_CRC;
             }
             if (lane == 0) {

@@ -1043,7 +1043,10 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                             size_t slen[2] = {0, 0}, jj[2] = {0, 0};
                             int n = 0;
                             for (size_t j = m0 + 2 * t; j < std::min(m1, m0 + 2 * t + 2); j++) {
-                                if (ms[j].isz == 0) continue;
+                                if (ms[j].isz == 0) {  // (an empty member must be one: hts_lite.hpp)
+                                    if (ms[j].size < ms[j].hl + 8 || !bgzf_empty_member_ok(cb + ms[j].off + ms[j].hl, ms[j].size - ms[j].hl - 8, cb + ms[j].off + ms[j].size - 8)) bad = true;
+                                    continue;
+                                }
                                 src[n] = cb + ms[j].off + ms[j].hl;
                                 slen[n] = ms[j].size - ms[j].hl - 8;
                                 jj[n++] = j;

@@ -188,6 +188,27 @@ private:
     bool closed_ = false;
 };
 
+// A BGZF member that claims ISIZE 0 (the end-of-file marker, or an empty block in the middle of a file): it is what it
+// says only if its DEFLATE stream ends without a byte of output and its CRC32 field is that of no bytes.  A damaged trailer
+// (ISIZE zeroed) must not make a member's records vanish without a word — htslib goes by what the stream inflates to.
+inline bool bgzf_empty_member_ok(const uint8_t *deflate, size_t n, const uint8_t *trailer) {
+    uint32_t crc;
+    memcpy(&crc, trailer, 4);
+    if (crc != 0) return false;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    uint8_t sink[8];
+    zs.next_in = const_cast<uint8_t *>(deflate);
+    zs.avail_in = (uInt)n;
+    zs.next_out = sink;
+    zs.avail_out = sizeof sink;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == 0;
+    inflateEnd(&zs);
+    return ok;
+}
+
 // ------------------------------------------------------------------ header
 struct Header {
     std::string text;                // SAM header text (lines end with '\n')
@@ -977,9 +998,12 @@ public:
             int n = 0;
             for (size_t j = 2 * t; j < std::min(m, 2 * t + 2); j++) {
                 const size_t k = first + j;
-                if (isz[j] == 0) continue;
                 const size_t hl = 12 + offs_[k].xlen;
                 if (offs_[k].size < hl + 8) { bad_ = true; return; }
+                if (isz[j] == 0) {
+                    if (!bgzf_empty_member_ok(comp_.data() + offs_[k].off + hl, offs_[k].size - hl - 8, comp_.data() + offs_[k].off + offs_[k].size - 8)) bad_ = true;
+                    continue;
+                }
                 src[n] = comp_.data() + offs_[k].off + hl;
                 slen[n] = offs_[k].size - hl - 8;
                 jj[n] = j;

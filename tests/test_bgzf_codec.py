@@ -199,3 +199,45 @@ def test_sam_lines_that_cannot_be_bam_records_are_refused(tmp_path):
     ok.write_text(hdr + "%s\t0\tchr1\t100\t60\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\n" % ("q" * 254))
     p = subprocess.run([FADE, "out", "-b", "-t", "2", str(ok)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0 and (b"q" * 254 + b"\0") in gzip.decompress(p.stdout)
+
+
+def test_reader_rejects_a_member_whose_trailer_was_zeroed(tmp_path):
+    """A member whose CRC32 and ISIZE fields read 0 while its DEFLATE stream holds records: an empty member must BE one (its
+    stream ends without a byte of output), else its records would vanish without a word — here every member holds whole
+    records, so nothing downstream could notice.  A real empty member in the middle of the file stays legal."""
+    sam = tmp_path / "in.sam"
+    _sam(sam, 200, 9)
+    p = subprocess.run([FADE, "out", "-u", "-t", "1", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0
+    payload = b"".join(_bgzf_blocks(p.stdout))
+    o = 4
+    l_text = struct.unpack_from("<i", payload, o)[0]
+    o += 4 + l_text
+    n_ref = struct.unpack_from("<i", payload, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        o += 4 + struct.unpack_from("<i", payload, o)[0] + 4
+    pieces, recs = [payload[:o]], []
+    while o < len(payload):
+        bs = struct.unpack_from("<i", payload, o)[0]
+        recs.append(payload[o:o + 4 + bs])
+        o += 4 + bs
+    pieces += [b"".join(recs[k:k + 10]) for k in range(0, len(recs), 10)]
+
+    def member(chunk):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        return b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+
+    ms = [member(x) for x in pieces]
+    eof = p.stdout[-28:]
+    bam = tmp_path / "x.bam"
+    count = lambda out: sum(1 for line in out.splitlines() if line and not line.startswith(b"@"))
+    bam.write_bytes(b"".join(ms[:5]) + eof + b"".join(ms[5:]) + eof)  # (an empty member in the middle: fine)
+    q = subprocess.run([FADE, "out", "-t", "2", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode == 0 and count(q.stdout) == len(recs), q.stderr.decode()[-500:]
+    bad = list(ms)
+    bad[7] = bad[7][:-8] + bytes(8)
+    bam.write_bytes(b"".join(bad) + eof)
+    q = subprocess.run([FADE, "out", "-t", "2", str(bam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode != 0 and b"corrupt" in q.stderr, "ten records vanished without a word (%d of %d came out)" % (count(q.stdout), len(recs))

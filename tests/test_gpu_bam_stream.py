@@ -214,6 +214,33 @@ def test_corrupt_inputs_fail_the_run(tmp_path, big):
     cut2.write_bytes(b"".join(ms[:50]))
     p = _run(["annotate", "-b", "-w", "100", str(cut2), str(big["fa"])])
     assert p.returncode != 0 and b"inside a record" in p.stderr
+    # a member whose CRC32 and ISIZE fields were zeroed, in a file whose members hold whole records: taken at its word the
+    # member would be an empty one and its records would vanish without any framing error
+    from test_gpu_inflate import member, EOF_MARK
+    payload = gzip.decompress(whole)
+    at = 8 + struct.unpack_from("<i", payload, 4)[0]
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 4 + struct.unpack_from("<i", payload, at)[0] + 4
+    pieces, recs = [payload[:at]], []
+    while at < len(payload) and len(recs) < 4000:
+        bs = struct.unpack_from("<I", payload, at)[0]
+        recs.append(payload[at:at + 4 + bs])
+        at += 4 + bs
+    pieces += [b"".join(recs[k:k + 50]) for k in range(0, len(recs), 50)]
+    ms2 = [member(x) for x in pieces]
+    aligned = tmp_path / "aligned.bam"
+    aligned.write_bytes(b"".join(ms2[:9]) + EOF_MARK + b"".join(ms2[9:]) + EOF_MARK)  # (a true empty member in the middle is fine)
+    for env in ({"FADE_BAM_INFLATE": "device"}, {"FADE_BAM_INFLATE": "host"}, {"FADE_BAM_DEVICE": "0"}):
+        p = _run(["annotate", "-b", "-w", "100", str(aligned), str(big["fa"])], env)
+        assert p.returncode == 0, (env, p.stderr.decode()[-800:])
+        assert len(samutil.bam_to_sam_records(p.stdout)[2]) == len(recs)
+    ms2[20] = ms2[20][:-8] + bytes(8)
+    aligned.write_bytes(b"".join(ms2) + EOF_MARK)
+    for env in ({"FADE_BAM_INFLATE": "device"}, {"FADE_BAM_INFLATE": "host"}, {"FADE_BAM_DEVICE": "0"}):
+        p = _run(["annotate", "-b", "-w", "100", str(aligned), str(big["fa"])], env)
+        assert p.returncode != 0, "fifty records vanished without a word (%s)" % env
 
 
 def test_header_only_bam_and_lanes_take_the_file_path(tmp_path, big):

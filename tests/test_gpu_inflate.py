@@ -101,7 +101,10 @@ def test_corrupt_members_are_reported_not_hung_on(ctx):
     big_isize = bytes(m[:-4]) + struct.pack("<I", 70000)
     truncated = bytes(m[:-30])
     bad_magic = b"\x1f\x8c" + bytes(m[2:])
-    for what, stream in (("crc", bad_crc), ("isize", bad_isize), ("isize > 64 KiB", big_isize), ("truncated", truncated), ("magic", bad_magic)):
+    zero_trailer = bytes(m[:-8]) + bytes(8)  # claims to be empty: its stream says otherwise
+    zero_tail = bytes(m[:200]) + bytes(len(m) - 200)
+    for what, stream in (("crc", bad_crc), ("isize", bad_isize), ("isize > 64 KiB", big_isize), ("truncated", truncated), ("magic", bad_magic),
+                         ("zeroed trailer", zero_trailer), ("zeroed from byte 200 on", zero_tail)):
         with pytest.raises(fade_amd.FadeHipError):
             ctx.bgzf_inflate(member(b"ok") + stream)
     # bit flips anywhere in the DEFLATE streams: every outcome but the original bytes must be an error (the CRC sees to it)
