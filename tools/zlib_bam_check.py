@@ -26,7 +26,8 @@ open("/tmp/zb.bam", "wb").write(b"".join(ms) + eof)
 print("zlib-6 BAM: %d members, %.0f MB -> %.0f MB" % (len(ms), len(payload) / 1e6, os.path.getsize("/tmp/zb.bam") / 1e6), flush=True)
 def walk(d, label):
     """Member by member through zlib, so that a bad member is named."""
-    o, k, parts = 0, 0, []
+    import hashlib
+    o, k, h = 0, 0, hashlib.md5()
     while o < len(d):
         bs = struct.unpack_from("<H", d, o + 16)[0] + 1
         try:
@@ -36,8 +37,8 @@ def walk(d, label):
         except Exception as e:
             open(os.path.join(ROOT, "gpurun_out", "bad_member_%s_%d.bin" % (label.split()[-2], k)), "wb").write(d[o:o + bs])
             raise SystemExit("%s: member %d at %d (bsize %d) of %d bytes: %s" % (label, k, o, bs, len(d), e))
-        parts.append(out); o += bs; k += 1
-    return b"".join(parts)
+        h.update(out); o += bs; k += 1
+    return h.hexdigest()
 
 
 fade = os.path.join(ROOT, "fade_amd", "fade")
@@ -53,4 +54,4 @@ for label, env in (("host pipeline", {"FADE_BAM_DEVICE": "0"}), ("file path, hos
     print("%-28s %.3f s  %.2f M reads/s" % (label, best, n / best / 1e6), flush=True)
     outs[label] = walk(p.stdout, label)
 assert outs["file path, host inflate"] == outs["host pipeline"] and outs["file path, device inflate"] == outs["host pipeline"]
-print("all three outputs inflate to the same bytes")
+print("all three outputs inflate to the same bytes (md5 %s)" % outs["host pipeline"])
