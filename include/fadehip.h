@@ -313,6 +313,7 @@ int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_byte
 /* front for a caller that inflates itself (host cores otherwise idle; the device then spends its time on the rest):
  * payload = the members' inflated bytes, any cut, pinned memory for PCIe speed.  Calls of both kinds may alternate. */
 int fadehip_bam_front_raw(fadehip_bam_stream *st, const void *payload, size_t n_bytes, int last);
+/* (*out is good during the next back call and no longer: write it, or have it written, before the call after next) */
 int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_bytes);
 /* totals so far: the eight Stats.parse counters (stats.d:45-54), records, reads beyond the kernels' limits */
 int fadehip_bam_totals(fadehip_bam_stream *st, int64_t stats[8], int64_t *n_records, int64_t *n_oversize);
