@@ -435,7 +435,10 @@ def main():
     ctx.close()
     if rank == 0:
         if do_e2e:
-            e = e2e_legs(bam_path, fa_path, e2e_written, cfg, usable_cpus(), tmp)
+            try:
+                e = e2e_legs(bam_path, fa_path, e2e_written, cfg, usable_cpus(), tmp)
+            except Exception as exc:  # (a missing binary, a full disk: never at the expense of the metric's line)
+                e = {"gpu": {"error": repr(exc)[:300]}}
             g, c = e.get("gpu") or {}, e.get("cpu") or {}
             out["e2e"] = {"what": "`fade annotate -b` BAM -> BAM on a %d-read file of this workload, wall time of the whole process, %d host threads.  gpu = the "
                                   "default: the file path on the device (record framing, annotate, tags, BGZF deflate as kernels; BGZF inflate on the host pool); "
