@@ -282,10 +282,10 @@ class Context:
         self.bgzf_deflate_submit(lane, data)
         return self.bgzf_deflate_wait(lane)
 
-    def bam_stream(self, ref_names, floor_len=5, window=300, first_record=0, stored=False):
+    def bam_stream(self, ref_names, floor_len=5, window=300, first_record=0, stored=False, tail_trim=0):
         """The file path on the device (fadehip_bam_*): BGZF members of a BAM's records in, BGZF members of the annotated
         records out.  ref_names: the BAM header's contigs (the genome must be uploaded)."""
-        return BamStream(self, ref_names, floor_len, window, first_record, stored)
+        return BamStream(self, ref_names, floor_len, window, first_record, stored, tail_trim)
 
     def bgzf_inflate(self, members, out_cap=None):
         """Whole BGZF members (bytes / uint8 array) -> their payloads, inflated on the device (CRC32 and ISIZE checked)."""
@@ -419,11 +419,11 @@ def format_tags(batch, contig_names, rs, aln):
 
 
 class BamStream:
-    def __init__(self, ctx, ref_names, floor_len, window, first_record, stored=False):
+    def __init__(self, ctx, ref_names, floor_len, window, first_record, stored=False, tail_trim=0):
         self._ctx, self._L = ctx, ctx._L
         names = [n.encode() if isinstance(n, str) else bytes(n) for n in ref_names]
         arr = (C.c_char_p * max(len(names), 1))(*names)
-        cfg = _lib.BamConfig(floor_len, window, len(names), 1 if stored else 0, arr, first_record, 0)
+        cfg = _lib.BamConfig(floor_len, window, len(names), 1 if stored else 0, arr, first_record, tail_trim)
         h = C.c_void_p()
         ctx._chk(self._L.fadehip_bam_open(ctx._h, C.byref(cfg), C.byref(h)))
         self._h = h

@@ -595,25 +595,30 @@ __device__ __forceinline__ uint32_t emit_record(const RecHdr &r, uint32_t info, 
             if (mine < 0) {
                 for (uint32_t k = q; k < q + 2u + fs; k++) s.put(r.p[k]);
             } else if (mine == 0) {
+                // bam_aux_update_int (htslib sam.c) of a value 0 .. 63: every integer slot is wide enough, it is reused and
+                // its type letter becomes the unsigned one of its size ("\0CS\0I"[old_sz]); a non-integer rs: EINVAL, the
+                // field stays as it is and nothing is appended
                 done[0] = true;
                 const uint8_t ot = r.p[q + 2];
                 const uint32_t os = (uint32_t)aux_type_size(ot);
                 const bool is_int = ot == 'c' || ot == 'C' || ot == 's' || ot == 'S' || ot == 'i' || ot == 'I';
-                const uint32_t omax = ot == 'c' ? 0x7fu : ot == 'C' ? 0xffu : ot == 's' ? 0x7fffu : ot == 'S' ? 0xffffu : ot == 'i' ? 0x7fffffffu : 0xffffffffu;
-                s.put('r'); s.put('s');
-                if (is_int && (uint32_t)rs <= omax) {
-                    s.put(ot);
+                if (is_int) {
+                    s.put('r'); s.put('s');
+                    s.put(os == 1u ? 'C' : os == 2u ? 'S' : 'I');
                     s.put(rs);
                     for (uint32_t k = 1; k < os; k++) s.put(0);
                 } else {
-                    s.put('C');
-                    s.put(rs);
+                    for (uint32_t k = q; k < q + 2u + fs; k++) s.put(r.p[k]);
                 }
             } else {
                 done[mine] = true;
-                s.put((uint8_t)tags[mine][0]); s.put((uint8_t)tags[mine][1]); s.put('Z');
-                st.string(mine - 1, s);
-                s.put(0);
+                if (r.p[q + 2] == 'Z') {
+                    s.put((uint8_t)tags[mine][0]); s.put((uint8_t)tags[mine][1]); s.put('Z');
+                    st.string(mine - 1, s);
+                    s.put(0);
+                } else {  // bam_aux_update_str on a tag of another type: EINVAL, unchanged
+                    for (uint32_t k = q; k < q + 2u + fs; k++) s.put(r.p[k]);
+                }
             }
             q += 2u + fs;
         }

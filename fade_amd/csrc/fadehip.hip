@@ -2063,7 +2063,9 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         u_len -= st->tail_trim;
     }
     DevBuf &ub = st->u[k & 1];
-    if ((rc = reserve_roomy(ctx, ub, (size_t)u_len + 256))) return rc;
+    // (sized from the UNTRIMMED length: the inflate kernel writes the last member's whole ISIZE, tail_trim only shortens
+    // what the framing looks at)
+    if ((rc = reserve_roomy(ctx, ub, (size_t)carry + (size_t)total + 256))) return rc;
     uint8_t *u = (uint8_t *)ub.p;
     if (carry) HIPCHK(ctx, hipMemcpyAsync(u, (const uint8_t *)st->u[(k + 1) & 1].p + st->prev_consumed, carry, hipMemcpyDeviceToDevice, q));
     const uint32_t nb = (uint32_t)blocks.size();

@@ -62,7 +62,8 @@ static void print_anno_help() {
             "-w --window-size Number of bases considered outside of read or mate region for re-alignment\n"
             "-b         --bam output bam\n"
             "-u        --ubam output uncompressed bam\n"
-            "          --gpus number of MI355X devices to shard batches over (default 1)\n"
+            "          --gpus number of MI355X devices, one process each on its own range of the input (default 1)\n"
+            "    --out-shards with --gpus N: every device writes a complete file PREFIX.<k>.bam (.sam), nothing is merged\n"
             "         --batch records per device batch (default 262144)\n"
             "         --stats print the stats.d summary of this run to stderr\n"
             "-h        --help This help information.\n\n",
@@ -73,7 +74,8 @@ struct Opts {
     int threads = 0, floor_len = 5, window = 300, gpus = 1, batch = 262144;
     bool bam = false, ubam = false, help = false, stats = false, timing = false, clip = false;
     std::vector<std::string> pos;
-    std::string seen;  // one letter per option met: t m w b u c h g(pus) B(atch) s(tats) T(iming)
+    std::string out_shards;  // --out-shards PREFIX (with --gpus N)
+    std::string seen;  // one letter per option met: t m w b u c h g(pus) B(atch) s(tats) T(iming) S(hards)
 };
 
 // std.getopt with config.bundling: short flags bundle (-bu), values attach (-w100, -w 100, --window-size=100)
@@ -105,6 +107,15 @@ static bool parse_opts(int argc, char **argv, Opts &o, std::string &err) {
             else if (name == "window-size") { o.seen += 'w'; if (!take(o.window)) return false; }
             else if (name == "gpus") { o.seen += 'g'; if (!take(o.gpus)) return false; }
             else if (name == "batch") { o.seen += 'B'; if (!take(o.batch)) return false; }
+            else if (name == "out-shards") {
+                o.seen += 'S';
+                if (!has_val) {
+                    if (i + 1 >= argc) { err = "Missing value for argument --" + name; return false; }
+                    val = argv[++i];
+                }
+                if (val.empty()) { err = "Invalid value for option --out-shards: (empty)"; return false; }
+                o.out_shards = val;
+            }
             else if (name == "bam") { o.seen += 'b'; o.bam = true; }
             else if (name == "ubam") { o.seen += 'u'; o.ubam = true; }
             else if (name == "stats") { o.seen += 's'; o.stats = true; }
@@ -507,6 +518,7 @@ static double since_process_start() {
 struct LaneEnv {
     bool on = false;
     int k = 0, n = 1, device = 0, rccl = 0;
+    bool shard = false;  // --out-shards: this lane writes a complete file (header and end-of-file block of its own)
     LaneRange range;
     std::string cl, status_path, id_path;
 };
@@ -525,6 +537,7 @@ static LaneEnv lane_env() {
     if (const char *v = getenv("FADE_LANE_CL")) e.cl = v;
     if (const char *v = getenv("FADE_LANE_STATUS")) e.status_path = v;
     if (const char *v = getenv("FADE_LANE_NCCL_ID")) e.id_path = v;
+    if (const char *v = getenv("FADE_LANE_SHARD")) e.shard = atoi(v) != 0;
     return e;
 }
 
@@ -669,15 +682,32 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
                 if (devmap[(size_t)a] == devmap[(size_t)b2]) distinct = false;
     }
     const int threads_each = std::max(1, (o.threads > 0 ? o.threads : default_threads()) / n_lanes);
-    const char *tmpd = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
-    char stem[512];
-    snprintf(stem, sizeof stem, "%s/fade_lanes_%d", tmpd, (int)getpid());
+    const bool shards = !o.out_shards.empty();
+    // Where the lanes write.  --out-shards: every lane a complete file of its own (header, its records, end-of-file block),
+    // nothing is merged (BASELINE config 4: "sharded per GPU").  Otherwise ONE stream on stdout: lane 0 writes straight into
+    // it (header first), lanes 1 .. N-1 into files of a private directory that this process forwards WHILE the lanes run —
+    // into their final place at once when stdout is a file that can be written at an offset (a lane's place is known as soon
+    // as the lanes before it have ended, and the copies of all lanes proceed side by side), one lane after the other when it
+    // is a pipe.
+    char dir[512] = "";
+    {
+        const char *tmpd = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+        snprintf(dir, sizeof dir, "%s/fade_lanes_XXXXXX", tmpd);
+        if (!mkdtemp(dir)) { fprintf(stderr, "[E::fade annotate] cannot make a directory under %s: %s\n", tmpd, strerror(errno)); return 1; }  // (0700, a name nobody can guess)
+    }
     std::vector<std::string> outp((size_t)n_lanes), stp((size_t)n_lanes);
+    std::vector<int> ofd((size_t)n_lanes, -1);  // lanes 1 ..: this process's read side of the lane's file
     std::vector<pid_t> pids((size_t)n_lanes, -1);
-    const std::string idp = std::string(stem) + ".ncclid";
+    const std::string idp = std::string(dir) + "/ncclid";
     auto cleanup = [&] {
-        for (int k = 0; k < n_lanes; k++) { unlink(outp[(size_t)k].c_str()); unlink(stp[(size_t)k].c_str()); }
+        for (int k = 0; k < n_lanes; k++) {
+            if (ofd[(size_t)k] >= 0) close(ofd[(size_t)k]);
+            if (!shards && !outp[(size_t)k].empty()) unlink(outp[(size_t)k].c_str());
+            unlink(stp[(size_t)k].c_str());
+        }
         unlink(idp.c_str());
+        unlink((idp + ".tmp").c_str());
+        rmdir(dir);
     };
     *fall_back = false;  // from here on the lanes own the run: a failure is reported, nothing is run twice
     if (o.timing)
@@ -686,11 +716,37 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
                     (unsigned long long)lr[(size_t)k].coff_start, (unsigned long long)lr[(size_t)k].first_rec, (unsigned long long)lr[(size_t)k].coff_end,
                     (unsigned long long)lr[(size_t)k].end_rec);
     fprintf(stderr, "[W::fade annotate] Output SAM/BAM will not be sorted (regardless of prior sorting)\n");
-    for (int k = 0; k < n_lanes; k++) {
-        outp[(size_t)k] = std::string(stem) + "." + std::to_string(k) + ".out";
-        stp[(size_t)k] = std::string(stem) + "." + std::to_string(k) + ".status";
+    fflush(stdout);
+    const auto t_spawn = std::chrono::steady_clock::now();
+    auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spawn).count(); };
+    bool ok = true;
+    for (int k = 0; k < n_lanes; k++) stp[(size_t)k] = std::string(dir) + "/" + std::to_string(k) + ".status";
+    // (FADE_LANES_LIVE=m: at most m lanes at a time, the next one starts when one ends — for boxes that allow few processes
+    // on a device, i.e. tests that put eight lanes on one GPU)
+    const int live_cap = std::max(1, std::min(n_lanes, getenv("FADE_LANES_LIVE") ? atoi(getenv("FADE_LANES_LIVE")) : n_lanes));
+    int next_lane = 0;
+    // the lanes sum their counters among themselves over RCCL when each has a device of its own and all of them run at once
+    // (FADE_LANES_RCCL=1 asks for it regardless: a test of what RCCL says to two ranks on one device; =0 leaves the sum to
+    // this process, which adds up the lanes' reports either way)
+    const char *rccl_env = getenv("FADE_LANES_RCCL");
+    const bool lanes_rccl = live_cap == n_lanes && (rccl_env ? atoi(rccl_env) != 0 : distinct);
+    auto start_lane = [&](int k) -> bool {
+        int wfd = -1;  // the lane's stdout (lane 0 of a merged run: this process's own)
+        if (shards) {
+            outp[(size_t)k] = o.out_shards + "." + std::to_string(k) + ((o.bam || o.ubam) ? ".bam" : ".sam");
+            wfd = open(outp[(size_t)k].c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+        } else if (k > 0) {
+            outp[(size_t)k] = std::string(dir) + "/" + std::to_string(k) + ".out";
+            wfd = open(outp[(size_t)k].c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+            if (wfd >= 0) ofd[(size_t)k] = open(outp[(size_t)k].c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+        }
+        if ((shards || k > 0) && (wfd < 0 || (!shards && ofd[(size_t)k] < 0))) {
+            fprintf(stderr, "[E::fade annotate] cannot create %s: %s\n", outp[(size_t)k].c_str(), strerror(errno));
+            if (wfd >= 0) close(wfd);
+            return false;
+        }
         char lane[256];
-        snprintf(lane, sizeof lane, "%d/%d:%d:%d:%llu:%llu:%llu:%llu", k, n_lanes, devmap[(size_t)k], distinct ? 1 : 0, (unsigned long long)lr[(size_t)k].coff_start,
+        snprintf(lane, sizeof lane, "%d/%d:%d:%d:%llu:%llu:%llu:%llu", k, n_lanes, devmap[(size_t)k], lanes_rccl ? 1 : 0, (unsigned long long)lr[(size_t)k].coff_start,
                  (unsigned long long)lr[(size_t)k].first_rec, (unsigned long long)lr[(size_t)k].coff_end, (unsigned long long)lr[(size_t)k].end_rec);
         std::vector<std::string> envs;
         for (char **e = environ; *e; e++)
@@ -699,6 +755,7 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
         envs.push_back("FADE_LANE_CL=" + cl);
         envs.push_back("FADE_LANE_STATUS=" + stp[(size_t)k]);
         envs.push_back("FADE_LANE_NCCL_ID=" + idp);
+        if (shards) envs.push_back("FADE_LANE_SHARD=1");
         std::vector<char *> envp;
         for (auto &e : envs) envp.push_back(const_cast<char *>(e.c_str()));
         envp.push_back(nullptr);
@@ -714,52 +771,193 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
         argv.push_back(nullptr);
         posix_spawn_file_actions_t fa;
         posix_spawn_file_actions_init(&fa);
-        posix_spawn_file_actions_addopen(&fa, 1, outp[(size_t)k].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        if (wfd >= 0) posix_spawn_file_actions_adddup2(&fa, wfd, 1);
         const int rc = posix_spawn(&pids[(size_t)k], "/proc/self/exe", &fa, nullptr, argv.data(), envp.data());
         posix_spawn_file_actions_destroy(&fa);
+        if (wfd >= 0) close(wfd);
         if (rc != 0) {
             fprintf(stderr, "[E::fade annotate] cannot start lane %d: %s\n", k, strerror(rc));
             pids[(size_t)k] = -1;
+            return false;
         }
-    }
-    bool ok = true;
-    for (int k = 0; k < n_lanes; k++) {
-        if (pids[(size_t)k] < 0) { ok = false; continue; }
+        return true;
+    };
+    while (ok && next_lane < live_cap) ok = start_lane(next_lane++);
+    // ---- the lanes run; their outputs are put together meanwhile
+    struct Merge {
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<char> ended;      // lane k has ended well: its file has its final size
+        std::vector<uint64_t> size;   // ... which is this
+        std::vector<char> copied;     // lane k's bytes are all in the output
+        bool abort = false;
+        std::string err;
+    } mg;
+    mg.ended.assign((size_t)n_lanes, 0);
+    mg.size.assign((size_t)n_lanes, 0);
+    mg.copied.assign((size_t)n_lanes, 0);
+    struct stat so;
+    const int oflags = fcntl(1, F_GETFL);
+    const off_t base = lseek(1, 0, SEEK_CUR);
+    // (FADE_LANES_MERGE=stream: one lane after the other even into a file — what a pipe gets; tests compare the two)
+    const bool placed = !shards && fstat(1, &so) == 0 && S_ISREG(so.st_mode) && base >= 0 && oflags >= 0 && !(oflags & O_APPEND) &&
+                        !(getenv("FADE_LANES_MERGE") && strcmp(getenv("FADE_LANES_MERGE"), "stream") == 0);
+    std::vector<double> t_end((size_t)n_lanes, 0), t_copied((size_t)n_lanes, 0);
+    std::vector<std::thread> copiers;
+    if (!shards && ok)
+        for (int k = 1; k < n_lanes; k++)
+            copiers.emplace_back([&, k] {
+                // lane k's bytes may go out once their place is known: behind the FINAL sizes of lanes 0 .. k-1 (placed), or
+                // behind the last byte of lane k-1 in the stream
+                uint64_t at = 0;
+                {
+                    std::unique_lock<std::mutex> l(mg.m);
+                    mg.cv.wait(l, [&] {
+                        if (mg.abort) return true;
+                        for (int j = 0; j < k; j++)
+                            if (!mg.ended[(size_t)j] || (!placed && !mg.copied[(size_t)j])) return false;
+                        return true;
+                    });
+                    if (mg.abort) return;
+                    for (int j = 0; j < k; j++) at += mg.size[(size_t)j];
+                }
+                std::vector<char> buf((size_t)4 << 20);
+                uint64_t pos = 0;
+                for (;;) {
+                    const ssize_t got = pread(ofd[(size_t)k], buf.data(), buf.size(), (off_t)pos);
+                    if (got < 0 && errno == EINTR) continue;
+                    if (got < 0) { std::lock_guard<std::mutex> l(mg.m); mg.abort = true; mg.err = std::string("read error on a lane's output: ") + strerror(errno); mg.cv.notify_all(); return; }
+                    if (got == 0) {
+                        std::unique_lock<std::mutex> l(mg.m);
+                        if (mg.abort) return;
+                        if (mg.ended[(size_t)k] && pos >= mg.size[(size_t)k]) break;
+                        mg.cv.wait_for(l, std::chrono::microseconds(300));  // (the lane is still writing)
+                        continue;
+                    }
+                    size_t done = 0;
+                    while (done < (size_t)got) {
+                        const ssize_t w = placed ? pwrite(1, buf.data() + done, (size_t)got - done, (off_t)((uint64_t)base + at + pos + done))
+                                                 : write(1, buf.data() + done, (size_t)got - done);
+                        if (w < 0 && errno == EINTR) continue;
+                        if (w <= 0) { std::lock_guard<std::mutex> l(mg.m); mg.abort = true; mg.err = "write error on the output stream"; mg.cv.notify_all(); return; }
+                        done += (size_t)w;
+                    }
+                    pos += (uint64_t)got;
+                }
+                std::lock_guard<std::mutex> l(mg.m);
+                mg.copied[(size_t)k] = 1;
+                t_copied[(size_t)k] = secs();
+                mg.cv.notify_all();
+            });
+    // reap whichever lane ends next; one that fails takes the others with it (a lane waiting in ncclCommInitRank for a dead
+    // peer would wait for ever)
+    int live = 0;
+    for (int k = 0; k < n_lanes; k++) live += pids[(size_t)k] > 0;
+    auto kill_all = [&] {
+        for (int k = 0; k < n_lanes; k++)
+            if (pids[(size_t)k] > 0) kill(pids[(size_t)k], SIGKILL);
+    };
+    if (!ok) kill_all();
+    while (live > 0) {
         int st = 0;
-        if (waitpid(pids[(size_t)k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-            fprintf(stderr, "[E::fade annotate] lane %d of %d failed\n", k, n_lanes);
-            ok = false;
+        const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) { if (errno == EINTR) continue; break; }
+        int k = 0;
+        while (k < n_lanes && pids[(size_t)k] != p) k++;
+        if (k == n_lanes) continue;
+        pids[(size_t)k] = -1;
+        live--;
+        const bool good = WIFEXITED(st) && WEXITSTATUS(st) == 0;
+        bool aborted;
+        {
+            std::lock_guard<std::mutex> l(mg.m);
+            aborted = mg.abort;
+        }
+        if (!good || aborted) {
+            if (ok && !good) fprintf(stderr, "[E::fade annotate] lane %d of %d failed\n", k, n_lanes);
+            if (ok) {
+                ok = false;
+                kill_all();
+                std::lock_guard<std::mutex> l(mg.m);
+                mg.abort = true;
+                mg.cv.notify_all();
+            }
+            continue;
+        }
+        uint64_t sz = 0;
+        if (!shards) {
+            if (k == 0) {
+                const off_t e = lseek(1, 0, SEEK_CUR);  // (lane 0 wrote through this very file description)
+                sz = placed && e >= base ? (uint64_t)(e - base) : 0;
+            } else {
+                struct stat sb2;
+                if (fstat(ofd[(size_t)k], &sb2) == 0) sz = (uint64_t)sb2.st_size;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> l(mg.m);
+            mg.ended[(size_t)k] = 1;
+            mg.size[(size_t)k] = sz;
+            if (k == 0) { mg.copied[0] = 1; t_copied[0] = secs(); }
+            t_end[(size_t)k] = secs();
+            mg.cv.notify_all();
+        }
+        if (ok && next_lane < n_lanes) {
+            if (start_lane(next_lane++)) live++;
+            else {
+                ok = false;
+                kill_all();
+                std::lock_guard<std::mutex> l(mg.m);
+                mg.abort = true;
+                mg.cv.notify_all();
+            }
         }
     }
+    for (auto &t : copiers) t.join();
+    if (!mg.err.empty()) { fprintf(stderr, "[E::fade annotate] %s\n", mg.err.c_str()); ok = false; }
     int64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_oversize = 0;
     for (int k = 0; k < n_lanes && ok; k++) {
         FILE *s = fopen(stp[(size_t)k].c_str(), "r");
         long long v[9], red[8];
-        if (!s || fscanf(s, "%lld %lld %lld %lld %lld %lld %lld %lld %lld", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) ok = false;
-        else {
+        if (!s || fscanf(s, "%lld %lld %lld %lld %lld %lld %lld %lld %lld", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) {
+            fprintf(stderr, "[E::fade annotate] lane %d left no report\n", k);
+            ok = false;
+        } else {
             for (int q = 0; q < 8; q++) totals[q] += v[q];
             n_oversize += v[8];
             // lanes on distinct devices have summed the counters among themselves (RCCL): every lane then holds the totals
-            if (distinct && fscanf(s, "%lld %lld %lld %lld %lld %lld %lld %lld", &red[0], &red[1], &red[2], &red[3], &red[4], &red[5], &red[6], &red[7]) == 8 && k == n_lanes - 1)
+            if (lanes_rccl && fscanf(s, "%lld %lld %lld %lld %lld %lld %lld %lld", &red[0], &red[1], &red[2], &red[3], &red[4], &red[5], &red[6], &red[7]) == 8 && k == n_lanes - 1)
                 for (int q = 0; q < 8; q++)
                     if (red[q] != totals[q]) { fprintf(stderr, "[E::fade annotate] the lanes' RCCL sum differs from the sum of their reports\n"); ok = false; break; }
         }
         if (s) fclose(s);
     }
     if (!ok) { cleanup(); return 1; }
-    // the outputs, lane after lane (lane 0 wrote the header), then the end-of-file block
-    std::vector<char> buf((size_t)8 << 20);
-    for (int k = 0; k < n_lanes; k++) {
-        FILE *in = fopen(outp[(size_t)k].c_str(), "rb");
-        if (!in) { cleanup(); return 1; }
-        size_t got;
-        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0)
-            if (fwrite(buf.data(), 1, got, stdout) != got) { fclose(in); cleanup(); fprintf(stderr, "[E::fade annotate] write error on the output stream\n"); return 1; }
-        fclose(in);
+    if (!shards) {
+        if (placed) {
+            uint64_t all = 0;
+            for (int k = 0; k < n_lanes; k++) all += mg.size[(size_t)k];
+            if (lseek(1, (off_t)((uint64_t)base + all), SEEK_SET) < 0) { fprintf(stderr, "[E::fade annotate] cannot seek the output: %s\n", strerror(errno)); cleanup(); return 1; }
+        }
+        if (o.bam || o.ubam) {
+            size_t done = 0;
+            while (done < sizeof BGZF_EOF) {
+                const ssize_t w = write(1, BGZF_EOF + done, sizeof BGZF_EOF - done);
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) { fprintf(stderr, "[E::fade annotate] write error on the output stream\n"); cleanup(); return 1; }
+                done += (size_t)w;
+            }
+        }
     }
-    if (o.bam || o.ubam) fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout);
-    fflush(stdout);
+    if (o.timing) {
+        double last_end = 0, last_copy = 0;
+        for (int k = 0; k < n_lanes; k++) { last_end = std::max(last_end, t_end[(size_t)k]); last_copy = std::max(last_copy, t_copied[(size_t)k]); }
+        fprintf(stderr, "[timing] lanes: %s; the last lane ended after %.3f s, the last byte was in place after %.3f s (merge behind the lanes: %.3f s);",
+                shards ? "a complete file per lane, nothing merged" : placed ? "lanes 1.. copied into their final place while the lanes ran" : "lanes forwarded in order while the lanes ran",
+                last_end, shards ? last_end : last_copy, shards ? 0.0 : std::max(0.0, last_copy - last_end));
+        for (int k = 0; k < n_lanes; k++) fprintf(stderr, " lane %d ended %.3f%s", k, t_end[(size_t)k], k + 1 < n_lanes ? "," : "\n");
+    }
     cleanup();
     if (n_oversize)
         fprintf(stderr, "[W::fade annotate] %lld soft-clipped reads were not re-aligned: read or window beyond the kernels' limits\n", (long long)n_oversize);
@@ -1137,7 +1335,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         fa.seqs.shrink_to_fit();
         // the header goes out through the CPU writer (its members only: no end-of-file block yet)
         {
-            Writer hw(stdout, o.ubam ? OutFmt::UBAM : OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0, false);
+            Writer hw(stdout, o.ubam ? OutFmt::UBAM : OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0 || lane.shard, false);
             hw.close();
         }
         int k;
@@ -1153,12 +1351,14 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
             q_done.push(0);
         }
         q_done.close();
-        if (failed) { abort_all = true; q_free.close(); q_cfree.close(); while (q_full.pop(k)) {} }
+        // a stage gave up (a write error, a back call that failed) or front did: the stages in front of this loop may sit in
+        // q_free / q_cfree, which nobody serves any more — closed here, BEFORE the join, so that they see the end
+        if (failed || abort_all) { abort_all = true; q_free.close(); q_cfree.close(); while (q_full.pop(k)) {} }
         for (auto &t : stages.th) t.join();
         stages.unblock = nullptr;
         if (!stage_err.empty()) { fprintf(stderr, "[E::fade annotate] %s\n", stage_err.c_str()); return 1; }
-        if (!lane.on) fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout);
-        fflush(stdout);
+        if ((!lane.on || lane.shard) && fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, stdout) != sizeof BGZF_EOF) { fprintf(stderr, "[E::fade annotate] write error on the output stream\n"); return 1; }
+        if (fflush(stdout) != 0 || ferror(stdout)) { fprintf(stderr, "[E::fade annotate] write error on the output stream\n"); return 1; }
         int64_t totals[8], n_rec = 0, n_over = 0;
         fadehip_bam_totals(st, totals, &n_rec, &n_over);
         if (lane.on) {
@@ -1363,7 +1563,7 @@ static int annotate_main(const std::string &cl, const Opts &o) {
         // BAM output: the BGZF blocks are compressed on the device (FADE_BGZF_DEVICE=0 keeps them on the host pool)
         std::unique_ptr<DeviceBgzf> dev_codec;
         if (fmt == OutFmt::BAM && !(getenv("FADE_BGZF_DEVICE") && atoi(getenv("FADE_BGZF_DEVICE")) == 0)) dev_codec.reset(new DeviceBgzf(ctxs[0]));
-        Writer writer(stdout, fmt, hdr, &pool, dev_codec.get(), !lane.on || lane.k == 0, !lane.on);
+        Writer writer(stdout, fmt, hdr, &pool, dev_codec.get(), !lane.on || lane.k == 0 || lane.shard, !lane.on || lane.shard);
 
         StageThreads wstage;  // declared after the writer it uses: joined before the writer goes away
         wstage.unblock = [&] {
@@ -1976,7 +2176,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "std.getopt.GetOptException: %s\n", err.c_str());
             return 1;
         }
-        if (!options_allowed(o, "tmwbugBsT")) return 1;
+        if (!options_allowed(o, "tmwbugBsTS")) return 1;
         // app.d:84-89: helpWanted | args.length < 3 (args = prog, "annotate", positionals...)
         if (o.help || o.pos.size() < 2) { print_anno_help(); return 0; }
         if (o.pos.size() < 3) {  // the reference indexes args[2] and dies; say why instead

@@ -391,10 +391,12 @@ struct Rec : RecApi<Rec> {
         d[o + 2] = type;
         memcpy(d.data() + o + 3, data, len);
     }
-    // htslib bam_aux_update_int for a non-negative value: in place when the existing integer type
-    // is wide enough, else replaced at the same position; appended (smallest type) when absent.
+    // htslib bam_aux_update_int (sam.c) for a non-negative value.  Absent: appended with the smallest type.  Present as an
+    // integer whose slot is wide enough: the slot is reused and its type letter becomes the UNSIGNED one of that size
+    // ("\0CS\0I"[old_sz] — an rs:c / rs:s / rs:i leaves as rs:C / rs:S / rs:I); too narrow: replaced at the same position.
+    // Present with a non-integer type: htslib returns EINVAL and leaves the record as it is, and so does this.
     void aux_update_uint(const char tag[2], uint32_t v) {
-        uint8_t type = v <= 0xff ? 'C' : v <= 0xffff ? 'S' : 'I';
+        uint8_t type = v < 0xff ? 'C' : v < 0xffff ? 'S' : 'I';  // (htslib compares with `<`: 255 already takes 'S')
         uint8_t buf[4];
         memcpy(buf, &v, 4);
         size_t p = aux_find(tag);
@@ -406,22 +408,24 @@ struct Rec : RecApi<Rec> {
         const uint8_t ot = d[p + 2];
         const size_t os = (size_t)aux_type_size(ot);
         const bool is_int = ot == 'c' || ot == 'C' || ot == 's' || ot == 'S' || ot == 'i' || ot == 'I';
-        const uint64_t omax = ot == 'c' ? 0x7f : ot == 'C' ? 0xff : ot == 's' ? 0x7fff : ot == 'S' ? 0xffff
-                              : ot == 'i' ? 0x7fffffff : 0xffffffffull;
-        if (is_int && v <= omax) {
+        if (!is_int) return;
+        if (os >= need) {
+            d[p + 2] = (uint8_t)"\0CS\0I"[os];
             memcpy(d.data() + p + 3, buf, os);  // little endian: low bytes first
             return;
         }
         const size_t fs = aux_field_size(p + 2);
         replace_bytes(p + 2, fs, type, buf, need);
     }
-    // htslib bam_aux_update_str: replaced at the same position when present, appended otherwise
+    // htslib bam_aux_update_str: replaced at the same position when present as 'Z', appended when absent; present with
+    // another type: EINVAL, the record stays as it is
     void aux_update_str(const char tag[2], const std::string &s) {
         size_t p = aux_find(tag);
         if (p == std::string::npos) {
             aux_append(tag, 'Z', s.c_str(), s.size() + 1);
             return;
         }
+        if (d[p + 2] != 'Z') return;
         const size_t fs = aux_field_size(p + 2);
         replace_bytes(p + 2, fs, 'Z', s.c_str(), s.size() + 1);
     }

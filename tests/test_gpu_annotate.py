@@ -50,22 +50,28 @@ def test_stats_allreduce_over_rccl(ctx):
 
 
 def test_stats_allreduce_with_two_contexts_on_the_one_device(ctx):
-    """Two contexts (two ranks) on this box's single GPU.  RCCL wants one rank per device: ncclCommInitAll with a device
-    listed twice is refused, which the C ABI reports as FADEHIP_E_RCCL — the reason `fade annotate --gpus N` under
-    FADE_DEVICE_MAP=0,0 sums on the host instead (fade_main.cpp).  Whichever way the sum is taken, every rank must end up
-    with the column sums: checked here for the RCCL call if this stack allows it, and for the host sum it falls back to."""
+    """Two contexts (two ranks) of ONE process on this box's single GPU, through ncclCommInitAll.  RCCL wants one rank per
+    device; what it says to a device listed twice is asserted for what it is — a sum that must be right, or a refusal that
+    must be FADEHIP_E_RCCL from ncclCommInitAll — and written to gpurun_out/rccl_two_contexts.txt (DESIGN.md §0(e) quotes
+    it).  The two-PROCESS form is tests/test_gpu_rccl_ranks.py.  `fade annotate --gpus N` under FADE_DEVICE_MAP=0,0 does not
+    depend on either: it sums the lanes' reports in the parent."""
+    import os
     import fade_amd
     other = fade_amd.Context(device=0)
     try:
         c = np.array([np.arange(8) * 10 + 1, np.arange(8) * 1000 + 5], dtype=np.int64)
         want = np.tile(c.sum(axis=0), (2, 1))
         try:
-            out = fade_amd.stats_allreduce([ctx, other], c)
-            assert np.array_equal(out, want)  # RCCL accepted two ranks on one device
+            out = fade_amd.stats_allreduce([ctx, other], c.copy())
+            ran = "RCCL formed a communicator of two ranks on one device and summed"
+            assert np.array_equal(out, want)
         except fade_amd.FadeHipError as e:
-            assert e.code == -8, e  # FADEHIP_E_RCCL: refused, not crashed
-            host = np.tile(c.sum(axis=0), (2, 1))  # what the driver does instead (fade_main.cpp: per_dev summed on the host)
-            assert np.array_equal(host, want)
+            ran = "refused: %s" % e
+            assert e.code == -8 and "ncclCommInitAll" in str(e), e  # FADEHIP_E_RCCL from the communicator set-up: refused, not crashed
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "rccl_two_contexts.txt"), "w") as f:
+            f.write(ran + "\n")
         # the contexts stay usable either way
         one = fade_amd.stats_allreduce([ctx], c[:1])
         assert np.array_equal(one, c[:1])

@@ -64,6 +64,14 @@ def test_device_file_path_equals_the_host_pipeline_on_the_golden_inputs(tmp_path
     assert b"file path on the device" in dev.stderr and b"file path on the device" not in host.stderr
     assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
     assert dev.stdout.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    # the file path's OWN bytes against the oracle's golden records (not only through the host pipeline): rs, am, as, ar, ab
+    # of every record and their order (anno.d:94-107), inflate on the device and on the host pool
+    from test_gpu_cli import _check_records, _expected
+    exp = _expected(tag)[0]
+    _check_records(samutil.bam_to_sam_records(dev.stdout)[2], exp)
+    raw = _run(base, {"FADE_BAM_INFLATE": "host"})
+    assert raw.returncode == 0 and b"file path on the device" in raw.stderr
+    _check_records(samutil.bam_to_sam_records(raw.stdout)[2], exp)
     few = _run(base[:1] + ["-t", "2"] + base[1:])  # (with fewer than 8 threads the device inflates: nothing is said about it here)
     assert few.returncode == 0 and b"inflate on 0 host threads" in few.stderr, few.stderr.decode()[-800:]
     assert samutil.bam_to_sam_records(few.stdout)[2] == samutil.bam_to_sam_records(dev.stdout)[2]
@@ -81,6 +89,50 @@ def test_device_file_path_equals_the_host_pipeline_on_the_golden_inputs(tmp_path
     _, _, r1 = samutil.bam_to_sam_records(dev.stdout)
     _, _, r2 = samutil.bam_to_sam_records(dev2.stdout)
     assert r1 == r2
+    _check_records(r2, exp)
+
+
+@pytest.mark.parametrize("seed,floor_len,window", [(11, 5, 100), (12, 0, 40), (13, 7, 300)])
+def test_device_file_path_against_the_oracle_on_iupac_reads_and_a_soft_masked_fasta(tmp_path, oracle, seed, floor_len, window):
+    """The file path held to the oracle directly (oracle.annotate_one per record: anno.d:55-110, analysis.d:84-92,108-118):
+    reads with N and IUPAC codes, every CIGAR op, random flags, a FASTA with lower-case stretches and N / IUPAC letters
+    (analysis.d:63 upper-cases the window) — both inflaters, records in input order."""
+    from test_gpu_fuzz import _random_batch
+    rng = np.random.default_rng(seed)
+    contigs = []
+    for k in range(3):
+        c = bytearray(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(4000, 9000)))].tobytes())
+        for q in rng.integers(0, len(c), size=len(c) // 40):
+            c[q] = int(rng.choice(list(b"NNNRYKMacgtn")))
+        a = int(rng.integers(0, len(c) - 300))
+        c[a:a + 200] = bytes(c[a:a + 200]).lower()
+        contigs.append(bytes(c).decode())
+    names = ["ctgA", "ctgB", "ctgC"]
+    b = _random_batch(rng, contigs, 2500, window)
+    qn = ["q%d" % i for i in range(len(b["pos"]))]
+    b["qname"] = [x.encode() for x in qn]
+    sam, fa, bam = tmp_path / "in.sam", tmp_path / "ref.fa", tmp_path / "in.bam"
+    sam.write_text(samutil.batch_to_sam(b, names, [len(c) for c in contigs], qn))
+    fa.write_text("".join(">%s\n%s\n" % (n, "\n".join(c[o:o + 70] for o in range(0, len(c), 70))) for n, c in zip(names, contigs)))
+    _bam_of(sam, bam)
+    G = oracle.GenomeHolder(names, contigs)
+    reads, keep = oracle.make_reads(b)
+    want = [oracle.annotate_one(G, reads[i], floor_len, window) for i in range(len(qn))]
+    assert sum(w["has_tags"] for w in want) >= 20
+    for inflate in ("device", "host"):
+        p = _run(["annotate", "--timing", "--min-length", str(floor_len), "-w", str(window), "-b", str(bam), str(fa)], {"FADE_BAM_INFLATE": inflate})
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert b"file path on the device" in p.stderr
+        _, _, recs = samutil.bam_to_sam_records(p.stdout)
+        assert [r["qname"] for r in recs] == qn
+        for r, w in zip(recs, want):
+            t = r["tags"]
+            assert int(t["rs"][1]) == w["rs"], (r["qname"], t["rs"], w)
+            if w["has_tags"]:
+                assert (t["am"][1], t["as"][1], t["ar"][1], t["ab"][1]) == (w["am"], w["as_"], w["ar"], w["ab"]), r["qname"]
+                assert [k for k in r["tag_order"] if k in ("rs", "am", "as", "ar", "ab")] == ["rs", "am", "as", "ar", "ab"]
+            else:
+                assert "am" not in t and "as" not in t
 
 
 @pytest.fixture(scope="module")
@@ -191,6 +243,72 @@ def test_stream_api_one_member_per_call(big):
         w_at += 4 + struct.unpack_from("<i", want, w_at)[0] + 4
     assert got == want[w_at:]
     assert n_rec == 30000 and totals[0] == 30000 and n_over == 0
+
+
+def test_a_tiny_last_call_whose_last_member_is_mostly_another_readers(big):
+    """tail_trim (a lane's last member belongs mostly to the next lane): the inflater still writes the member's whole
+    ISIZE, so the call's buffer must be sized from the untrimmed length — here the last call inflates to 64 KB of which a
+    few hundred bytes are this stream's (a buffer sized from the trimmed length would be overrun by ~60 KB).  The records
+    that come out are exactly the ones in front of the cut, byte for byte those of the whole-file run."""
+    from test_gpu_inflate import member
+    raw = big["bam"].read_bytes()
+    payload = gzip.decompress(raw)
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    names = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", payload, at)[0]
+        names.append(payload[at + 4:at + 4 + ln - 1].decode())
+        at += 4 + ln + 4
+    # the first 40 records; the cut lies a few hundred bytes into a member of 0xff00 bytes, alone in the last call
+    recs_at = at
+    for _ in range(40):
+        at += 4 + struct.unpack_from("<I", payload, at)[0]
+    mine = payload[recs_at:at]
+    assert len(mine) > 0x1000
+    first = mine[:len(mine) - 300]                      # call 1: ends inside a record
+    last = mine[len(mine) - 300:] + payload[at:at + 0xff00 - 300]  # call 2: 300 bytes of ours, the rest another reader's
+    assert len(last) == 0xff00
+    g = big["g"]
+    ctx = fade_amd.Context(device=0)
+    try:
+        ctx.genome_upload(g.names, g.ascii_contigs())
+        st = ctx.bam_stream(names, floor_len=5, window=100, first_record=0, tail_trim=len(last) - 300)
+        out = []
+        st.front(member(first, 6), last=False)
+        out.append(st.back())
+        st.front(member(last, 6), last=True)
+        out.append(st.back())
+        totals, n_rec, n_over = st.totals()
+        st.close()
+        # (the same stream again on the warmed-up buffers, and a neighbour allocation checked for stray bytes)
+        canary = ctx.bgzf_deflate(bytes(range(256)) * 64)
+        assert gzip.decompress(canary) == bytes(range(256)) * 64
+    finally:
+        ctx.close()
+    assert n_rec == 40 and totals[0] == 40
+    got = gzip.decompress(b"".join(out))
+    want = gzip.decompress(big["host"].stdout)
+    l_text_w = struct.unpack_from("<i", want, 4)[0]
+    w_at = 8 + l_text_w
+    n_ref_w = struct.unpack_from("<i", want, w_at)[0]
+    w_at += 4
+    for _ in range(n_ref_w):
+        w_at += 4 + struct.unpack_from("<i", want, w_at)[0] + 4
+    assert got == want[w_at:w_at + len(got)] and len(got) > len(mine)
+
+
+@pytest.mark.parametrize("inflate", ["device", "host"])
+def test_a_full_output_device_fails_the_run_instead_of_hanging_it(big, inflate):
+    """stdout = /dev/full: every write fails with ENOSPC.  The writer stage gives up, and the stages in front of it — which
+    sit in queues nobody serves any more — must see the end: a message and a non-zero exit, not a hang."""
+    with open("/dev/full", "wb") as full:
+        p = subprocess.run([FADE, "annotate", "-w", "100", "-b", str(big["bam"]), str(big["fa"])], stdout=full, stderr=subprocess.PIPE, timeout=120,
+                           env=dict(os.environ, FADE_BAM_INFLATE=inflate, FADE_BAM_CHUNK_MB="1"))
+    assert p.returncode != 0
+    assert b"write error on the output stream" in p.stderr, p.stderr.decode()[-1500:]
 
 
 def test_corrupt_inputs_fail_the_run(tmp_path, big):
@@ -538,3 +656,29 @@ def test_records_with_every_kind_of_tag(tmp_path, big, with_ours):
     assert gzip.decompress(dev.stdout) == gzip.decompress(host.stdout)
     _, _, recs = samutil.bam_to_sam_records(dev.stdout)
     assert len(recs) == n and sum("am" in r["tags"] for r in recs) > 100
+    # htslib's update semantics, stated on their own (sam.c bam_aux_update_int / bam_aux_update_str): an integer rs keeps its
+    # slot and position and leaves with the UNSIGNED type letter of its size; an rs of another type stays as it is (EINVAL)
+    # and no second rs is appended; a string tag of ours that is not 'Z' stays as it is; absent tags are appended, rs as 'C'
+    _, _, ins = samutil.bam_to_sam_records(b"".join(member(b, 1) for b in blocks) + EOF_MARK)
+    seen = dict(int_kept=0, other_kept=0, appended=0, str_kept=0)
+    for ri, ro in zip(ins, recs):
+        ti, to = ri["tags"], ro["tags"]
+        assert ro["tag_order"].count("rs") == 1
+        if "rs" in ti:
+            assert ro["tag_order"].index("rs") == ri["tag_order"].index("rs")
+            if "rs.bamtype" in ti:
+                assert to["rs.bamtype"] == {"c": "C", "C": "C", "s": "S", "S": "S", "i": "I", "I": "I"}[ti["rs.bamtype"]]
+                assert 0 <= int(to["rs"][1]) < 64
+                seen["int_kept"] += 1
+            else:
+                assert to["rs"] == ti["rs"]
+                seen["other_kept"] += 1
+        else:
+            assert to["rs.bamtype"] == "C" and ro["tag_order"][len(ri["tag_order"])] == "rs"
+            seen["appended"] += 1
+        for k in ("am", "as", "ar", "ab"):
+            if k in ti and ti[k][0] != "Z":
+                assert to[k] == ti[k] and ro["tag_order"].count(k) == 1
+                seen["str_kept"] += 1
+    if with_ours:
+        assert min(seen.values()) > 20, seen

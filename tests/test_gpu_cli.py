@@ -270,3 +270,124 @@ def test_cli_lanes_one_process_per_gpu_on_disjoint_ranges(tmp_path, fmt):
     assert stats(one.stderr) == stats(two.stderr) == stats(three.stderr) and stats(one.stderr)[0] == "\t30000"
     if fmt:
         assert two.stdout.endswith(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+
+
+@pytest.fixture(scope="module")
+def lanes_bam(tmp_path_factory):
+    """800,000 reads of C2 as a BAM file (tools/synthgen: the bench's generator), and the one-process run over it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synthgen as sg
+    from fade_amd import synth
+    d = tmp_path_factory.mktemp("lanes")
+    cfg = synth.config("C2")
+    cfg["contig_len"] = 2_000_000
+    g = sg.Genome(cfg["n_contigs"], cfg["contig_len"], 42)
+    bam, fa = str(d / "in.bam"), str(d / "ref.fa")
+    g.write_fasta(fa)
+    w = sg.BamWriter(bam, g)
+    for k in range(4):
+        w.write(sg.make_reads(g, 200_000, 100 + k, cfg), k * 100_000)
+    w.close()
+    one_out = str(d / "one.bam")
+    with open(one_out, "wb") as fo:
+        one = subprocess.run([FADE, "annotate", "--stats", "-w", "100", "-b", bam, fa], stdout=fo, stderr=subprocess.PIPE, timeout=600)
+    assert one.returncode == 0, one.stderr.decode()[-1500:]
+    return dict(dir=d, bam=bam, fa=fa, one=one_out, one_err=one.stderr)
+
+
+def _bam_payload(path_or_bytes):
+    import gzip
+    raw = gzip.decompress(open(path_or_bytes, "rb").read() if isinstance(path_or_bytes, str) else path_or_bytes)
+    l_text = int.from_bytes(raw[4:8], "little")
+    text = [l for l in raw[8:8 + l_text].decode().splitlines() if not l.startswith("@PG\tID:fade-annotate")]
+    return text, raw[8 + l_text:]
+
+
+def _stats_lines(err):
+    return [l for l in err.decode().split("read count:")[1].splitlines() if not l.startswith("[timing]") and l][:7]
+
+
+@pytest.mark.parametrize("mode", ["placed", "stream", "pipe"])
+def test_cli_eight_lanes_merge_while_they_run(lanes_bam, mode):
+    """`fade annotate --gpus 8 -b` (BASELINE config 4 rehearsed on one device: FADE_DEVICE_MAP puts every lane
+    on GPU 0, FADE_LANES_LIVE=4 keeps within the box's process limit).  The parent forwards the lanes' outputs WHILE they
+    run: into their final place when stdout is a file (placed), one after the other when it is a pipe (pipe; `stream` asks
+    for that order into a file).  Records and their order = the one-process run's; --timing reports the merge behind the
+    last lane, which must be a small part of the run (the serial tail this replaces was a copy of everything)."""
+    d = lanes_bam["dir"]
+    env = dict(os.environ, FADE_DEVICE_MAP="0,0,0,0,0,0,0,0", FADE_LANES_LIVE="4")
+    if mode == "stream":
+        env["FADE_LANES_MERGE"] = "stream"
+    args = [FADE, "annotate", "--stats", "--timing", "--gpus", "8", "-w", "100", "-b", lanes_bam["bam"], lanes_bam["fa"]]
+    if mode == "pipe":
+        p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        out = p.stdout
+    else:
+        path = str(d / ("eight_%s.bam" % mode))
+        with open(path, "wb") as fo:
+            p = subprocess.run(args, stdout=fo, stderr=subprocess.PIPE, timeout=900, env=env)
+        out = open(path, "rb").read()
+    assert p.returncode == 0, p.stderr.decode()[-2500:]
+    err = p.stderr.decode()
+    assert "lane 7 of 8" in err
+    assert ("copied into their final place while the lanes ran" in err) == (mode == "placed")
+    assert ("forwarded in order while the lanes ran" in err) == (mode != "placed")
+    assert _bam_payload(out) == _bam_payload(lanes_bam["one"])
+    assert out.endswith(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    assert _stats_lines(p.stderr) == _stats_lines(lanes_bam["one_err"]) and _stats_lines(p.stderr)[0] == "\t800000"
+    line = [l for l in err.splitlines() if l.startswith("[timing] lanes:")][0]
+    last_end = float(line.split("the last lane ended after ")[1].split(" s")[0])
+    tail = float(line.split("merge behind the lanes: ")[1].split(" s")[0])
+    assert tail < max(0.25, 0.5 * last_end), line
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "lanes_merge_%s.txt" % mode), "w") as f:
+        f.write("\n".join(l for l in err.splitlines() if l.startswith("[timing] lane")) + "\n")
+
+
+def test_cli_out_shards_every_lane_a_complete_file(lanes_bam):
+    """`--gpus 6 --out-shards PREFIX`: every lane writes PREFIX.<k>.bam, a complete BAM (header with the @PG line, the lane's
+    records, the end-of-file block); nothing goes to stdout, nothing is merged.  The shards' records, in lane order, are the
+    one-process run's."""
+    d = lanes_bam["dir"]
+    prefix = str(d / "shard")
+    p = subprocess.run([FADE, "annotate", "--stats", "--timing", "--gpus", "6", "--out-shards", prefix, "-w", "100", "-b", lanes_bam["bam"], lanes_bam["fa"]],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, FADE_DEVICE_MAP="0,0,0,0,0,0"))
+    assert p.returncode == 0, p.stderr.decode()[-2500:]
+    assert p.stdout == b"" and b"a complete file per lane, nothing merged" in p.stderr
+    text1, recs1 = _bam_payload(lanes_bam["one"])
+    body = b""
+    n = 0
+    for k in range(6):
+        data = open("%s.%d.bam" % (prefix, k), "rb").read()
+        assert data.endswith(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+        if k in (0, 5):  # (decoding 270,000 records in Python twice is enough)
+            text, names, recs = samutil.bam_to_sam_records(data)
+            assert any(l.startswith("@PG\tID:fade-annotate") for l in text.splitlines()) and len(recs) > 50_000
+            assert all("rs" in r["tags"] for r in recs[:2000])
+        t, b = _bam_payload(data)
+        assert t == text1
+        # behind l_text + text come n_ref and the references: the same in every shard; the records follow
+        import struct
+        at = 0
+        n_ref = struct.unpack_from("<i", b, at)[0]
+        at += 4
+        for _ in range(n_ref):
+            at += 4 + struct.unpack_from("<i", b, at)[0] + 4
+        if k == 0:
+            body += b[:at]
+        body += b[at:]
+        n += 1
+    assert body == recs1
+    assert _stats_lines(p.stderr) == _stats_lines(lanes_bam["one_err"])
+
+
+def test_cli_a_failing_lane_ends_the_run(lanes_bam):
+    """One lane that cannot work (its device does not exist) fails; the parent must notice whichever lane ends first, stop
+    the others and report — not wait for lanes in order, and not leave lanes waiting for a dead peer."""
+    p = subprocess.run([FADE, "annotate", "--gpus", "3", "-w", "100", "-b", lanes_bam["bam"], lanes_bam["fa"]], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, FADE_DEVICE_MAP="0,0,63"))
+    assert p.returncode != 0
+    assert b"lane 2 of 3 failed" in p.stderr, p.stderr.decode()[-1500:]
+    left = [f for f in os.listdir(os.environ.get("TMPDIR", "/tmp")) if f.startswith("fade_lanes_")]
+    assert left == [], left
