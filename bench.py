@@ -45,13 +45,13 @@ VALU_PEAK_TLANE = 39.3
 VALU_F32_PEAK_TLANE = 78.6
 STAT_NAMES = ["read_count", "clipped", "sup", "art_sup", "art", "art_mate", "aln_l", "aln_r"]
 BATCHES_PER_STEP = 10
-ROUND = "r03"
+ROUND = "r04"
 
 
 def pmc_summary(config):
     """The committed rocprofv3 --pmc passes of this build and config (profiles/collect.sh + summarize_pmc.py), or None.
     Replayed, not measured in this run: the fields that come from it carry `source`."""
-    for rnd in (ROUND, "r02"):
+    for rnd in (ROUND, "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (rnd, config))
         try:
             return json.load(open(path)), os.path.relpath(path, ROOT)
@@ -123,39 +123,143 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def e2e_legs(bam, fa, n_reads, cfg, threads, tmp):
+def e2e_run(exe, bam, fa, n_reads, cfg, threads, out, reps, env=None):
+    """One leg: `exe annotate -b bam fa > out`, wall time of the whole process, best of `reps` runs."""
+    best = None
+    for _ in range(reps):
+        if os.path.exists(out):
+            os.remove(out)  # (truncating the previous output is not part of the run)
+        t1 = time.perf_counter()
+        with open(out, "wb") as fo:
+            p = subprocess.run([exe, "annotate", "--timing", "-t", str(threads), "-w", str(cfg["window"]), "--min-length",
+                                str(cfg["floor_len"]), "-b", bam, fa], stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+        dt = time.perf_counter() - t1
+        if p.returncode != 0:
+            return dict(error=p.stderr.decode(errors="replace")[-400:])
+        r = dict(seconds=dt, reads_per_s=n_reads / dt, out_bytes=os.path.getsize(out), best_of=reps,
+                 timing=[l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]")][:8])
+        if best is None or r["seconds"] < best["seconds"]:
+            best = r
+    if os.path.exists(out):
+        os.remove(out)
+    return best
+
+
+def e2e_legs(bam, fa, n_reads, cfg, threads, tmp, which=("gpu", "gpu_device_inflate", "gpu_host_pipeline", "cpu")):
     """The whole program on a BAM file, GPU driver and CPU comparator on the same threads: wall time of each process
-    (start-up, FASTA load and genome upload, BGZF inflate, annotate, tags, BGZF deflate, exit), best of 2 runs each."""
+    (start-up, FASTA load and genome upload, BGZF inflate, annotate, tags, BGZF deflate, exit), best of 2 runs for EVERY leg."""
     fade = os.path.join(ROOT, "fade_amd", "fade")
     cpu = os.path.join(ROOT, "tools", "cpu_annotate")
-    res = {}
+    legs = {
+        # default: the file path on the device (framing, annotate, tags, deflate as kernels), BGZF inflate on the host pool
+        "gpu": (fade, None),
+        "gpu_device_inflate": (fade, {"FADE_BAM_INFLATE": "device"}),  # ... inflate on the device too
+        "gpu_host_pipeline": (fade, {"FADE_BAM_DEVICE": "0"}),        # round 2's pipeline (+ device deflate)
+        "cpu": (cpu, None),
+    }
+    return {k: e2e_run(legs[k][0], bam, fa, n_reads, cfg, threads, os.path.join(tmp, "bench_e2e.%s.bam" % k), 2, legs[k][1]) for k in which}
 
-    def run(tag, exe, reps, env=None):
-        best = None
-        out = os.path.join(tmp, "bench_e2e.%s.bam" % tag)
-        for _ in range(reps):
-            if os.path.exists(out):
-                os.remove(out)  # (truncating the previous output is not part of the run)
-            t1 = time.perf_counter()
-            with open(out, "wb") as fo:
-                p = subprocess.run([exe, "annotate", "--timing", "-t", str(threads), "-w", str(cfg["window"]), "--min-length",
-                                    str(cfg["floor_len"]), "-b", bam, fa], stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
-            dt = time.perf_counter() - t1
-            if p.returncode != 0:
-                return dict(error=p.stderr.decode(errors="replace")[-400:])
-            r = dict(seconds=dt, reads_per_s=n_reads / dt, out_bytes=os.path.getsize(out),
-                     timing=[l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]")][:8])
-            if best is None or r["seconds"] < best["seconds"]:
-                best = r
-        os.remove(out)
-        return best
 
-    # default: the file path on the device (framing, annotate, tags, deflate as kernels), BGZF inflate on the host pool
-    res["gpu"] = run("gpu", fade, 2)
-    res["gpu_device_inflate"] = run("gpu_di", fade, 2, {"FADE_BAM_INFLATE": "device"})  # ... inflate on the device too
-    res["gpu_host_pipeline"] = run("gpu_hp", fade, 1, {"FADE_BAM_DEVICE": "0"})  # round 2's pipeline (+ device deflate)
-    res["cpu"] = run("cpu", cpu, 1)
-    return res
+def bgzf_chunks(path, chunk_payload):
+    """The BGZF members of a file grouped into runs whose payloads add up to at most chunk_payload bytes: [(bytes, isize sum)]."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    out, at, lo, acc = [], 0, 0, 0
+    n = len(raw)
+    while at + 28 <= n:
+        bsize = int(raw[at + 16]) + (int(raw[at + 17]) << 8) + 1
+        isz = int(raw[at + bsize - 4]) | (int(raw[at + bsize - 3]) << 8) | (int(raw[at + bsize - 2]) << 16) | (int(raw[at + bsize - 1]) << 24)
+        if acc and acc + isz > chunk_payload:
+            out.append((raw[lo:at], acc))
+            lo, acc = at, 0
+        acc += isz
+        at += bsize
+    if at > lo:
+        out.append((raw[lo:at], acc))
+    return out
+
+
+def records_path_rate(ctx, bam, names, cfg, n_reads, barrier, chunk_mb=32, passes=3):
+    """value_from_records: the path from BAM RECORD BYTES.  The workload's BAM payload (what htslib's inflate hands to
+    bam_read1 — record after record, block_size first), already inflated and in pinned host memory, goes through
+    fadehip_bam_front_raw: H2D, record framing, the packing of the batch arrays, the gate (anno.d:61-65 decided on the
+    device for every record — no host code looks at a record), score pass, pass 2, tags, the rewritten records left on the
+    device (FADEHIP_BAM_NO_OUTPUT: no codec).  front and back on a thread each, as the `fade` driver runs them."""
+    import ctypes as C
+    import threading
+    L = ctx._L
+    chunks = []
+    hdr = None
+    for members, isz in bgzf_chunks(bam, chunk_mb << 20):
+        pay = ctx.bgzf_inflate(members, out_cap=isz + 64)  # (setup: the device's inflater, checked against ISIZE / CRC32)
+        assert len(pay) == isz
+        if hdr is None:
+            l_text = int(np.frombuffer(pay[4:8].tobytes(), "<i4")[0])
+            at = 8 + l_text
+            n_ref = int(np.frombuffer(pay[at:at + 4].tobytes(), "<i4")[0])
+            at += 4
+            for _ in range(n_ref):
+                at += 4 + int(np.frombuffer(pay[at:at + 4].tobytes(), "<i4")[0]) + 4
+            hdr = at
+        ptr = C.c_void_p()
+        ctx._chk(L.fadehip_host_alloc(ctx._h, max(len(pay), 64), C.byref(ptr)))
+        C.memmove(ptr, pay.ctypes.data, len(pay))
+        chunks.append((ptr, len(pay)))
+    payload_bytes = sum(n for _, n in chunks)
+    times, totals = [], None
+    for it in range(passes + 1):
+        st = ctx.bam_stream(names, floor_len=cfg["floor_len"], window=cfg["window"], first_record=hdr, no_output=True)
+        err = []
+        go = threading.Semaphore(0)
+
+        def backs():
+            try:
+                for _ in chunks:
+                    go.acquire()
+                    st.back()
+            except Exception as exc:  # noqa: BLE001
+                err.append(exc)
+
+        th = threading.Thread(target=backs)
+        barrier()
+        t0 = time.perf_counter()
+        th.start()
+        for j, (ptr, n) in enumerate(chunks):
+            st.front_raw_ptr(ptr, n, last=(j == len(chunks) - 1))
+            go.release()
+        th.join()
+        barrier()
+        dt = time.perf_counter() - t0
+        if err:
+            raise err[0]
+        totals = st.totals()
+        st.close()
+        if it:  # (the first pass sizes the stream's buffers)
+            times.append(dt)
+    for ptr, _ in chunks:
+        L.fadehip_host_free(ctx._h, ptr)
+    assert totals[1] == n_reads, (totals, n_reads)
+    return dict(seconds=times, payload_bytes=payload_bytes, calls=len(chunks), stats=totals[0], records=totals[1])
+
+
+def cpu_from_records(sample_bam, fa, cfg, threads, reps=3):
+    """cpu_baseline on value_from_records' definition: tools/cpu_annotate --records-only — the sample is read, inflated and
+    framed outside the clock; inside it every record goes from its BAM bytes (a bam1_t as htslib hands it over) through
+    annotateTask of the oracle (gate, reverse complement, FASTA window, one striped SW call per qualifying clip, gates, tag
+    strings) on all threads; nothing is compressed or written.  Median of `reps`."""
+    exe = os.path.join(ROOT, "tools", "cpu_annotate")
+    rs = []
+    for _ in range(reps):
+        p = subprocess.run([exe, "annotate", "--records-only", "-t", str(threads), "-w", str(cfg["window"]), "--min-length", str(cfg["floor_len"]), "-b",
+                            sample_bam, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if p.returncode != 0:
+            return dict(error=p.stderr.decode(errors="replace")[-300:])
+        rs.append(json.loads(p.stdout.decode().strip().splitlines()[-1]))
+    rs.sort(key=lambda r: r["seconds"])
+    r = rs[len(rs) // 2]
+    return dict(value=r["records"] / r["seconds"], unit="reads/s", cores=threads, kind="port",
+                sample="%d reads of the same workload as BAM records in memory, median of %d passes (%.2f s each); the oracle's annotateTask per record "
+                       "incl. the tag strings, %d threads; reading / inflating / framing the sample is outside the clock, nothing is written" % (
+                           r["records"], reps, r["seconds"], threads))
 
 
 def main():
@@ -168,6 +272,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (fade annotate / tools/cpu_annotate on a BAM file)")
     ap.add_argument("--e2e-reads", type=int, default=10_000_000)
+    ap.add_argument("--e2e-big-reads", type=int, default=30_000_000, help="reads of the second, larger end-to-end file (0: skip that leg)")
     ap.add_argument("--slots", type=int, default=2, help="batches in flight per GPU")
     ap.add_argument("--synth", default="native", choices=["native", "numpy"], help="generator of the synthetic reads "
                     "(tools/synthgen.cpp on all host threads, or fade_amd/synth.py: the same laws, another random stream)")
@@ -214,18 +319,28 @@ def main():
     ctx = fade_amd.Context(device=local, max_batch_reads=max(args.batch_reads, 1 << 20))
     ctx.genome_upload(genome.names, genome.ascii_contigs())
     do_cpu = rank == 0 and not args.no_cpu and world == 1
-    do_e2e = rank == 0 and not args.no_e2e and world == 1 and args.synth == "native"
+    # end to end: every rank has a BAM file of ITS shard of the reads ("sharded per GPU"); rank 0 alone
+    # also runs the CPU comparator and the larger file
+    do_e2e = not args.no_e2e and args.synth == "native"
     tmp = os.environ.get("TMPDIR", "/tmp")
-    bam_path, fa_path = os.path.join(tmp, "bench_e2e.bam"), os.path.join(tmp, "bench_e2e.fa")
-    bam_writer = None
+    sfx = "" if world == 1 else ".%d" % rank
+    bam_path, fa_path = os.path.join(tmp, "bench_e2e%s.bam" % sfx), os.path.join(tmp, "bench_e2e%s.fa" % sfx)
+    big_path, sample_path = os.path.join(tmp, "bench_e2e_big.bam"), os.path.join(tmp, "bench_e2e_sample.bam")
+    do_big = do_e2e and world == 1 and args.e2e_big_reads > 0
+    bam_writer = big_writer = sample_writer = None
     if do_e2e:
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s"])
+        if rank == 0:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s"])
         genome.write_fasta(fa_path)
         bam_writer = sg.BamWriter(bam_path, genome)
+        if do_big:
+            big_writer = sg.BamWriter(big_path, genome)
+        if do_cpu:
+            sample_writer = sg.BamWriter(sample_path, genome)
     # per-GPU record range: each rank owns its own shard of the reads (stream 100 (k + 1) + rank)
     full, pinned, pinned_pre = [], [], []
     t_gen = t_pack = t_bam = 0.0
-    e2e_written = 0
+    e2e_written = big_reps = 0
     for k in range(BATCHES_PER_STEP):
         t0 = time.perf_counter()
         if args.synth == "native":
@@ -244,13 +359,22 @@ def main():
             m = min(len(b["pos"]), args.e2e_reads - e2e_written)
             bam_writer.write(b if m == len(b["pos"]) else synth.take(b, np.arange(m)), e2e_written // 2)
             e2e_written += m
+        if big_writer is not None:  # the larger file: the workload's batches over and over under new read names
+            big_reps = max(1, -(-args.e2e_big_reads // (args.batch_reads * BATCHES_PER_STEP)))
+            for rep in range(big_reps):
+                big_writer.write(b, (rep * args.batch_reads * BATCHES_PER_STEP + k * args.batch_reads) // 2)
+        if sample_writer is not None and k < 2:  # the CPU legs' bounded sample: 2 M reads
+            sample_writer.write(b, k * args.batch_reads // 2)
         t3 = time.perf_counter()
         t_gen, t_pack, t_bam = t_gen + t1 - t0, t_pack + t2 - t1, t_bam + t3 - t2
         full.append(b if (do_cpu and k < 2) else None)  # the CPU leg's bounded sample: 2 M reads
     if bam_writer is not None:
         t0 = time.perf_counter()
-        bam_writer.close()
+        for w_ in (bam_writer, big_writer, sample_writer):
+            if w_ is not None:
+                w_.close()
         t_bam += time.perf_counter() - t0
+    big_reads = big_reps * args.batch_reads * BATCHES_PER_STEP if do_big else 0
     t_setup.update(synthetic_batches=t_gen, pack_pinned_blocks=t_pack, e2e_bam=t_bam)
     floor_len, window = cfg["floor_len"], cfg["window"]
 
@@ -386,7 +510,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "units_per_launch": units,
                          "bytes_per_unit": alg / max(units, 1.0),
                          "kernel_ms": fwd, "kernel_ms_is": "HIP events around the kernel on its stream, launches that had the device to themselves "
-                                                           "(one slot, serial; %d launches after the timed region)" % len(solo),
+                                                           "(one slot, serial, each launch behind a host wait and an upload: %d launches after the timed region).  The "
+                                                           "launch state of the three figures: kernel_ms = cold-ish solo launches (clock ramp and the CU-masked stream's "
+                                                           "hand-over included; the noisiest), the rocprofv3 1-slot trace of profiles/ = the same launches back to back "
+                                                           "(4-5 %% shorter), kernel_ms_streamed = inside the timed two-slot loop (tails of two passes overlap)" % len(solo),
                          "kernel_ms_streamed": fwd_streamed,
                          "snapshot_bytes_per_launch": snap,
                          "gcups": cells / (fwd * 1e-3) / 1e9},
@@ -432,11 +559,68 @@ def main():
                 out["extras"] = ex
             except Exception as exc:  # (never at the expense of the metric's line)
                 out["extras"] = {"error": repr(exc)[:200]}
+    # ---- the path from BAM record bytes (no host code looks at a record): every rank on its shard's file
+    rec = None
+    if do_e2e:
+        try:
+            rec = records_path_rate(ctx, bam_path, genome.names, cfg, e2e_written, barrier)
+        except Exception as exc:  # (never at the expense of the metric's line)
+            rec = {"error": repr(exc)[:300]}
+        tr = torch.tensor([max(rec["seconds"]) if "seconds" in rec else -1.0, min(rec["seconds"]) if "seconds" in rec else -1.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        if rank == 0 and "seconds" in rec and float(tr[0]) > 0:
+            out["value_from_records"] = e2e_written * world / float(tr[1] if world == 1 else tr[0])
+            out["value_from_records_is"] = (
+                "starts from BAM record bytes: the %d-read workload's inflated BAM payload (%d bytes per rank: what htslib's inflate hands to bam_read1), "
+                "pinned, in %d calls of <= 32 MB -> fadehip_bam_front_raw (H2D, record framing, packing of the batch arrays, the gate of anno.d:61-65 for "
+                "every record, score pass, pass 2, tag sizes) -> fadehip_bam_back under FADEHIP_BAM_NO_OUTPUT (the records rewritten with their tags, "
+                "left on the device; no codec); front and back on a thread each; nothing about a record is decided on the host (tools/synthgen's "
+                "sg_compact, which packs `value`'s blocks, is not involved); best of %d passes%s; all passes: %s s" % (
+                    e2e_written, rec["payload_bytes"], rec["calls"], len(rec["seconds"]), "" if world == 1 else " (slowest rank)",
+                    ", ".join("%.3f" % x for x in rec["seconds"])))
+            assert rec["stats"][0] == e2e_written
+        elif rank == 0:
+            out["value_from_records"] = None
+            out["value_from_records_is"] = rec.get("error")
     ctx.close()
+    # ---- end to end with N ranks: every rank runs `fade annotate -b` on ITS shard's file on ITS device, a share of the host
+    # threads each; first rank 0 alone (the others wait), then all together: what the node gives N processes at once
+    e2e_ranks = None
+    if do_e2e and world > 1:
+        fade = os.path.join(ROOT, "fade_amd", "fade")
+        thr = max(1, usable_cpus() // world)
+        env = {"FADE_DEVICE_MAP": str(local)}
+        alone = None
+        barrier()
+        if rank == 0:
+            alone = e2e_run(fade, bam_path, fa_path, e2e_written, cfg, thr, os.path.join(tmp, "bench_e2e%s.out.bam" % sfx), 2, env)
+        barrier()
+        mine = e2e_run(fade, bam_path, fa_path, e2e_written, cfg, thr, os.path.join(tmp, "bench_e2e%s.out.bam" % sfx), 1, env)
+        barrier()
+        secs = torch.tensor([mine.get("seconds", -1.0)], dtype=torch.float64, device=dev)
+        allsecs = [torch.zeros_like(secs) for _ in range(world)]
+        dist.all_gather(allsecs, secs)
+        per = [float(x[0]) for x in allsecs]
+        if rank == 0:
+            ok = all(x > 0 for x in per) and alone and alone.get("seconds")
+            agg = e2e_written * world / max(per) if ok else None
+            e2e_ranks = {"what": "`fade annotate -b` on every rank's own %d-read shard file (BASELINE config 4: sharded per GPU; what `fade annotate --gpus N "
+                                 "--out-shards` runs per lane), device = the rank's, %d host threads each; `alone`: rank 0 with the node to itself; `together`: all "
+                                 "%d ranks at once, aggregate = all reads / the slowest rank's wall time" % (e2e_written, thr, world),
+                         "alone_reads_per_s": alone.get("reads_per_s") if alone else None, "per_rank_seconds": per, "aggregate_reads_per_s": agg,
+                         "e2e_weak_scaling": (agg / (world * alone["reads_per_s"])) if ok else None, "alone": alone, "rank0_together": mine}
+        for pth in (bam_path, fa_path):
+            if os.path.exists(pth):
+                os.remove(pth)
     if rank == 0:
-        if do_e2e:
+        if do_e2e and world > 1:
+            out["e2e"] = e2e_ranks
+        elif do_e2e:
             try:
                 e = e2e_legs(bam_path, fa_path, e2e_written, cfg, usable_cpus(), tmp)
+                if do_big:
+                    e["big"] = e2e_legs(big_path, fa_path, big_reads, cfg, usable_cpus(), tmp, which=("gpu", "cpu"))
             except Exception as exc:  # (a missing binary, a full disk: never at the expense of the metric's line)
                 e = {"gpu": {"error": repr(exc)[:300]}}
             g, c = e.get("gpu") or {}, e.get("cpu") or {}
@@ -444,13 +628,22 @@ def main():
                                   "default: the file path on the device (record framing, annotate, tags, BGZF deflate as kernels; BGZF inflate on the host pool); "
                                   "gpu_device_inflate = FADE_BAM_INFLATE=device (inflate as a kernel too: only compressed bytes cross PCIe); gpu_host_pipeline = "
                                   "FADE_BAM_DEVICE=0 (records handled by the host pool, level-2 batches to the device, deflate on the device); "
-                                  "cpu = tools/cpu_annotate: the same reader / writer / codec around the CPU oracle" % (e2e_written, usable_cpus()),
+                                  "cpu = tools/cpu_annotate: the same reader / writer / codec around the CPU oracle — this build's own fast inflate / "
+                                  "deflate / CRC (several times zlib's speed), so a STRONGER comparator than reference FADE's htslib + zlib -6 would be.  "
+                                  "Every leg is the best of 2 runs" % (e2e_written, usable_cpus()),
                           "gpu_reads_per_s": g.get("reads_per_s"), "cpu_reads_per_s": c.get("reads_per_s"),
                           "gpu_over_cpu": (g["reads_per_s"] / c["reads_per_s"]) if g.get("reads_per_s") and c.get("reads_per_s") else None,
                           "gpu_device_inflate_reads_per_s": (e.get("gpu_device_inflate") or {}).get("reads_per_s"),
                           "gpu_host_pipeline_reads_per_s": (e.get("gpu_host_pipeline") or {}).get("reads_per_s"),
                           "gpu": g, "gpu_device_inflate": e.get("gpu_device_inflate"), "gpu_host_pipeline": e.get("gpu_host_pipeline"), "cpu": c}
-            for pth in (bam_path, fa_path):
+            if e.get("big"):
+                bg, bc = e["big"].get("gpu") or {}, e["big"].get("cpu") or {}
+                out["e2e"]["big"] = {"reads": big_reads, "what": "the same two legs (gpu default, cpu) on a %d-read file: the workload's batches %d times over under new read names"
+                                                                  % (big_reads, big_reps),
+                                     "gpu_reads_per_s": bg.get("reads_per_s"), "cpu_reads_per_s": bc.get("reads_per_s"),
+                                     "gpu_over_cpu": (bg["reads_per_s"] / bc["reads_per_s"]) if bg.get("reads_per_s") and bc.get("reads_per_s") else None,
+                                     "gpu": bg, "cpu": bc}
+            for pth in (bam_path, fa_path, big_path):
                 if os.path.exists(pth):
                     os.remove(pth)
         else:
@@ -459,6 +652,15 @@ def main():
             cb = cpu_baseline(genome, cfg, [b for b in full if b is not None])
             cb["gpu_over_cpu"] = out["value"] / cb["value"]
             out["cpu_baseline"] = cb
+            if do_e2e and os.path.exists(sample_path):
+                genome.write_fasta(fa_path)
+                cr = cpu_from_records(sample_path, fa_path, cfg, cb["cores"])
+                if cr.get("value") and out.get("value_from_records"):
+                    cr["gpu_over_cpu"] = out["value_from_records"] / cr["value"]
+                out["cpu_baseline_from_records"] = cr
+                for pth in (sample_path, fa_path):
+                    if os.path.exists(pth):
+                        os.remove(pth)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -157,7 +157,7 @@ struct fadehip_bam_config {
     int floor_len;               /// --min-length
     int window;                  /// -w
     int n_ref;                   /// contigs of the BAM header
-    int flags;                   /// 1 (FADEHIP_BAM_STORED): uncompressed BGZF out
+    int flags;                   /// 1 (FADEHIP_BAM_STORED): uncompressed BGZF out; 2 (FADEHIP_BAM_NO_OUTPUT): back makes no BGZF (measurement)
     const(char*)* ref_names;     /// [n_ref]
     uint first_record;           /// payload bytes of the first member passed that precede the first record
     uint tail_trim;              /// payload bytes at the end of the last member that belong to the next reader

@@ -282,10 +282,10 @@ class Context:
         self.bgzf_deflate_submit(lane, data)
         return self.bgzf_deflate_wait(lane)
 
-    def bam_stream(self, ref_names, floor_len=5, window=300, first_record=0, stored=False, tail_trim=0):
+    def bam_stream(self, ref_names, floor_len=5, window=300, first_record=0, stored=False, tail_trim=0, no_output=False):
         """The file path on the device (fadehip_bam_*): BGZF members of a BAM's records in, BGZF members of the annotated
         records out.  ref_names: the BAM header's contigs (the genome must be uploaded)."""
-        return BamStream(self, ref_names, floor_len, window, first_record, stored, tail_trim)
+        return BamStream(self, ref_names, floor_len, window, first_record, stored, tail_trim, no_output)
 
     def bgzf_inflate(self, members, out_cap=None):
         """Whole BGZF members (bytes / uint8 array) -> their payloads, inflated on the device (CRC32 and ISIZE checked)."""
@@ -419,11 +419,11 @@ def format_tags(batch, contig_names, rs, aln):
 
 
 class BamStream:
-    def __init__(self, ctx, ref_names, floor_len, window, first_record, stored=False, tail_trim=0):
+    def __init__(self, ctx, ref_names, floor_len, window, first_record, stored=False, tail_trim=0, no_output=False):
         self._ctx, self._L = ctx, ctx._L
         names = [n.encode() if isinstance(n, str) else bytes(n) for n in ref_names]
         arr = (C.c_char_p * max(len(names), 1))(*names)
-        cfg = _lib.BamConfig(floor_len, window, len(names), 1 if stored else 0, arr, first_record, tail_trim)
+        cfg = _lib.BamConfig(floor_len, window, len(names), (1 if stored else 0) | (2 if no_output else 0), arr, first_record, tail_trim)
         h = C.c_void_p()
         ctx._chk(self._L.fadehip_bam_open(ctx._h, C.byref(cfg), C.byref(h)))
         self._h = h
@@ -436,6 +436,10 @@ class BamStream:
     def front_raw(self, payload, last=False):
         arr = np.frombuffer(payload, dtype=np.uint8) if isinstance(payload, (bytes, bytearray, memoryview)) else np.ascontiguousarray(payload, dtype=np.uint8)
         self._ctx._chk(self._L.fadehip_bam_front_raw(self._h, arr.ctypes.data if arr.nbytes else None, arr.nbytes, 1 if last else 0))
+
+    def front_raw_ptr(self, ptr, nbytes, last=False):
+        """front_raw on memory the caller owns (pinned memory from fadehip_host_alloc: the H2D then runs at PCIe speed)."""
+        self._ctx._chk(self._L.fadehip_bam_front_raw(self._h, ptr, nbytes, 1 if last else 0))
 
     def back(self):
         p, n = C.c_void_p(), C.c_size_t(0)

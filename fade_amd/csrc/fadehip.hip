@@ -153,8 +153,10 @@ struct Slot {
 // run beside the kernels of the other.
 struct BgzfLane {
     hipStream_t stream = nullptr;
-    DevBuf src, slots, meta, member_off, packed;  // meta: out_size [n] | out_crc [n] | ticket | total (u64)
-    PinBuf out;
+    DevBuf src, slots, meta, member_off;  // meta: out_size [n] | out_crc [n] | ticket | total (u64)
+    PinBuf out;                   // the members, packed: the pack kernel writes them straight into pinned host memory
+    uint8_t *h_out = nullptr;     // where the submission in flight packs to (out.p, or a buffer of the caller: the file path's ring)
+    hipEvent_t done = nullptr;    // recorded behind the submission's last kernel
     uint64_t *h_total = nullptr;  // pinned
     size_t n_bytes = 0;
     uint32_t n_blocks = 0;
@@ -1307,7 +1309,8 @@ void fadehip_destroy(fadehip_ctx *ctx) {
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (BgzfLane &l : ctx->bgzf) {
-        for (DevBuf *b : {&l.src, &l.slots, &l.meta, &l.member_off, &l.packed}) release(*b);
+        for (DevBuf *b : {&l.src, &l.slots, &l.meta, &l.member_off}) release(*b);
+        if (l.done) (void)hipEventDestroy(l.done);
         release(l.out);
         if (l.h_total) (void)hipHostFree(l.h_total);
         if (l.stream && (&l == &ctx->bgzf[0] || l.stream != ctx->bgzf[0].stream)) (void)hipStreamDestroy(l.stream);
@@ -1786,6 +1789,7 @@ static int bgzf_lane_ready(fadehip_ctx *ctx, int lane, bool one_stream = false) 
         if (lane > 0 && (one_stream || getenv("FADEHIP_BGZF_ONE_STREAM")) && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
         else HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
+        HIPCHK(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
     }
     if (!ctx->bgzf_ready) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)bgzf64::bgzf_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bgzf64::LDS_BYTES));
@@ -1799,7 +1803,7 @@ static int bgzf_lane_ready(fadehip_ctx *ctx, int lane, bool one_stream = false) 
             fprintf(stderr, "[fadehip bgzf] compressor workgroups per CU: %d (0xff00-byte blocks, %d B of LDS), %d (0x7f00-byte blocks, %d B)\n", p64, bgzf64::LDS_BYTES, p32, bgzf32::LDS_BYTES);
         }
     }
-    if (l.state == 1) HIPCHK(ctx, hipStreamSynchronize(l.stream));  // never waited for: its buffers are still in use
+    if (l.state == 1) HIPCHK(ctx, hipEventSynchronize(l.done));  // never waited for: its buffers are still in use
     l.state = 0;
     return 0;
 }
@@ -1825,14 +1829,23 @@ static int bgzf_pick_geom_host(const fadehip_ctx *ctx, const uint8_t *p, size_t 
     }
     return seen && (double)eq < 0.15 * (double)seen ? 32 : 64;
 }
-static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t n_bytes, int geom) {
+// (host_out: pinned memory the members are packed into — the lane's own buffer when NULL.  A member is at most its block's
+// bytes + 5 (stored) + 26 of BGZF framing: the buffer is sized for that, the kernel writes through PCIe, and nothing but
+// the 8-byte total has to be copied afterwards.)
+static size_t bgzf_out_cap(size_t n_bytes, int geom) {
+    const size_t block = geom == 32 ? (size_t)bgzf32::BLOCK : (size_t)bgzf64::BLOCK;
+    return n_bytes + ((n_bytes + block - 1) / block) * 32 + 64;
+}
+static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t n_bytes, int geom, PinBuf *host_out = nullptr) {
     BgzfLane &l = ctx->bgzf[lane];
     const size_t block = geom == 32 ? (size_t)bgzf32::BLOCK : (size_t)bgzf64::BLOCK;
     const uint32_t nb = (uint32_t)((n_bytes + block - 1) / block);
     int rc;
+    PinBuf &ob = host_out ? *host_out : l.out;
     if ((rc = reserve(ctx, l.slots, (size_t)nb * bgzf64::SLOT)) || (rc = reserve(ctx, l.meta, (size_t)nb * 8 + 1024)) ||
-        (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) || (rc = reserve(ctx, l.packed, (size_t)nb * bgzf64::SLOT)))
+        (rc = reserve(ctx, l.member_off, (size_t)nb * 8)) || (rc = reserve_pinned(ctx, ob, bgzf_out_cap(n_bytes, geom))))
         return rc;
+    l.h_out = ob.p;
     uint32_t *d_size = (uint32_t *)l.meta.p, *d_crc = d_size + nb, *d_ticket = d_crc + nb;
     uint64_t *d_total = (uint64_t *)(((uintptr_t)(d_ticket + 2) + 7) & ~(uintptr_t)7);
     HIPCHK(ctx, hipMemsetAsync(d_ticket, 0, 8, l.stream));
@@ -1860,7 +1873,7 @@ static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t
         hipLaunchKernelGGL(bgzf32::bgzf_scan_kernel, dim3(1), dim3(1024), 0, l.stream, (const uint32_t *)d_size, nb, (uint64_t *)l.member_off.p, d_total);
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL(bgzf32::bgzf_pack_kernel, dim3(nb), dim3(256), 0, l.stream, (const uint8_t *)l.slots.p, (const uint32_t *)d_size,
-                           (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, (uint8_t *)l.packed.p);
+                           (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, l.h_out);
     } else {
         bgzf64::DeflateArgs a;
         fill(a);
@@ -1869,10 +1882,11 @@ static int bgzf_enqueue(fadehip_ctx *ctx, int lane, const uint8_t *d_src, size_t
         hipLaunchKernelGGL(bgzf64::bgzf_scan_kernel, dim3(1), dim3(1024), 0, l.stream, (const uint32_t *)d_size, nb, (uint64_t *)l.member_off.p, d_total);
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL(bgzf64::bgzf_pack_kernel, dim3(nb), dim3(256), 0, l.stream, (const uint8_t *)l.slots.p, (const uint32_t *)d_size,
-                           (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, (uint8_t *)l.packed.p);
+                           (const uint32_t *)d_crc, (const uint64_t *)l.member_off.p, (uint64_t)n_bytes, nb, l.h_out);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(l.h_total, d_total, 8, hipMemcpyDeviceToHost, l.stream));
+    HIPCHK(ctx, hipEventRecord(l.done, l.stream));
     l.n_bytes = n_bytes;
     l.n_blocks = nb;
     l.geom = geom;
@@ -1900,7 +1914,7 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
     BgzfLane &l = ctx->bgzf[lane];
     if (l.state != 1) return set_err(ctx, FADEHIP_E_STATE, "bgzf lane %d has nothing submitted", lane);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(l.stream));
+    HIPCHK(ctx, hipEventSynchronize(l.done));
     const uint64_t total = *l.h_total;
     l.state = 0;
     if (getenv("FADEHIP_BGZF_PROF")) {
@@ -1935,11 +1949,7 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
         return set_err(ctx, FADEHIP_E_STATE, "internal: bgzf members add up to %llu bytes (%u blocks timed out, first wait 0x%08x)", (unsigned long long)total, bad, why);
     }
     ctx->bgzf_last_ratio = (double)total / (double)std::max<size_t>(l.n_bytes, 1);
-    int rc = reserve_pinned(ctx, l.out, (size_t)total);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(l.out.p, l.packed.p, (size_t)total, hipMemcpyDeviceToHost, l.stream));
-    HIPCHK(ctx, hipStreamSynchronize(l.stream));
-    *out = l.out.p;
+    *out = l.h_out;  // (packed there by the kernel itself)
     *out_bytes = (size_t)total;
     return 0;
 }
@@ -1999,22 +2009,42 @@ struct fadehip_bam_stream {
     int32_t floor_len = 0, window = 0, n_ref = 0;
     uint32_t first_record = 0, tail_trim = 0;
     bool stored = false;  // uncompressed BGZF out
+    bool no_output = false;  // FADEHIP_BAM_NO_OUTPUT: back gives the call's device bytes back without making BGZF of them
     DevBuf names_text, names_off;
-    // front half (one call at a time)
-    DevBuf comp, blocks, status, ticket;
-    DevBuf u[2];                 // inflated bytes, ping-pong: the tail of one chunk is carried to the front of the next
-    uint32_t prev_len = 0, prev_consumed = 0;  // of u[(k - 1) & 1]
-    DevBuf seg, slots, rec_off, info, sent_of, art_of, out_size, blk32, blk64, counts;
-    PinBuf h_blocks, h_counts;
-    uint64_t k_front = 0, k_back = 0;
     struct Out {
         DevBuf o;
         size_t bytes = 0;
         hipEvent_t ready = nullptr;
-        int state = 0;  // 0 free, 1 waiting for back
+        int state = 0;  // 0 free, 1 its call's kernels are enqueued up to the tag sizes (to be finished), 2 finished: waiting for back
     } ring[FADEHIP_BAM_CHUNKS];
+    // The front half, two calls in flight.  Call k lives in set k & 1 and on the ctx's slot k & 1 (a stream each):
+    //   A  H2D (or H2D + inflate), carry-over of the previous call's cut-off record, framing, which records go to the gate
+    //      and their sizes -> the host waits (buffers are sized from what the device found)
+    //   B  packing, gate / score pass / pass 2, tag sizes                      -> enqueued, front returns
+    //   C  the host reads the sizes (the one other wait), the rewrite kernel   -> "finishing" the call: done by back when it
+    //      takes the call (or by front before the set is used again)
+    // so that A of call k + 1 runs on the device beside B and C of call k, and no stream idles while the host waits for
+    // another.  Order between calls: A(k + 1) needs where call k's last whole record ended (known once front(k) has waited for
+    // its A); everything else of two calls is independent.
+    struct Set {
+        DevBuf comp, blocks, status, ticket;  // members to inflate on the device
+        DevBuf u;                             // the call's inflated bytes, the previous call's cut-off record in front
+        DevBuf seg, slots, rec_off, info, sent_of, art_of, out_size, blk32, blk64, counts;
+        PinBuf h_blocks, h_counts;
+        uint64_t k = ~0ull;
+        uint32_t n_rec = 0, n_sent = 0, ntb = 0;
+        bool pending = false;  // B is enqueued, C is not
+        bam::TagArgs ta;
+        Out *out = nullptr;
+        double t_b = 0;
+    } set[2];
+    uint32_t prev_len = 0, prev_consumed = 0;  // of the previous call's u
+    uint64_t k_front = 0, k_back = 0;
+    uint64_t k_sub = 0;                     // calls handed to the compressor (back may run one ahead of the call it returns)
+    PinBuf outbuf[FADEHIP_BAM_CHUNKS];      // the members of call k, packed by the kernel itself: pinned, k % FADEHIP_BAM_CHUNKS
     std::mutex mu;
     std::condition_variable cv;
+    std::mutex pipe_mu;  // finishing a call (front and back may both come to do it)
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_records = 0, n_oversize = 0, n_redone = 0;
     bool failed = false, ended = false, closing = false;
@@ -2032,18 +2062,69 @@ int bam_fail(fadehip_bam_stream *st, int rc) {
     return rc;
 }
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// C of call k (see fadehip_bam_stream): waits for the call's run and tag sizes, sizes the output, enqueues the rewrite.
+// Idempotent; front and back may both arrive here for the same call.
+int bam_finish_call(fadehip_bam_stream *st, uint64_t k) {
+    std::lock_guard<std::mutex> pl(st->pipe_mu);
+    fadehip_ctx *ctx = st->ctx;
+    fadehip_bam_stream::Set &S = st->set[k & 1];
+    if (S.k != k || !S.pending) return 0;
+    Slot &s = ctx->slots[k & 1];
+    hipStream_t q = s.stream;
+    fadehip_bam_stream::Out *out = S.out;
+    const double t0 = now_s();
+    int rc;
+    out->bytes = 0;
+    if (S.n_rec) {
+        bam::ChunkCounts *h_counts = (bam::ChunkCounts *)S.h_counts.p;
+        if (S.n_sent) {
+            if ((rc = finish_run(ctx, s, (int)(k & 1)))) return rc;  // waits for the stream: run and sizes
+            std::lock_guard<std::mutex> l(st->mu);
+            for (int t = 0; t < 8; t++) st->stats[t] += s.stats[t];
+            st->n_oversize += s.n_oversize;
+        } else {
+            HIPCHK(ctx, hipStreamSynchronize(q));
+            std::lock_guard<std::mutex> l(st->mu);
+            st->stats[0] += S.n_rec;
+        }
+        const uint64_t out_bytes = h_counts->out_bytes;
+        if (out_bytes > ((uint64_t)1 << 31)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu output bytes in one call (at most 2^31)", (unsigned long long)out_bytes);
+        if ((rc = reserve_roomy(ctx, out->o, (size_t)out_bytes + 256))) return rc;
+        S.ta.o = (uint8_t *)out->o.p;
+        hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(S.ntb), dim3(bam::REWRITE_WAVES * 64), 0, q, S.ta);
+        HIPCHK(ctx, hipGetLastError());
+        out->bytes = (size_t)out_bytes;
+        std::lock_guard<std::mutex> l(st->mu);
+        st->n_records += S.n_rec;
+    }
+    if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(out->ready, q));
+    S.pending = false;
+    st->t_tags += now_s() - t0;
+    {
+        std::lock_guard<std::mutex> l(st->mu);
+        out->state = 2;
+    }
+    st->cv.notify_all();
+    return 0;
+}
+
 int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_bytes, int last, bool raw) {
     fadehip_ctx *ctx = st->ctx;
-    Slot &s = ctx->slots[0];
+    const uint64_t k = st->k_front;
+    fadehip_bam_stream::Set &S = st->set[k & 1];
+    Slot &s = ctx->slots[k & 1];
     int rc;
-    // every stream is an HSA queue to set up and to give back (tens of ms each): a slot that has none yet works on the
-    // ctx's copy stream, which exists anyway and which the file path does not use otherwise
-    if (!s.stream && !s.h_zb && ctx->copy_stream) s.stream = ctx->copy_stream;
+    // the set's previous call must have been finished (back has usually done that long ago)
+    if (k >= 2 && (rc = bam_finish_call(st, k - 2))) return rc;
+    // every stream is an HSA queue to set up and to give back (tens of ms each): slot 0 works on the ctx's copy stream, which
+    // exists anyway and which the file path does not use otherwise; slot 1 gets a stream of its own when the second call comes
+    if (!s.stream && !s.h_zb && (k & 1) == 0 && ctx->copy_stream) s.stream = ctx->copy_stream;
     if ((rc = ensure_slot(ctx, s))) return rc;
     hipStream_t q = s.stream;
-    const uint64_t k = st->k_front;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
+    const double t0 = now_s();
     // ---- the members, and where their payloads go
     std::vector<bgzf::InflateBlock> blocks;
     size_t consumed = 0;
@@ -2062,43 +2143,44 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         if ((uint64_t)st->tail_trim > total) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: tail_trim %u exceeds the last call's %llu bytes", st->tail_trim, (unsigned long long)total);
         u_len -= st->tail_trim;
     }
-    DevBuf &ub = st->u[k & 1];
     // (sized from the UNTRIMMED length: the inflate kernel writes the last member's whole ISIZE, tail_trim only shortens
     // what the framing looks at)
-    if ((rc = reserve_roomy(ctx, ub, (size_t)carry + (size_t)total + 256))) return rc;
-    uint8_t *u = (uint8_t *)ub.p;
-    if (carry) HIPCHK(ctx, hipMemcpyAsync(u, (const uint8_t *)st->u[(k + 1) & 1].p + st->prev_consumed, carry, hipMemcpyDeviceToDevice, q));
+    if ((rc = reserve_roomy(ctx, S.u, (size_t)carry + (size_t)total + 256))) return rc;
+    uint8_t *u = (uint8_t *)S.u.p;
+    // the cut-off record of the previous call: its bytes are final (front waited for that call's framing), and the rewrite
+    // that also reads them does not change them
+    if (carry) HIPCHK(ctx, hipMemcpyAsync(u, (const uint8_t *)st->set[(k + 1) & 1].u.p + st->prev_consumed, carry, hipMemcpyDeviceToDevice, q));
     const uint32_t nb = (uint32_t)blocks.size();
     if (raw && n_bytes) HIPCHK(ctx, hipMemcpyAsync(u + carry, members, n_bytes, hipMemcpyHostToDevice, q));
     if (nb) {
         for (auto &b : blocks) b.dst_off += carry;
-        if ((rc = reserve_roomy(ctx, st->comp, n_bytes + 16)) || (rc = reserve_roomy(ctx, st->blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
-            (rc = reserve_roomy(ctx, st->status, 4 * (size_t)nb)) || (rc = reserve_roomy(ctx, st->ticket, 64)) ||
-            (rc = reserve_pinned(ctx, st->h_blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)))
+        if ((rc = reserve_roomy(ctx, S.comp, n_bytes + 16)) || (rc = reserve_roomy(ctx, S.blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
+            (rc = reserve_roomy(ctx, S.status, 4 * (size_t)nb)) || (rc = reserve_roomy(ctx, S.ticket, 64)) ||
+            (rc = reserve_pinned(ctx, S.h_blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)))
             return rc;
-        memcpy(st->h_blocks.p, blocks.data(), sizeof(bgzf::InflateBlock) * (size_t)nb);
-        HIPCHK(ctx, hipMemcpyAsync(st->comp.p, members, n_bytes, hipMemcpyHostToDevice, q));
-        HIPCHK(ctx, hipMemcpyAsync(st->blocks.p, st->h_blocks.p, sizeof(bgzf::InflateBlock) * (size_t)nb, hipMemcpyHostToDevice, q));
+        memcpy(S.h_blocks.p, blocks.data(), sizeof(bgzf::InflateBlock) * (size_t)nb);
+        HIPCHK(ctx, hipMemcpyAsync(S.comp.p, members, n_bytes, hipMemcpyHostToDevice, q));
+        HIPCHK(ctx, hipMemcpyAsync(S.blocks.p, S.h_blocks.p, sizeof(bgzf::InflateBlock) * (size_t)nb, hipMemcpyHostToDevice, q));
         bgzf::InflateArgs ia;
-        ia.comp = (const uint8_t *)st->comp.p;
-        ia.blocks = (const bgzf::InflateBlock *)st->blocks.p;
+        ia.comp = (const uint8_t *)S.comp.p;
+        ia.blocks = (const bgzf::InflateBlock *)S.blocks.p;
         ia.n_blocks = nb;
         ia.out = u;
         ia.out_shift = nullptr;
-        ia.status = (uint32_t *)st->status.p;
-        ia.ticket = (uint32_t *)st->ticket.p;
+        ia.status = (uint32_t *)S.status.p;
+        ia.ticket = (uint32_t *)S.ticket.p;
         ia.check_crc = 1;
         if ((rc = launch_inflate(ctx, q, ia))) return rc;
     }
     // ---- framing
     const uint32_t n_seg = (u_len + bam::SEG - 1) / bam::SEG;
     const uint32_t rec_cap = u_len / 36u + 2u;
-    if ((rc = reserve_roomy(ctx, st->seg, 16 * (size_t)std::max(n_seg, 1u))) || (rc = reserve_roomy(ctx, st->slots, 4 * (size_t)bam::SEG_SLOTS * std::max(n_seg, 1u))) ||
-        (rc = reserve_roomy(ctx, st->rec_off, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, st->counts, sizeof(bam::ChunkCounts))) ||
-        (rc = reserve_pinned(ctx, st->h_counts, sizeof(bam::ChunkCounts) + 16)))
+    if ((rc = reserve_roomy(ctx, S.seg, 16 * (size_t)std::max(n_seg, 1u))) || (rc = reserve_roomy(ctx, S.slots, 4 * (size_t)bam::SEG_SLOTS * std::max(n_seg, 1u))) ||
+        (rc = reserve_roomy(ctx, S.rec_off, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, S.counts, sizeof(bam::ChunkCounts))) ||
+        (rc = reserve_pinned(ctx, S.h_counts, sizeof(bam::ChunkCounts) + 16)))
         return rc;
-    bam::ChunkCounts *d_counts = (bam::ChunkCounts *)st->counts.p;
-    bam::ChunkCounts *h_counts = (bam::ChunkCounts *)st->h_counts.p;
+    bam::ChunkCounts *d_counts = (bam::ChunkCounts *)S.counts.p;
+    bam::ChunkCounts *h_counts = (bam::ChunkCounts *)S.h_counts.p;
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, sizeof(bam::ChunkCounts), q));
     HIPCHK(ctx, hipMemsetAsync(&d_counts->l_seq_min, 0xff, 4, q));
     bam::FrameArgs fa;
@@ -2107,12 +2189,12 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     fa.first = k == 0 ? st->first_record : 0u;
     fa.n_ref = st->n_ref;
     fa.n_seg_cap = n_seg;
-    fa.cand = (uint32_t *)st->seg.p;
+    fa.cand = (uint32_t *)S.seg.p;
     fa.exit_ = fa.cand + std::max(n_seg, 1u);
     fa.cnt = fa.exit_ + std::max(n_seg, 1u);
     fa.base = fa.cnt + std::max(n_seg, 1u);
-    fa.slots = (uint32_t *)st->slots.p;
-    fa.rec_off = (uint32_t *)st->rec_off.p;
+    fa.slots = (uint32_t *)S.slots.p;
+    fa.rec_off = (uint32_t *)S.rec_off.p;
     fa.rec_cap = rec_cap;
     fa.counts = d_counts;
     if (n_seg) {
@@ -2126,8 +2208,8 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     // which records go to the device's gate, their sizes: enqueued behind the framing for as many records as the bytes could
     // hold at most (threads beyond the records that are there return at once), so that ONE wait brings back both counts
     const uint32_t nblk_cap = (rec_cap + bam::PACK_BLOCK - 1) / bam::PACK_BLOCK;
-    if ((rc = reserve_roomy(ctx, st->info, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, st->sent_of, 4 * (size_t)rec_cap)) ||
-        (rc = reserve_roomy(ctx, st->out_size, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, st->blk32, 24 * (size_t)nblk_cap)))
+    if ((rc = reserve_roomy(ctx, S.info, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, S.sent_of, 4 * (size_t)rec_cap)) ||
+        (rc = reserve_roomy(ctx, S.out_size, 4 * (size_t)rec_cap)) || (rc = reserve_roomy(ctx, S.blk32, 24 * (size_t)nblk_cap)))
         return rc;
     bam::PackArgs pa;
     memset(&pa, 0, sizeof pa);
@@ -2136,27 +2218,27 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     pa.counts_in = d_counts;
     pa.r0 = 0;
     pa.r1_cap = rec_cap;
-    pa.info = (uint32_t *)st->info.p;
-    pa.blk_sums = (uint32_t *)st->blk32.p;
+    pa.info = (uint32_t *)S.info.p;
+    pa.blk_sums = (uint32_t *)S.blk32.p;
     pa.blk_base = pa.blk_sums + 3 * (size_t)nblk_cap;
     pa.counts = d_counts;
-    pa.sent_of = (int32_t *)st->sent_of.p;
+    pa.sent_of = (int32_t *)S.sent_of.p;
     hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(nblk_cap), dim3(bam::PACK_BLOCK), 0, q, pa);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk_cap);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
-    uint32_t *h_tick = (uint32_t *)(st->h_counts.p + sizeof(bam::ChunkCounts));
+    uint32_t *h_tick = (uint32_t *)(S.h_counts.p + sizeof(bam::ChunkCounts));
     h_tick[0] = h_tick[1] = 0;
-    if (nb) HIPCHK(ctx, hipMemcpyAsync(h_tick, st->ticket.p, 8, hipMemcpyDeviceToHost, q));
-    const double t1 = now();
+    if (nb) HIPCHK(ctx, hipMemcpyAsync(h_tick, S.ticket.p, 8, hipMemcpyDeviceToHost, q));
+    const double t1 = now_s();
     HIPCHK(ctx, hipStreamSynchronize(q));  // (1) the records of this call and the sizes of their batch
-    const double t2 = now();
+    const double t2 = now_s();
     st->t_inflate += t1 - t0;
     st->t_frame += t2 - t1;
     if (nb && h_tick[1]) {
         std::vector<uint32_t> stt(nb);
-        HIPCHK(ctx, hipMemcpy(stt.data(), st->status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(stt.data(), S.status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
         for (uint32_t b = 0; b < nb; b++)
             if (stt[b]) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu, member %u of %u: %s (%u members failed)", (unsigned long long)k, b, nb, inflate_error_name(stt[b]), h_tick[1]);
     }
@@ -2177,10 +2259,14 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         if (st->failed || st->closing) return set_err(ctx, FADEHIP_E_STATE, "bam stream: stopped");
     }
     out->bytes = 0;
+    S.k = k;
+    S.n_rec = n_rec;
+    S.n_sent = 0;
+    S.ntb = 0;
+    S.out = out;
     if (n_rec) {
         const uint32_t nblk = (n_rec + bam::PACK_BLOCK - 1) / bam::PACK_BLOCK, ntb = (n_rec + bam::TAG_BLOCK - 1) / bam::TAG_BLOCK;
-        if ((rc = reserve_roomy(ctx, st->blk64, 16 * (size_t)ntb))) return rc;
-        const double t4 = t2;
+        if ((rc = reserve_roomy(ctx, S.blk64, 16 * (size_t)ntb))) return rc;
         if (h_counts->n_bad_layout)
             return set_err(ctx, FADEHIP_E_INVALID, "bam stream: call %llu: %u records whose fields do not fit their block_size or whose tags are not whole fields (corrupt BAM)", (unsigned long long)k, h_counts->n_bad_layout);
         const uint32_t n_sent = h_counts->n_sent;
@@ -2233,16 +2319,16 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
             s.state = 2;
         }
         // ---- what anno.d:94-107 adds: sizes, offsets
-        if ((rc = reserve_roomy(ctx, st->art_of, 4 * (size_t)std::max(n_sent, 1u)))) return rc;
+        if ((rc = reserve_roomy(ctx, S.art_of, 4 * (size_t)std::max(n_sent, 1u)))) return rc;
         if (n_sent) {
-            HIPCHK(ctx, hipMemsetAsync(st->art_of.p, 0xff, 4 * (size_t)n_sent, q));
+            HIPCHK(ctx, hipMemsetAsync(S.art_of.p, 0xff, 4 * (size_t)n_sent, q));
             if (s.out_cap) {
                 hipLaunchKernelGGL(bam::bam_art_index_kernel, dim3((s.out_cap + 255) / 256), dim3(256), 0, q, (const fadehip_aln *)s.aln.p,
-                                   (const uint32_t *)(s.d_counters() + 2 * NUM_LISTS + 3), s.out_cap, (int32_t *)st->art_of.p, n_sent);
+                                   (const uint32_t *)(s.d_counters() + 2 * NUM_LISTS + 3), s.out_cap, (int32_t *)S.art_of.p, n_sent);
                 HIPCHK(ctx, hipGetLastError());
             }
         }
-        bam::TagArgs ta;
+        bam::TagArgs &ta = S.ta;
         memset(&ta, 0, sizeof ta);
         ta.u = u;
         ta.rec_off = fa.rec_off;
@@ -2253,12 +2339,12 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         ta.sent_of = pa.sent_of;
         ta.rs = (const uint8_t *)s.rs.p;
         ta.aln = (const fadehip_aln *)s.aln.p;
-        ta.art_of = (const int32_t *)st->art_of.p;
+        ta.art_of = (const int32_t *)S.art_of.p;
         ta.names.text = (const char *)st->names_text.p;
         ta.names.off = (const uint32_t *)st->names_off.p;
         ta.names.n = st->n_ref;
-        ta.out_size = (uint32_t *)st->out_size.p;
-        ta.blk_sums = (uint64_t *)st->blk64.p;
+        ta.out_size = (uint32_t *)S.out_size.p;
+        ta.blk_sums = (uint64_t *)S.blk64.p;
         ta.blk_base = ta.blk_sums + ntb;
         ta.counts = d_counts;
         ta.out_base = 0;
@@ -2267,34 +2353,13 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         hipLaunchKernelGGL(bam::bam_tag_scan_kernel, dim3(1), dim3(1024), 0, q, ta, ntb);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
-        if (n_sent) {
-            if ((rc = finish_run(ctx, s, 0))) return rc;  // (2) waits for the stream: run and sizes
-            std::lock_guard<std::mutex> l(st->mu);
-            for (int t = 0; t < 8; t++) st->stats[t] += s.stats[t];
-            st->n_oversize += s.n_oversize;
-        } else {
-            HIPCHK(ctx, hipStreamSynchronize(q));
-            std::lock_guard<std::mutex> l(st->mu);
-            st->stats[0] += n_rec;
-        }
-        st->t_run += now() - t4;
-        const uint64_t out_bytes = h_counts->out_bytes;
-        if (out_bytes > ((uint64_t)1 << 31)) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: %llu output bytes in one call (at most 2^31)", (unsigned long long)out_bytes);
-        if ((rc = reserve_roomy(ctx, out->o, (size_t)out_bytes + 256))) return rc;
-        ta.o = (uint8_t *)out->o.p;
-        hipLaunchKernelGGL(bam::bam_rewrite_kernel, dim3(ntb), dim3(bam::REWRITE_WAVES * 64), 0, q, ta);
-        HIPCHK(ctx, hipGetLastError());
-        out->bytes = (size_t)out_bytes;
-        {
-            std::lock_guard<std::mutex> l(st->mu);
-            st->n_records += n_rec;
-        }
-        st->t_tags += now() - t4;
+        S.n_sent = n_sent;
+        S.ntb = ntb;
     }
-    if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventRecord(out->ready, q));
-    // the inflated bytes of this call are read by the next call's carry copy and by nothing else once the rewrite is done:
-    // both are on this stream, in order.
+    S.pending = true;
+    st->t_run += now_s() - t2;
+    // the inflated bytes of this call are read by the next call's carry copy and by this call's rewrite, which change nothing;
+    // the set's buffers are written again by call k + 2, whose front finishes this call first.
     {
         std::lock_guard<std::mutex> l(st->mu);
         out->state = 1;
@@ -2309,7 +2374,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
 
 int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out) {
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
-    if (!cfg || !out || cfg->n_ref < 0 || (cfg->n_ref && !cfg->ref_names) || cfg->window < 0 || (cfg->flags & ~FADEHIP_BAM_STORED))
+    if (!cfg || !out || cfg->n_ref < 0 || (cfg->n_ref && !cfg->ref_names) || cfg->window < 0 || (cfg->flags & ~(FADEHIP_BAM_STORED | FADEHIP_BAM_NO_OUTPUT)))
         return set_err(ctx, FADEHIP_E_INVALID, "bam stream: bad configuration");
     if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
     if (!ctx->two_pass) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: needs the default kernels (FADEHIP_KERNEL unset)");
@@ -2323,6 +2388,7 @@ int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_ba
     st->first_record = cfg->first_record;
     st->tail_trim = cfg->tail_trim;
     st->stored = (cfg->flags & FADEHIP_BAM_STORED) != 0;
+    st->no_output = (cfg->flags & FADEHIP_BAM_NO_OUTPUT) != 0;
     std::string text;
     std::vector<uint32_t> off((size_t)cfg->n_ref + 1, 0);
     for (int k = 0; k < cfg->n_ref; k++) {
@@ -2353,7 +2419,8 @@ int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_byte
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int rc = bam_front_impl(st, (const uint8_t *)members, n_bytes, last, false);
     if (rc) {
-        (void)hipStreamSynchronize(ctx->slots[0].stream);
+        for (int q = 0; q < 2; q++)
+            if (ctx->slots[q].stream) (void)hipStreamSynchronize(ctx->slots[q].stream);
         return bam_fail(st, rc);
     }
     return 0;
@@ -2368,10 +2435,44 @@ int fadehip_bam_front_raw(fadehip_bam_stream *st, const void *payload, size_t n_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int rc = bam_front_impl(st, (const uint8_t *)payload, n_bytes, last, true);
     if (rc) {
-        (void)hipStreamSynchronize(ctx->slots[0].stream);
+        for (int q = 0; q < 2; q++)
+            if (ctx->slots[q].stream) (void)hipStreamSynchronize(ctx->slots[q].stream);
         return bam_fail(st, rc);
     }
     return 0;
+}
+
+// the back half's first step for call k: the call is finished (sizes read, rewrite enqueued) and its bytes go to the
+// compressor on lane k & 1, the members packed into the stream's pinned buffer k % FADEHIP_BAM_CHUNKS
+static int bam_submit_back(fadehip_bam_stream *st, uint64_t k) {
+    fadehip_ctx *ctx = st->ctx;
+    fadehip_bam_stream::Out *o = &st->ring[k % FADEHIP_BAM_CHUNKS];
+    int rc;
+    if ((rc = bam_finish_call(st, k))) return rc;
+    st->k_sub = k + 1;
+    if (!o->bytes || st->no_output) return 0;
+    const int lane = (int)(k & 1);
+    // (FADEHIP_BAM_BACK_STREAMS=1: both lanes on one stream — one HSA queue fewer, but call k's members then cross PCIe
+    // before call k + 1's compressor starts instead of beside it)
+    static const bool one_stream = getenv("FADEHIP_BAM_BACK_STREAMS") && atoi(getenv("FADEHIP_BAM_BACK_STREAMS")) == 1;
+    if ((rc = bgzf_lane_ready(ctx, lane, one_stream))) return rc;
+    BgzfLane &l = ctx->bgzf[lane];
+    if (hipStreamWaitEvent(l.stream, o->ready, 0) != hipSuccess) return set_err(ctx, FADEHIP_E_HIP, "bam stream: hipStreamWaitEvent failed");
+    PinBuf &ob = st->outbuf[k % FADEHIP_BAM_CHUNKS];
+    if (st->stored) {
+        // uncompressed BGZF: the members' sizes are known here; the kernel stores them straight into the pinned buffer
+        const uint32_t nb = (uint32_t)((o->bytes + bgzf::STORE_BLOCK - 1) / bgzf::STORE_BLOCK);
+        const size_t total = o->bytes + (size_t)nb * (bgzf::STORE_MEMBER - bgzf::STORE_BLOCK);
+        if ((rc = reserve_pinned(ctx, ob, (size_t)nb * bgzf::STORE_MEMBER))) return rc;
+        hipLaunchKernelGGL(bgzf::bgzf_store_kernel, dim3(nb), dim3(bgzf::STORE_WG), 0, l.stream, (const uint8_t *)o->o.p, (uint64_t)o->bytes, nb, ob.p);
+        if (hipGetLastError() != hipSuccess || hipEventRecord(l.done, l.stream) != hipSuccess) return set_err(ctx, FADEHIP_E_HIP, "bam stream: storing the members failed");
+        l.h_out = ob.p;
+        *l.h_total = total;
+        l.n_bytes = o->bytes;
+        l.state = 1;
+        return 0;
+    }
+    return bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes, bgzf_pick_geom(ctx), &ob);
 }
 
 int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_bytes) {
@@ -2380,32 +2481,38 @@ int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_by
     if (!out || !out_bytes) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
     *out = nullptr;
     *out_bytes = 0;
-    fadehip_bam_stream::Out *o;
+    const uint64_t k = st->k_back;
+    fadehip_bam_stream::Out *o = &st->ring[k % FADEHIP_BAM_CHUNKS];
+    bool next_waiting = false;
     {
         std::unique_lock<std::mutex> l(st->mu);
-        o = &st->ring[st->k_back % FADEHIP_BAM_CHUNKS];
-        if (o->state != 1) return set_err(ctx, FADEHIP_E_STATE, st->failed ? "bam stream: an earlier call failed" : "bam stream: no front call is waiting for back");
+        if ((o->state == 0 && st->k_sub <= k) || st->failed) return set_err(ctx, FADEHIP_E_STATE, st->failed ? "bam stream: an earlier call failed" : "bam stream: no front call is waiting for back");
+        next_waiting = st->k_front > k + 1 && st->ring[(k + 1) % FADEHIP_BAM_CHUNKS].state != 0;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = 0;
-    if (o->bytes) {
-        const int lane = (int)(st->k_back & 1);  // the lanes in turn: a call's bytes stay valid during the next call
-        if ((rc = bgzf_lane_ready(ctx, lane, true))) return bam_fail(st, rc);
+    // the call's last step (sizes read, rewrite enqueued) is taken here, beside the front half's work on the next call
+    if (st->k_sub <= k && (rc = bam_submit_back(st, k))) return bam_fail(st, rc);
+    // The call after this one, if its front half is through on the device: its compressor is enqueued now, so that it
+    // starts the moment this call's has left the CUs — while this call's members cross PCIe and the caller gets them.
+    if (next_waiting && st->k_sub == k + 1) {
+        bool through;
+        {
+            std::lock_guard<std::mutex> pl(st->pipe_mu);
+            fadehip_bam_stream::Set &S = st->set[(k + 1) & 1];
+            through = S.k != k + 1 || !S.pending || hipStreamQuery(ctx->slots[(k + 1) & 1].stream) == hipSuccess;
+        }
+        if (through && (rc = bam_submit_back(st, k + 1))) return bam_fail(st, rc);
+    }
+    if (o->bytes && !st->no_output) {
+        const int lane = (int)(k & 1);
         BgzfLane &l = ctx->bgzf[lane];
-        if (hipStreamWaitEvent(l.stream, o->ready, 0) != hipSuccess) return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: hipStreamWaitEvent failed"));
         if (st->stored) {
-            // uncompressed BGZF: the members' sizes are known here, nothing has to come back before the copy
-            const uint32_t nb = (uint32_t)((o->bytes + bgzf::STORE_BLOCK - 1) / bgzf::STORE_BLOCK);
-            const size_t total = o->bytes + (size_t)nb * (bgzf::STORE_MEMBER - bgzf::STORE_BLOCK);
-            if ((rc = reserve_roomy(ctx, l.packed, (size_t)nb * bgzf::STORE_MEMBER)) || (rc = reserve_pinned(ctx, l.out, total))) return bam_fail(st, rc);
-            hipLaunchKernelGGL(bgzf::bgzf_store_kernel, dim3(nb), dim3(bgzf::STORE_WG), 0, l.stream, (const uint8_t *)o->o.p, (uint64_t)o->bytes, nb, (uint8_t *)l.packed.p);
-            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(l.out.p, l.packed.p, total, hipMemcpyDeviceToHost, l.stream) != hipSuccess ||
-                hipStreamSynchronize(l.stream) != hipSuccess)
-                return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: storing the members failed"));
-            *out = l.out.p;
-            *out_bytes = total;
-        } else
-        if ((rc = bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes, bgzf_pick_geom(ctx))) || (rc = fadehip_bgzf_deflate_wait(ctx, lane, out, out_bytes))) return bam_fail(st, rc);
+            if (hipEventSynchronize(l.done) != hipSuccess) return bam_fail(st, set_err(ctx, FADEHIP_E_HIP, "bam stream: storing the members failed"));
+            l.state = 0;
+            *out = l.h_out;
+            *out_bytes = (size_t)*l.h_total;
+        } else if ((rc = fadehip_bgzf_deflate_wait(ctx, lane, out, out_bytes))) return bam_fail(st, rc);
     } else if (o->ready) {
         (void)hipEventSynchronize(o->ready);
     }
@@ -2436,20 +2543,28 @@ void fadehip_bam_close(fadehip_bam_stream *st) {
     st->cv.notify_all();
     fadehip_ctx *ctx = st->ctx;
     if (getenv("FADEHIP_BAM_PROF"))
-        fprintf(stderr, "[fadehip bam] %llu front calls: enqueue copy / inflate + frame + pack count %.3f s, wait (1) %.3f | enqueue pack + run + sizes, wait (2) %.3f, "
-                        "front after (1) in all %.3f | segments walked again %lld\n", (unsigned long long)st->k_front, st->t_inflate, st->t_frame, st->t_run, st->t_tags,
+        fprintf(stderr, "[fadehip bam] %llu front calls: A enqueue (copy / inflate, frame, pack count) %.3f s, wait for A %.3f | B enqueue (pack, run, tag sizes) %.3f | "
+                        "C (wait for B, rewrite enqueued; taken by back or front) %.3f | segments walked again %lld\n", (unsigned long long)st->k_front, st->t_inflate, st->t_frame, st->t_run, st->t_tags,
                 (long long)st->n_redone);
     (void)hipSetDevice(ctx->device);
-    if (ctx->slots[0].stream) (void)hipStreamSynchronize(ctx->slots[0].stream);
+    for (int q = 0; q < 2; q++) {
+        if (ctx->slots[q].stream) (void)hipStreamSynchronize(ctx->slots[q].stream);
+        ctx->slots[q].device_only = false;
+        ctx->slots[q].wide_all = false;
+        if (ctx->slots[q].state == 2) ctx->slots[q].state = 0;  // (a call that was never finished: nothing of it is handed out)
+    }
     for (BgzfLane &l : ctx->bgzf)
         if (l.stream) (void)hipStreamSynchronize(l.stream);
-    ctx->slots[0].device_only = false;
-    ctx->slots[0].wide_all = false;
-    for (DevBuf *b : {&st->names_text, &st->names_off, &st->comp, &st->blocks, &st->status, &st->ticket, &st->u[0], &st->u[1], &st->seg, &st->slots,
-                      &st->rec_off, &st->info, &st->sent_of, &st->art_of, &st->out_size, &st->blk32, &st->blk64, &st->counts})
-        release(*b);
-    release(st->h_blocks);
-    release(st->h_counts);
+    release(st->names_text);
+    release(st->names_off);
+    for (auto &S : st->set) {
+        for (DevBuf *b : {&S.comp, &S.blocks, &S.status, &S.ticket, &S.u, &S.seg, &S.slots, &S.rec_off, &S.info, &S.sent_of, &S.art_of, &S.out_size, &S.blk32,
+                          &S.blk64, &S.counts})
+            release(*b);
+        release(S.h_blocks);
+        release(S.h_counts);
+    }
+    for (auto &ob : st->outbuf) release(ob);
     for (auto &o : st->ring) {
         release(o.o);
         if (o.ready) (void)hipEventDestroy(o.ready);

@@ -71,9 +71,11 @@ typedef struct {
     int32_t ext;       /* 2 : cost of each further gap base */
     int32_t match;     /* 2 */
     int32_t mismatch;  /* -3 */
-    int32_t max_ref_len;   /* longest reference window re-aligned; 0 -> 2^20, which is also the most.  Windows of up to 8000
-                              bases take the wave kernels, longer ones the thread-per-alignment kernel (slow path); a read
-                              whose window is longer still is left un-re-aligned and counted in n_oversize */
+    int32_t max_ref_len;   /* longest reference window re-aligned; 0 -> 2^20, which is also the most.  Windows of up to 32,000
+                              columns take the 16-lane wave kernels (8 alignments per wavefront; the window streams through LDS in
+                              chunks), up to 65,000 — and reads of 513 .. 4,096 bases — the one-alignment-per-wavefront kernel,
+                              beyond that the thread-per-alignment kernel (slow path); a read whose window is longer than
+                              max_ref_len is left un-re-aligned and counted in n_oversize */
     int32_t max_batch_reads; /* capacity of one annotate batch; 0 -> 1<<20 */
     int64_t trace_bytes;   /* device bytes reserved for trace tables / checkpoints; 0 -> sized on demand */
     int32_t trace_all;     /* 1: level 2 returns a CIGAR for every re-aligned read (default: only for reads whose
@@ -241,7 +243,8 @@ int fadehip_sync(fadehip_ctx *ctx);
  * device.  counts[0] alignments, counts[1] DP cells, counts[2] trace scratch bytes of the largest pass-2 plan,
  * counts[3] algorithmic bytes of the dominant kernel as SURVEY.md §8(d) defines them (packed query + packed window +
  * 16 B descriptor + 64 B result slot per alignment), counts[4] bytes of wave snapshots the score pass leaves for
- * pass 2 (int16 H and E-hat per query row every 32 sweep steps), counts[5] candidates traced by pass 2. */
+ * pass 2 (the wave's loop-carried state every 128 sweep steps; written only when the slot's previous run sent more than
+ * 1/32 of its alignments to pass 2 — 0 otherwise), counts[5] candidates traced by pass 2. */
 int fadehip_last_run_profile(fadehip_ctx *ctx, int slot, float ms[4], int64_t counts[6]);
 
 /* ------------------------------------------------------ BGZF compression of the output stream -- */
@@ -284,23 +287,33 @@ int fadehip_bgzf_inflate(fadehip_ctx *ctx, const void *members, size_t n_bytes, 
  * output's header members itself, and then passes the input's members from the one that holds the first record on
  * (first_record = bytes of that member's payload in front of the first record: the BGZF virtual offset's low 16 bits).
  *   front : whole BGZF members of the input (any number; cut where the caller likes — records may span members and
- *           calls).  Inflates, frames, annotates and rewrites the records that are complete; the tail of a record cut by
- *           the end of the call is kept for the next one.  Returns when the records' new bytes are on the device (the call
- *           waits for the device twice: sizes come back, buffers are sized, the next kernels go out).
- *   back  : compresses what the oldest finished front call produced and returns the BGZF members in pinned memory, valid
- *           until the back call AFTER the next (a writer thread may still be writing them while the next call compresses).  Outputs come in input order.  Without a finished front call waiting: FADEHIP_E_STATE
- *           (it never blocks for one).
- * front and back may run on two threads (one each): while back compresses chunk k, front works on chunk k+1; front
- * blocks while FADEHIP_BAM_CHUNKS finished chunks await back (a single-threaded caller alternates front and back).  A record already carrying rs / am / as / ar / ab is updated the way
- * htslib's bam_aux_update_* do (first occurrence: in place or replaced at its position).  Errors (corrupt member,
- * impossible record, input ending inside a record when last != 0) fail the call and every later one.
- * The genome must have been uploaded (fadehip_genome_upload); the stream uses the ctx's slot 0 and both BGZF lanes. */
+ *           calls).  Inflates and frames the records that are complete (the tail of a record cut by the end of the call is
+ *           kept for the next one), waits ONCE for the device — the buffers of the call are sized from what the framing
+ *           found — and returns with the annotate kernels and the tag sizes of the call enqueued.  The input buffer may be
+ *           reused when front returns.  Two calls are in flight: call k + 1 is framed while call k is annotated.
+ *   back  : finishes the oldest front call (reads its sizes, enqueues the kernel that writes the records with their tags),
+ *           compresses what it produced and returns the BGZF members in pinned memory — the kernel packs them there itself —,
+ *           valid until the back call AFTER the next (a writer thread may still be writing them while the next call
+ *           compresses).  If the call after is through its front half too, its compressor is enqueued before this call's
+ *           members are waited for.  Outputs come in input order.  Without a front call waiting: FADEHIP_E_STATE (it never
+ *           blocks for one).
+ * front and back may run on two threads (one each): while back compresses chunk k, front works on chunks k+1 and k+2; front
+ * blocks while FADEHIP_BAM_CHUNKS chunks await back (a single-threaded caller alternates front and back).  A record already
+ * carrying rs / am / as / ar / ab is updated the way htslib's bam_aux_update_int / bam_aux_update_str do (first occurrence:
+ * an integer rs keeps its slot and takes the unsigned type letter of its size; a string tag is replaced at its position; a
+ * tag of the wrong kind — rs:Z, am:i — is left as it is, as htslib's EINVAL leaves it).  Errors (corrupt member, impossible
+ * record, input ending inside a record when last != 0) fail the call and every later one; what the device finds in a
+ * call's records after front has returned surfaces at the call's back.  fadehip_bam_totals counts the calls back has taken.
+ * The genome must have been uploaded (fadehip_genome_upload); the stream uses the ctx's slots 0 and 1 and both BGZF lanes. */
 typedef struct fadehip_bam_stream fadehip_bam_stream;
 typedef struct fadehip_bam_config {
     int32_t floor_len;            /* --min-length (anno.d: artifact_floor_length) */
     int32_t window;               /* -w (align_buffer_size) */
     int32_t n_ref;                /* contigs of the BAM header: refID is checked against it, ref_names[refID] goes into am */
-    int32_t flags;                /* FADEHIP_BAM_STORED: uncompressed BGZF out (`fade annotate -u`, htslib's level 0) */
+    int32_t flags;                /* FADEHIP_BAM_STORED: uncompressed BGZF out (`fade annotate -u`, htslib's level 0);
+                                   * FADEHIP_BAM_NO_OUTPUT: back waits for the call's annotated records (on the device) and gives
+                                   * their buffer back without making BGZF of them, *out_bytes = 0 — the rate of the record path
+                                   * alone, from BAM record bytes to annotated record bytes (bench.py's value_from_records) */
     const char *const *ref_names; /* [n_ref] NUL-terminated */
     uint32_t first_record;        /* payload bytes of the first member passed to front that precede the first record */
     uint32_t tail_trim;           /* payload bytes at the END of the last member (front's last call) that are not this stream's:
@@ -308,6 +321,7 @@ typedef struct fadehip_bam_config {
 } fadehip_bam_config;
 #define FADEHIP_BAM_CHUNKS 3
 #define FADEHIP_BAM_STORED 1
+#define FADEHIP_BAM_NO_OUTPUT 2
 int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out);
 int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_bytes, int last);
 /* front for a caller that inflates itself (host cores otherwise idle; the device then spends its time on the rest):

@@ -28,9 +28,16 @@ def sw_pairs():
     qs, rs = make_pairs(rng, 210, lq_range=(8, 260), lr_range=(20, 700))
     with open(os.path.join(HERE, "sw_pairs.tsv"), "w") as f:
         f.write("#query\tref\tscore\tend_query\tend_ref\tbeg_query\tposition\tn_ops\tcigar_front16\n")
-        for q, r in zip(qs, rs):
-            res = O.sw(q.tobytes(), r.tobytes())
-            f.write("\t".join([q.tobytes().decode(), r.tobytes().decode(), str(res["score"]), str(res["end_query"]),
+        pairs = [(q.tobytes().decode(), r.tobytes().decode()) for q, r in zip(qs, rs)]
+        # + the pairs that exercise the rules random pairs do not reach (A.4 traceback priority, A.4 gap-tie): inputs in
+        # rule_pairs.in.tsv, found by tools/pin_kit/find_pairs.py — so that ONE pin-kit run decides every rule switch
+        for line in open(os.path.join(HERE, "rule_pairs.in.tsv")):
+            if not line.startswith("#"):
+                _, q, r = line.rstrip("\n").split("\t")
+                pairs.append((q, r))
+        for q, r in pairs:
+            res = O.sw(q, r)
+            f.write("\t".join([q, r, str(res["score"]), str(res["end_query"]),
                                str(res["end_ref"]), str(res["beg_query"]), str(res["beg_ref"]), str(res["n_ops"]),
                                O.cigar_str(res["ops"][:16])]) + "\n")
 

@@ -41,11 +41,40 @@ def _load_case(tag):
 
 def test_oracle_reproduces_golden_sw(oracle):
     rows = _load_sw()
-    assert len(rows) == 210
+    assert len(rows) == 226  # 210 random / adversarial pairs + 16 that exercise the A.4 rules (rule_pairs.in.tsv)
     for q, r, nums, cig in rows:
         res = oracle.sw(q, r)
         assert (res["score"], res["end_query"], res["end_ref"], res["beg_query"], res["beg_ref"], res["n_ops"]) == nums
         assert oracle.cigar_str(res["ops"][:16]) == cig
+
+
+def test_one_pin_kit_run_decides_every_rule(oracle):
+    """tools/pin_kit: a maintainer with libparasail / dparasail prints sw_pairs.tsv's columns for the committed pairs and
+    compare.py names the FO_RULE_* switch a mismatch points to.  That run must DECIDE every switch (SURVEY Appendix A.1,
+    A.3-A.6): for each of the seven bits, at least five committed pairs change under the flip — in the columns the D kit
+    prints (score, position, n_ops, cigar; end_query / end_ref / beg_query are -1 there) — and compare.py, fed the oracle's
+    output under the flipped rule as if it were the kit's, names exactly that bit for them and no other.  (The eighth
+    assumption, dhtslib's Cigar.alignedLength, is the probe line of pin_dparasail.d: 22 or 24.)"""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(GOLD))
+    spec = importlib.util.spec_from_file_location("pin_compare", os.path.join(root, "tools", "pin_kit", "compare.py"))
+    cmp_ = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmp_)
+    rows = _load_sw()
+    for bit in cmp_.RULES:
+        flipped = oracle.default_params(rules=0x7f & ~bit)
+        for d_kit in (False, True):
+            kit = []
+            for q, r, nums, cig in rows:
+                f = cmp_.fields(oracle.sw(q, r, params=flipped))
+                if d_kit:
+                    f[1] = f[2] = f[3] = -1
+                kit.append([q, r] + [str(x) for x in f[:6]] + [f[6]])
+            diffs = cmp_.diagnose(kit)
+            named = [d for d in diffs if d[4] == [bit]]
+            assert len(named) >= 5, (bit, d_kit, len(diffs), len(named))
+            assert all(bit in d[4] for d in diffs), (bit, d_kit)  # every line that moved is explained by this flip
 
 
 @pytest.mark.parametrize("tag", CASES)

@@ -54,3 +54,27 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["stats"]["read_count"] == 2 * 20000 * 10 and r["scaling"] == "weak"
+
+
+def test_bench_line_carries_the_record_path_and_the_end_to_end_legs():
+    """One rank, small: value_from_records (the path from BAM record bytes, nothing decided on the host) beside value, the CPU
+    baseline on the same definition, the e2e block with every leg best-of-2 and the larger file's legs."""
+    r = _bench(["--gpus", "1", "--steps", "1", "--warmup", "1", "--batch-reads", "40000", "--e2e-reads", "400000", "--e2e-big-reads", "800000"])
+    assert r["value_from_records"] > 0 and "fadehip_bam_front_raw" in r["value_from_records_is"]
+    c = r["cpu_baseline_from_records"]
+    assert c["value"] > 0 and c["kind"] == "port" and c["cores"] >= 1 and c["gpu_over_cpu"] > 0
+    e = r["e2e"]
+    assert e["gpu_reads_per_s"] > 0 and e["cpu_reads_per_s"] > 0 and e["gpu"]["best_of"] == 2 and e["cpu"]["best_of"] == 2
+    assert e["big"]["reads"] == 800000 and e["big"]["gpu_reads_per_s"] > 0 and e["big"]["cpu_reads_per_s"] > 0
+    assert "kernel_ms_is" in r["roofline"] and r["cpu_baseline"]["value"] > 0
+
+
+def test_bench_two_ranks_run_the_end_to_end_leg_on_their_shards():
+    """`--gpus 2` with the e2e leg: every rank annotates ITS shard's BAM file (`fade annotate -b`, its own process and device
+    context), rank 0 first alone, then both at once; the line reports per-rank times, the aggregate and e2e_weak_scaling."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--batch-reads", "40000", "--e2e-reads", "400000", "--no-cpu"],
+               env={"FADE_BENCH_BACKEND": "gloo", "MASTER_PORT": "29677"})
+    e = r["e2e"]
+    assert r["n_gpus"] == 2 and len(e["per_rank_seconds"]) == 2 and all(x > 0 for x in e["per_rank_seconds"])
+    assert e["alone_reads_per_s"] > 0 and e["aggregate_reads_per_s"] > 0 and 0 < e["e2e_weak_scaling"] < 3
+    assert r["value_from_records"] > 0

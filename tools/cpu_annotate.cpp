@@ -19,7 +19,7 @@ using namespace htsl;
 
 int main(int argc, char **argv) {
     int threads = 16, floor_len = 5, window = 300, batch = 262144;
-    bool bam = false, ubam = false, timing = false;
+    bool bam = false, ubam = false, timing = false, records_only = false;
     std::vector<std::string> pos;
     std::string cl = "fade";
     for (int i = 1; i < argc; i++) cl += std::string(" ") + argv[i];
@@ -32,6 +32,7 @@ int main(int argc, char **argv) {
         else if (a == "-b") bam = true;
         else if (a == "-u") ubam = true;
         else if (a == "--timing") timing = true;
+        else if (a == "--records-only") records_only = true;  // the path from bam1_t-shaped records alone: see below
         else pos.push_back(a);
     }
     if (pos.size() != 3 || pos[0] != "annotate") {
@@ -83,8 +84,12 @@ int main(int argc, char **argv) {
         fo_params_default(&prm);
         prm.striped = 1;
         const OutFmt fmt = bam ? OutFmt::BAM : ubam ? OutFmt::UBAM : OutFmt::SAM;
-        Writer writer(stdout, fmt, hdr, &pool);
-        BoundedQueue<std::unique_ptr<Work>> q_in(2), q_out(2);
+        // --records-only (bench.py's cpu_baseline_from_records): the input is read, inflated and framed FIRST, outside the
+        // clock; the clock then covers what starts from a record as htslib hands it over (bam1_t: anno.d:55) — the gate,
+        // reverse complement, FASTA window, SW, gates, tag strings of every record on all threads — and nothing is written.
+        std::unique_ptr<Writer> writer_p;
+        if (!records_only) writer_p.reset(new Writer(stdout, fmt, hdr, &pool));
+        BoundedQueue<std::unique_ptr<Work>> q_in(records_only ? (size_t)1 << 20 : 2), q_out(2);
         std::thread t_reader([&] {
             try {
                 for (;;) {
@@ -103,8 +108,8 @@ int main(int argc, char **argv) {
             std::unique_ptr<Work> w;
             try {
                 while (q_out.pop(w)) {
-                    if (w->is_block) writer.write_block(w->blk, w->bout);
-                    else writer.write(w->recs);
+                    if (w->is_block) writer_p->write_block(w->blk, w->bout);
+                    else writer_p->write(w->recs);
                 }
             } catch (const std::exception &e) {
                 set_err(e.what());
@@ -113,8 +118,11 @@ int main(int argc, char **argv) {
         });
         struct Tags { std::string t[4]; };
         std::unique_ptr<Work> w;
+        size_t n_records = 0;
+        if (records_only) t_reader.join();  // (every record is in memory before the clock starts)
         try {
         while (q_in.pop(w)) {
+            n_records += w->n();
             const auto t0 = std::chrono::steady_clock::now();
             const size_t n = w->n(), nt = (size_t)pool.size() * 8;
             std::vector<uint8_t> rs(n, 0);
@@ -212,7 +220,7 @@ int main(int argc, char **argv) {
                 });
             }
             t_sw += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            q_out.push(std::move(w));
+            if (!records_only) q_out.push(std::move(w));
         }
         } catch (const std::exception &e) {  // let the reader run out so that it can be joined
             set_err(e.what());
@@ -220,9 +228,10 @@ int main(int argc, char **argv) {
         }
         q_out.close();
         t_writer.join();
-        t_reader.join();
+        if (t_reader.joinable()) t_reader.join();
         if (!stage_err.empty()) throw std::runtime_error(stage_err);
-        writer.close();
+        if (writer_p) writer_p->close();
+        if (records_only) printf("{\"records\": %zu, \"seconds\": %.6f, \"threads\": %d}\n", n_records, t_sw, threads);
     } catch (const std::exception &e) {
         fprintf(stderr, "[E::cpu_annotate] %s\n", e.what());
         return 1;

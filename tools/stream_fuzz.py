@@ -1,5 +1,6 @@
-"""Differential fuzz of the file path on the device against the host pipeline (the checker of tests/test_gpu_bam_stream.py,
-itself held to the oracle by tests/test_gpu_cli.py): random read mixes, random extra tags (ours among them), odd records,
+"""Differential fuzz of the file path on the device against TWO checkers: the host pipeline (FADE_BAM_DEVICE=0) and
+tools/cpu_annotate — the CPU oracle's annotateTask (oracle/: anno.d:55-110, analysis.d:22-124) around the same reader and
+writer, i.e. the oracle itself, record for record and tag for tag: random read mixes, random extra tags (ours among them), odd records,
 members of random sizes and levels with empty members between them, random call sizes, both inflate modes, random -w and
 --min-length.  The two outputs must inflate to the same bytes.
     python tools/stream_fuzz.py [seconds] [first_seed]      (GPU box; progress lines go to stdout)"""
@@ -22,6 +23,7 @@ from test_gpu_bam_stream import _random_aux, _rec  # noqa: E402
 from test_gpu_inflate import EOF_MARK, member  # noqa: E402
 
 FADE = os.path.join(ROOT, "fade_amd", "fade")
+CPU = os.path.join(ROOT, "tools", "cpu_annotate")
 TMP = os.environ.get("TMPDIR", "/tmp")
 
 
@@ -124,6 +126,15 @@ def one(seed):
         assert got == want, what
     stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
     assert stats(dev.stderr) == stats(host.stderr), what
+    # the oracle itself: every record's bytes (rs, am / as / ar / ab, their order and types, the untouched rest) must be the
+    # ones the CPU restatement of annotateTask writes (another command line in @PG: the records are compared)
+    cargs = [a for a in args if a != "--stats"]
+    if "-t" not in cargs:
+        cargs[1:1] = ["-t", "8"]
+    cpu = subprocess.run([CPU] + cargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert cpu.returncode == 0, what + "\n" + cpu.stderr.decode()[-1500:]
+    ora = gzip.decompress(cpu.stdout)
+    assert got[header_len(got):] == ora[header_len(ora):], "vs the oracle (tools/cpu_annotate): " + what
     return n_rec, len(ms)
 
 
@@ -138,5 +149,5 @@ if __name__ == "__main__":
         recs += r
         mems += m
         if done % 10 == 0:
-            print("%d cases, %d records, %d members, 0 mismatches (%.0f s)" % (done, recs, mems, time.time() - t0), flush=True)
-    print("stream fuzz: %d cases, %d records, %d members: 0 mismatches" % (done, recs, mems))
+            print("%d cases, %d records, %d members, 0 mismatches vs host pipeline and vs oracle (%.0f s)" % (done, recs, mems, time.time() - t0), flush=True)
+    print("stream fuzz: %d cases, %d records, %d members: 0 mismatches against the host pipeline, 0 against the oracle (tools/cpu_annotate)" % (done, recs, mems))
