@@ -307,11 +307,16 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *tmp16,
 }
 
 // thread per record: layout check, anno.d:61-65 (does the record go to the device?), SA, our own tags; block sums
+// (The launch is sized from an ESTIMATE of the records the bytes hold — a bound from the bytes alone would be eight times
+// too many workgroups, each waiting for a wave slot beside the compressor; the grid strides over the blocks of PACK_BLOCK
+// records there really are, whatever the estimate was.)
 __global__ __launch_bounds__(PACK_BLOCK) void bam_pack_count_kernel(PackArgs a) {
     __shared__ uint32_t red[16][8];
     const uint32_t n_all = a.counts_in->n_records;
     const uint32_t r1 = min(a.r1_cap, n_all);
-    const uint32_t i = a.r0 + blockIdx.x * PACK_BLOCK + threadIdx.x;
+    const uint32_t n_blk = r1 > a.r0 ? (r1 - a.r0 + PACK_BLOCK - 1) / PACK_BLOCK : 0u;
+    for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    const uint32_t i = a.r0 + blk * PACK_BLOCK + threadIdx.x;
     uint32_t info = 0, ncig = 0, nseq = 0, lq = 0, span = 0;
     if (i < r1) {
         const RecHdr r = rec_header(a.u + a.rec_off[i]);
@@ -375,9 +380,9 @@ __global__ __launch_bounds__(PACK_BLOCK) void bam_pack_count_kernel(PackArgs a) 
             t[3] = min(t[3], red[w][3]); t[4] = max(t[4], red[w][4]); t[5] = max(t[5], red[w][5]);
             t[6] += red[w][6]; t[7] += red[w][7];
         }
-        a.blk_sums[3 * blockIdx.x + 0] = t[0];
-        a.blk_sums[3 * blockIdx.x + 1] = t[1];
-        a.blk_sums[3 * blockIdx.x + 2] = t[2];
+        a.blk_sums[3 * blk + 0] = t[0];
+        a.blk_sums[3 * blk + 1] = t[1];
+        a.blk_sums[3 * blk + 2] = t[2];
         ChunkCounts *c = a.counts;
         if (t[0]) {
             atomicMin(&c->l_seq_min, t[3]);
@@ -388,12 +393,18 @@ __global__ __launch_bounds__(PACK_BLOCK) void bam_pack_count_kernel(PackArgs a) 
         if (t[7] & 0xffffu) atomicAdd(&c->n_bad_layout, t[7] & 0xffffu);
         if (t[7] >> 16) atomicAdd(&c->n_ours, t[7] >> 16);
     }
+    __syncthreads();  // `red` is written again by the block's next round
+    }
 }
 
 // one block: exclusive scan of the block sums (three columns) -> blk_base, totals -> counts
 __global__ __launch_bounds__(1024) void bam_pack_scan_kernel(PackArgs a, uint32_t n_blocks) {
     __shared__ uint32_t part[1024][3];
     const int tid = threadIdx.x;
+    {   // (the count kernel wrote sums for the blocks of records there are; beyond them the array holds nothing)
+        const uint32_t r1 = min(a.r1_cap, a.counts_in->n_records);
+        n_blocks = min(n_blocks, r1 > a.r0 ? (r1 - a.r0 + PACK_BLOCK - 1) / PACK_BLOCK : 0u);
+    }
     const uint32_t per = (n_blocks + 1023u) / 1024u, lo = (uint32_t)tid * per, hi = min(lo + per, n_blocks);
     uint32_t s[3] = {0, 0, 0};
     for (uint32_t k = lo; k < hi; k++)

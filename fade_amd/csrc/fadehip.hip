@@ -195,6 +195,9 @@ struct fadehip_ctx {
     bool use_packed = true;
     bool two_pass = true;
     int tail_cus_per_xcd = 1;  // FADEHIP_TAIL_CUS: CUs per XCD the score pass leaves alone (0: no CU mask, one stream per slot)
+    int score_g8 = 1;            // the score pass of reads of up to 152 bases in the 160-row class on eight-lane groups (FADEHIP_SCORE_G8=0: sixteen-lane groups; 2: at two waves per SIMD): the score pass of 150-base reads on eight-lane groups (A/B variant)
+    bool blocking_sync = false;  // FADEHIP_BLOCKING_SYNC=1: waits for the device sleep
+    bool score_persist = false;  // FADEHIP_SCORE_PERSIST=1: the score pass as a persistent launch (A/B variant)
     int p2_waves_fixed = 0;    // FADEHIP_P2_WAVES: waves of the persistent pass-2 launch (0: adaptive, see run_class_two_pass)
     int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
     bool debug = false;
@@ -551,7 +554,28 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
             HIPCHK(ctx, hipStreamWaitEvent(sst, s.ev[ef], 0));
         }
         if (c.timed && (rc = record(ctx, s, &e0, sst))) return rc;
-        if ((rc = launch_pk_mode(ctx, cls, 1, a, octs, lds1, sst, p.longw))) return rc;
+        int waves1 = octs;
+        if (ctx->score_persist && class_rows(cls) == 10 && !p.longw && s.tickets_used < (int)Slot::N_TICKETS) {
+            // the A/B variant: as many waves as the CUs of the stream hold at once, each drawing octets by ticket
+            const int res = resident_waves(ctx, cls, 1, lds1, p.longw);
+            const int cus = std::max(ctx->cu_count, 1), mine = s.score_stream ? std::max(cus - 8 * ctx->tail_cus_per_xcd, 1) : cus;
+            waves1 = std::max(1, std::min(octs, (int)((int64_t)res * mine / cus)));
+            a.ticket = s.d_ticket(s.tickets_used++);
+        }
+        // the other A/B variant: eight-lane groups, 19 rows per lane (152 rows for reads of up to 152 bases in the 160-row class),
+        // sixteen alignments per wavefront; no snapshots in this geometry (pass 2 re-computes from step 0)
+        const bool g8 = ctx->score_g8 && class_rows(cls) == 10 && s.max_lq <= 152 && !p.longw && n_ck == 0 && !a.ticket;
+        if (g8) {
+            SwArgs copy = a;
+            void *args[] = {&copy};
+            const void *fn = ctx->score_g8 == 2 ? (const void *)sw_pk_kernel<19, 1, false, 8, false, 2> : (const void *)sw_pk_kernel<19, 1, false, 8>;
+            HIPCHK(ctx, hipLaunchKernel(fn, dim3((unsigned)((n + 15) / 16)), dim3(64), args, 2 * lds1, sst));
+        } else if (a.ticket) {
+            SwArgs copy = a;
+            void *args[] = {&copy};
+            HIPCHK(ctx, hipLaunchKernel((const void *)sw_pk_kernel<10, 1, false, 16, true>, dim3((unsigned)waves1), dim3(64), args, lds1, sst));
+        } else if ((rc = launch_pk_mode(ctx, cls, 1, a, waves1, lds1, sst, p.longw))) return rc;
+        a.ticket = nullptr;
         if ((c.timed || sst != st) && (rc = record(ctx, s, &e1, sst))) return rc;
         if (sst != st) HIPCHK(ctx, hipStreamWaitEvent(st, s.ev[e1], 0));
         // pass 2 + tracebacks + re-traced paths: one persistent launch
@@ -1237,6 +1261,17 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
         return fail(FADEHIP_E_INVALID);
     }
     if ((rc = build_score_tab(ctx, ctx->prm, ctx->sc))) return fail(rc);
+    // FADEHIP_BLOCKING_SYNC=1 (the `fade` driver's file path sets it): a thread that waits for the device sleeps instead of
+    // spinning.  A file-to-file run keeps every host core busy inflating; the two threads that wait for the front and the
+    // back half of each call would otherwise burn a core each.  Not the default: a wake-up costs tens of microseconds,
+    // which the level-2 pipeline (a result every millisecond) does not have to spare.
+    if (const char *kv = getenv("FADEHIP_BLOCKING_SYNC")) {
+        if (atoi(kv)) {
+            ctx->blocking_sync = true;
+            (void)hipSetDevice(device);
+            if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();  // (a device already in use keeps its flags)
+        }
+    }
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
         set_err(ctx, FADEHIP_E_NODEVICE, "cannot open HIP device %d", device);
@@ -1264,6 +1299,8 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     if (const char *kv = getenv("FADEHIP_SPAN_SLACK")) ctx->span_slack = atoi(kv);
     if (const char *kv = getenv("FADEHIP_TAIL_CUS")) ctx->tail_cus_per_xcd = std::max(0, std::min(atoi(kv), 8));
     if (const char *kv = getenv("FADEHIP_P2_WAVES")) ctx->p2_waves_fixed = std::max(0, atoi(kv));
+    if (const char *kv = getenv("FADEHIP_SCORE_PERSIST")) ctx->score_persist = atoi(kv) != 0;
+    if (const char *kv = getenv("FADEHIP_SCORE_G8")) ctx->score_g8 = atoi(kv);
     ctx->debug = getenv("FADEHIP_DEBUG") != nullptr;
     uint8_t table[256];
     fill_ascii_table(table);
@@ -1789,7 +1826,7 @@ static int bgzf_lane_ready(fadehip_ctx *ctx, int lane, bool one_stream = false) 
         if (lane > 0 && (one_stream || getenv("FADEHIP_BGZF_ONE_STREAM")) && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
         else HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
-        HIPCHK(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
     }
     if (!ctx->bgzf_ready) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)bgzf64::bgzf_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bgzf64::LDS_BYTES));
@@ -2036,15 +2073,15 @@ struct fadehip_bam_stream {
         bool pending = false;  // B is enqueued, C is not
         bam::TagArgs ta;
         Out *out = nullptr;
-        double t_b = 0;
+        std::mutex mu;  // finishing the set's call (front and back may both come to do it; the OTHER set's call is not held up)
     } set[2];
     uint32_t prev_len = 0, prev_consumed = 0;  // of the previous call's u
+    double rec_bytes_avg = 0;                  // bytes per record of the previous call (sizes the next call's record-parallel launch)
     uint64_t k_front = 0, k_back = 0;
     uint64_t k_sub = 0;                     // calls handed to the compressor (back may run one ahead of the call it returns)
     PinBuf outbuf[FADEHIP_BAM_CHUNKS];      // the members of call k, packed by the kernel itself: pinned, k % FADEHIP_BAM_CHUNKS
     std::mutex mu;
     std::condition_variable cv;
-    std::mutex pipe_mu;  // finishing a call (front and back may both come to do it)
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_records = 0, n_oversize = 0, n_redone = 0;
     bool failed = false, ended = false, closing = false;
@@ -2067,9 +2104,9 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // C of call k (see fadehip_bam_stream): waits for the call's run and tag sizes, sizes the output, enqueues the rewrite.
 // Idempotent; front and back may both arrive here for the same call.
 int bam_finish_call(fadehip_bam_stream *st, uint64_t k) {
-    std::lock_guard<std::mutex> pl(st->pipe_mu);
     fadehip_ctx *ctx = st->ctx;
     fadehip_bam_stream::Set &S = st->set[k & 1];
+    std::lock_guard<std::mutex> pl(S.mu);
     if (S.k != k || !S.pending) return 0;
     Slot &s = ctx->slots[k & 1];
     hipStream_t q = s.stream;
@@ -2099,7 +2136,7 @@ int bam_finish_call(fadehip_bam_stream *st, uint64_t k) {
         std::lock_guard<std::mutex> l(st->mu);
         st->n_records += S.n_rec;
     }
-    if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
+    if (!out->ready) HIPCHK(ctx, hipEventCreateWithFlags(&out->ready, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
     HIPCHK(ctx, hipEventRecord(out->ready, q));
     S.pending = false;
     st->t_tags += now_s() - t0;
@@ -2223,7 +2260,9 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     pa.blk_base = pa.blk_sums + 3 * (size_t)nblk_cap;
     pa.counts = d_counts;
     pa.sent_of = (int32_t *)S.sent_of.p;
-    hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(nblk_cap), dim3(bam::PACK_BLOCK), 0, q, pa);
+    // (sized from the bytes per record of the calls so far, with a margin; the kernel strides over what is really there)
+    const uint32_t nblk_est = st->rec_bytes_avg > 0 ? (uint32_t)((double)u_len / st->rec_bytes_avg * 1.25 / bam::PACK_BLOCK) + 8u : nblk_cap;
+    hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(std::max(1u, std::min(nblk_cap, nblk_est))), dim3(bam::PACK_BLOCK), 0, q, pa);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk_cap);
     HIPCHK(ctx, hipGetLastError());
@@ -2250,6 +2289,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     st->prev_len = u_len;
     st->prev_consumed = used;
     st->n_redone += h_counts->n_redone;
+    if (n_rec) st->rec_bytes_avg = (double)used / (double)n_rec;
     // ---- a place in the ring
     fadehip_bam_stream::Out *out;
     {
@@ -2498,8 +2538,8 @@ int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_by
     if (next_waiting && st->k_sub == k + 1) {
         bool through;
         {
-            std::lock_guard<std::mutex> pl(st->pipe_mu);
             fadehip_bam_stream::Set &S = st->set[(k + 1) & 1];
+            std::lock_guard<std::mutex> pl(S.mu);
             through = S.k != k + 1 || !S.pending || hipStreamQuery(ctx->slots[(k + 1) & 1].stream) == hipSuccess;
         }
         if (through && (rc = bam_submit_back(st, k + 1))) return bam_fail(st, rc);

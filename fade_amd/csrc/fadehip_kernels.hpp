@@ -395,7 +395,7 @@ struct SwArgs {
     SelArgs sel;                // MODE 1: the selection, done by the wave that scored the alignment
     const uint32_t *bucket_n;   // MODE 2: [NUM_BUCKETS] candidates per bucket, as the selection left them
     uint32_t cand_cap;          // MODE 2: entries per bucket of `cand`
-    uint32_t *ticket;           // MODE 2: the waves of the launch draw octets from this counter until the table is exhausted
+    uint32_t *ticket;           // MODE 2 (MODE 1 when set: the persistent variant): the waves of the launch draw octets from this counter until the table / list is exhausted
     unsigned long long *cand_total;  // MODE 2: + candidates of this launch (by the wave that draws ticket 0)
     // MODE 2 walks the traceback of an octet's candidates right after tracing them (same wave, trace still in L2)
     const Meta *meta;           // nullptr for level 1
@@ -1306,16 +1306,27 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 // (168; R = 16 spills ~100 registers outside its sweep and is still 6 % faster than at 2 waves), 2 beyond (R = 20 / 24:
 // +27 % / +30 % over the unconstrained allocation, which took 256 VGPRs and one wave).  The traced pass is latency-bound:
 // 3 or 4 waves per SIMD (40 / 85 spilled registers) changed nothing measurable, it is left alone.
-__host__ __device__ constexpr int pk_min_waves(int R, int MODE) { return MODE != 1 ? 1 : (R <= 10 ? 4 : (R <= 16 ? 3 : 2)); }
+__host__ __device__ constexpr int pk_min_waves(int R, int MODE, int LG = 16, int WV = 0) { return WV ? WV : MODE != 1 ? 1 : (LG == 8 ? 3 : (R <= 10 ? 4 : (R <= 16 ? 3 : 2))); }
 
 // LONGW: the launch may hold windows longer than one staged chunk (CH_COLS columns); the sweep then re-stages at chunk
 // boundaries.  A kernel of its own, so that the ordinary launch keeps its registers (the chunk loop cost the 150-base
 // score pass 29 spilled registers when it was a run-time branch).
-template <int R, int MODE, bool LONGW = false>
-__global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs a) {
+// LG: lanes per alignment pair.  16 (everything but one A/B variant): four pairs, eight alignments per wavefront.  8
+// (FADEHIP_SCORE_G8, MODE 1 only): eight pairs, sixteen alignments per wavefront, a lane owning R rows of 8 R
+// (19 x 8 = 152 rows for 150-base reads instead of 10 x 16 = 160; the skew is 7 steps instead of 15).  DPP row_shr:1
+// still shifts within 16-lane rows, so lane 8 of a row is given the DP boundary by hand.
+// PERSIST (FADEHIP_SCORE_PERSIST, MODE 1 only, the other A/B variant): the score pass as a persistent launch whose waves draw
+// octets from a ticket.  Both variants are instantiations of their own: the ordinary score pass keeps its registers.
+template <int R, int MODE, bool LONGW = false, int LG = 16, bool PERSIST = false, int WV = 0>
+__global__ __launch_bounds__(64, pk_min_waves(R, MODE, LG, WV)) void sw_pk_kernel(SwArgs a) {
+    static_assert(LG == 16 || (LG == 8 && MODE == 1 && !LONGW), "eight-lane groups exist for the score pass only");
+    static_assert(!PERSIST || MODE == 1, "the persistent variant is a score pass");
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x;
-    const int g = lane >> 4, lig = lane & 15;
+    constexpr int NG = 64 / LG, NPW = 2 * NG;  // groups, alignments per wavefront
+    const int g = lane / LG, lig = lane & (LG - 1);
+    const uint32_t lig0m = (LG == 8 && lig == 0) ? 0xffffffffu : 0u;  // LG = 8: lanes that take the DP boundary instead of their neighbour's values
+    (void)lig0m;
     // ---- score table in LDS, indexed by the PAIR of column classes (cA, cB) of a lane's two alignments: entry
     // (7 cA + cB) = 16 bytes {rowA.lo, rowB.lo, rowA.hi, rowB.hi}, row c = 8 bytes, byte q = 8 * W'(query class q,
     // column class c).  The class word that travels along the lanes IS the entry's byte offset, so a step costs one
@@ -1372,12 +1383,20 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         if (kA < n_b) { const Cand c = cl[kA]; srcA = c.src; c0A = c.c0; haveA = true; }
         if (kB < n_b) { const Cand c = cl[kB]; srcB = c.src; c0B = c.c0; haveB = true; }
     } else {
-        if (!first_round || oct * 8 >= n_items) break;
+        if constexpr (PERSIST) {
+            uint32_t tk = 0;
+            if (lane == 0) tk = atomicAdd(a.ticket, 1u);
+            oct = (int)__builtin_amdgcn_readfirstlane(tk);
+            if (oct * NPW >= n_items) break;
+            if (!first_round) __syncthreads();  // the previous octet's window is no longer read
+        } else {
+            if (!first_round || oct * NPW >= n_items) break;
+        }
     }
     // MODE 2: an octet is traced, its tracebacks walked, and the members whose path left the traced steps are traced
     // again from further back (4 snapshots, then step 0, where no path can leave) — all by the wave that drew it
     for (int attempt = 0;; attempt++) {
-    const int itemA = oct * 8 + g * 2, itemB = itemA + 1;
+    const int itemA = oct * NPW + g * 2, itemB = itemA + 1;
     Work wa, wb;
     wa.r_base = wb.r_base = 0; wa.q_base = wb.q_base = 0; wa.lq = wb.lq = 0; wa.lr = wb.lr = 0;
     wa.idx = wb.idx = 0; wa.flags = wb.flags = 0; wa.out = wb.out = 0;
@@ -1404,11 +1423,10 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         if (itemB < n_items) wb = a.work[itemB];
     }
     const int lqA = (int)wa.lq, lrA = (int)wa.lr, lqB = (int)wb.lq, lrB = (int)wb.lr;
-    int mx = P2 ? max(stepsA, stepsB) : max(lrA, lrB) + 15;
+    int mx = P2 ? max(stepsA, stepsB) : max(lrA, lrB) + LG - 1;
     int maxst = __builtin_amdgcn_readlane(mx, 0);
-    maxst = max(maxst, __builtin_amdgcn_readlane(mx, 16));
-    maxst = max(maxst, __builtin_amdgcn_readlane(mx, 32));
-    maxst = max(maxst, __builtin_amdgcn_readlane(mx, 48));
+#pragma unroll
+    for (int k = 1; k < NG; k++) maxst = max(maxst, __builtin_amdgcn_readlane(mx, k * LG));
     const int n_blocks = (maxst + 3) >> 2;
 
     // ---- stage both windows: 16 bits per column = (7 classA + classB) * 16, the byte offset into wtab
@@ -1421,7 +1439,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // fetches a block's class words one block ahead)
     auto stage = [&](const int c0) __attribute__((always_inline)) {
         const int c1 = min(n_cols, c0 + CH_COLS + 8);
-        for (int k0 = c0 + lig * 8; k0 < c1; k0 += 128) {
+        for (int k0 = c0 + lig * 8; k0 < c1; k0 += 8 * LG) {
             Nib8 na, nb;
             na.word = nb.word = 0; na.byte0 = nb.byte0 = 0;
             const uint64_t ra0 = wa.r_base + (uint64_t)k0, rb0 = wb.r_base + (uint64_t)k0;
@@ -1489,8 +1507,9 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     // <= 448): 8*H8 + 2*(31 - t % 32) + (row even) = 64 * score + 6 low bits, 32-step windows and half the fold work.
     // Row classes 16 .. 24 (scores <= 768): 4*H8 + 2*(15 - t % 16) + (row even) = 32 * score + 5 low bits, 16-step
     // windows (the fold work of the unpaired key).  R = 32 (scores up to 1024) keeps one key per row.
-    constexpr bool PAIRKEY = (MODE == 1) && (R <= 24);
-    constexpr int KW = (PAIRKEY && R > 14) ? 16 : 32;              // steps per key window
+    constexpr int ROWS = R * LG;                                   // query rows of the kernel: what bounds the score
+    constexpr bool PAIRKEY = (MODE == 1) && (ROWS <= 384);
+    constexpr int KW = (PAIRKEY && ROWS > 224) ? 16 : 32;          // steps per key window
     constexpr int KLOW = PAIRKEY ? (KW == 32 ? 6 : 5) : 5;          // key bits below the score
     constexpr uint32_t KLOWM = ((1u << KLOW) - 1u) * 0x10001u;      // ... as a mask over both halves
     uint32_t Hl[R], Eh[R], bestA[R], bestB[R];  // MODE 1 reuses bestA as the window key and bestB as GH
@@ -1607,6 +1626,11 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             rc = (uint32_t)__builtin_amdgcn_update_dpp((int)fresh, (int)rc, DPP_ROW_SHR1, 0xf, 0xf, false);
             uint32_t hu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
             uint32_t fu = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fu_out, DPP_ROW_SHR1, 0xf, 0xf, true);
+            if constexpr (LG == 8) {  // lane 8 of a DPP row starts a group of its own
+                rc = bfi(lig0m, fresh, rc);
+                hu &= ~lig0m;
+                fu &= ~lig0m;
+            }
             uint2 tA, tB;
             if constexpr (FAST) {
                 const uint2 e = *reinterpret_cast<const uint2 *>(wt + rc);
@@ -1671,6 +1695,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                 if constexpr (PAIRKEY) {
                     const uint32_t k = KW == 32 ? pk_mad8(H, (r & 1) ? tk_odd : tk_even) : pk_mad4(H, (r & 1) ? tk_odd : tk_even);
                     if (r & 1) bestA[r >> 1] = pk_max3_nonneg(bestA[r >> 1], kprev, k);
+                    else if ((R & 1) && r == R - 1) bestA[r >> 1] = pk_max3_nonneg(bestA[r >> 1], k, k);  // (an odd R: the last row has no partner)
                     else kprev = k;
                 }
                 hd = hl;
@@ -1696,7 +1721,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
         const uint32_t wbase = PAIRKEY ? (win * (2 * KW) + (2 * KW - 1)) * 0x10001u : (win * 32 + 31) * 0x10001u;
         const uint32_t HMASK = (PAIRKEY && !end_min_ref) ? ~(((1u << (KLOW - 1)) - 1u) * 0x10001u) : ~KLOWM, PMASK = KLOWM;
 #pragma unroll
-        for (int r = 0; r < (PAIRKEY ? R / 2 : R); r++) {
+        for (int r = 0; r < (PAIRKEY ? (R + 1) / 2 : R); r++) {
             const uint32_t wk = bestA[r];
             const uint32_t wH = wk & HMASK;
             const uint32_t imp = as_u32(__builtin_elementwise_sub_sat(as_u2(wH), as_u2(bestB[r])));
@@ -1730,7 +1755,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
     else sweep(std::true_type{});
 
     // per-lane candidates: NK 32-bit keys (H8 << 16) | (0xffff - t) per alignment and the lane-local row each belongs to
-    constexpr int NK = PAIRKEY ? R / 2 : R;
+    constexpr int NK = PAIRKEY ? (R + 1) / 2 : R;
     uint32_t rowA[R], rowB[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { rowA[r] = (uint32_t)r; rowB[r] = (uint32_t)r; }
@@ -1786,7 +1811,7 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
             cb = end_min_ref ? (h << 32) | (nj << 16) | ni : (h << 32) | (ni << 16) | nj;
         }
 #pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
+        for (int m = 1; m < LG; m <<= 1) {
             const uint64_t oa = __shfl_xor(ca, m, 64), ob = __shfl_xor(cb, m, 64);
             ca = oa > ca ? oa : ca;
             cb = ob > cb ? ob : cb;
@@ -1825,7 +1850,8 @@ __global__ __launch_bounds__(64, pk_min_waves(R, MODE)) void sw_pk_kernel(SwArgs
                     f.end_r = cc ? (int32_t)(0xffff - ((cc >> 16) & 0xffff)) : 0;
                     f.end_q = cc ? (int32_t)(0xffff - (cc & 0xffff)) : 0;
                     f.pad = 0;
-                    art = select_one(a.sel, item, lig ? wb : wa, f, R, a.q_nib, a.r_nib, a.sc.rules);
+                    // (R here is pass 2's rows per lane: it sizes the steps a candidate's re-computation will take)
+                    art = select_one(a.sel, item, lig ? wb : wa, f, LG == 8 ? (R + 1) / 2 : R, a.q_nib, a.r_nib, a.sc.rules);
                 }
                 if (a.sel.stats) add_artifact_stats(a.sel.stats, art, blockIdx.x);
             }

@@ -1069,6 +1069,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         fadehip_params prm;
         fadehip_params_default(&prm);
         setenv("FADEHIP_TAIL_CUS", "0", 0);  // one batch at a time: no CU-masked stream, fewer queues
+        setenv("FADEHIP_BLOCKING_SYNC", "1", 0);  // the threads that wait for the device sleep: the cores are the inflater's
         int device = 0;
         if (lane.on) device = lane.device;
         else if (const char *dm = getenv("FADE_DEVICE_MAP")) device = atoi(dm);
@@ -1108,7 +1109,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         const size_t ccap = host_inflate ? std::max<size_t>(chunk / 2, 1 << 20) : chunk, HEAD = 65536 + 64;
         constexpr int NBUF = 3;
         struct CBuf { uint8_t *p = nullptr; size_t n = 0; uint64_t off = 0; bool eof = false; std::vector<uint8_t> own; };
-        struct In { uint8_t *p = nullptr; size_t n = 0; bool last = false; int cbuf = -1; };
+        struct In { uint8_t *p = nullptr, *pin = nullptr; size_t n = 0; bool last = false, compressed = false; int cbuf = -1; };
         CBuf cbufs[NBUF];
         In bufs[NBUF];
         auto pinned = [&](size_t bytes) -> uint8_t * {
@@ -1117,11 +1118,20 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
             guard.pinned.push_back(q);
             return (uint8_t *)q;
         };
+        // FADE_BAM_DEVICE_SHARE=n: with the pool inflating, every n-th call's members go to the device as they are (inflated by
+        // the kernel of FADE_BAM_INFLATE=device): the cores are the bottleneck of a file-to-file run once the device's half is
+        // fast, and the device has time to spare for a share of the inflating.  0: none.
+        const int dev_share = host_inflate ? std::max(0, getenv("FADE_BAM_DEVICE_SHARE") ? atoi(getenv("FADE_BAM_DEVICE_SHARE")) : 0) : 0;
+        std::atomic<int> cbuf_refs[NBUF];
+        for (auto &r : cbuf_refs) r = 0;
         for (int k = 0; k < NBUF; k++) {
             if (host_inflate) {
-                cbufs[k].own.resize(HEAD + ccap + 64);
-                cbufs[k].p = cbufs[k].own.data();
-                bufs[k].p = pinned(chunk + 65536 + 64);
+                if (dev_share) cbufs[k].p = pinned(HEAD + ccap + 64);  // (some of its members cross PCIe as they are)
+                else {
+                    cbufs[k].own.resize(HEAD + ccap + 64);
+                    cbufs[k].p = cbufs[k].own.data();
+                }
+                bufs[k].pin = bufs[k].p = pinned(chunk + 65536 + 64);
             } else {
                 cbufs[k].p = pinned(HEAD + ccap + 64);  // (handed to front as they are: pinned)
             }
@@ -1208,6 +1218,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                 std::vector<Mem> ms;
                 int ck;
                 bool ended = false;
+                unsigned batch_no = 0;
                 while (!ended && !abort_all && q_cfull.pop(ck)) {
                     CBuf &c = cbufs[ck];
                     if (tail.size() > HEAD) throw std::runtime_error("BGZF member larger than 64 KiB in " + path);
@@ -1231,12 +1242,27 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                     }
                     // host mode: batches of members whose payloads fill a pinned buffer
                     size_t m0 = 0;
+                    cbuf_refs[ck] = 1;  // (this thread's own hold on the compressed bytes)
                     do {
                         size_t total = 0, m1 = m0;
                         while (m1 < ms.size() && total + ms[m1].isz <= chunk) total += ms[m1++].isz;
                         int slot;
                         if (!q_free.pop(slot)) { ended = true; break; }
                         In &b = bufs[slot];
+                        b.p = b.pin;
+                        b.compressed = false;
+                        // a call of the device's share: the members as they lie (never the run's last call, whose tail a lane trims here)
+                        if (dev_share && m1 > m0 && ++batch_no % (unsigned)dev_share == 0 && !(ended && m1 == ms.size())) {
+                            b.p = cb + ms[m0].off;
+                            b.n = ms[m1 - 1].off + ms[m1 - 1].size - ms[m0].off;
+                            b.last = false;
+                            b.compressed = true;
+                            b.cbuf = ck;
+                            cbuf_refs[ck]++;
+                            q_full.push(slot);
+                            m0 = m1;
+                            continue;
+                        }
                         std::vector<size_t> ooff(m1 - m0 + 1, 0);
                         for (size_t j = m0; j < m1; j++) ooff[j - m0 + 1] = ooff[j - m0] + ms[j].isz;
                         std::atomic<bool> bad{false};
@@ -1280,7 +1306,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                         q_full.push(slot);
                         m0 = m1;
                     } while (m0 < ms.size());
-                    q_cfree.push(ck);  // (inflated: the compressed bytes are done with)
+                    if (--cbuf_refs[ck] == 0) q_cfree.push(ck);  // (inflated: the compressed bytes are done with, unless a call of the device's share still reads them)
                 }
             } catch (const std::exception &e) {
                 set_err(e.what());
@@ -1316,7 +1342,9 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         // records start (the header has been flushed by then); the file offset is set behind the last byte at the end.
         std::atomic<long long> placed_base{-1};
         std::atomic<uint64_t> placed_bytes{0};
-        const int n_wr = std::max(1, std::min(8, getenv("FADE_BAM_WRITERS") ? atoi(getenv("FADE_BAM_WRITERS")) : 4));
+        // (FADE_BAM_WRITERS=n: off by default — measured on the GPU box, four pwrites side by side into one file took 0.21-0.23 s
+        // per 1.6 GB against 0.18 s front to back: buffered writes to one inode serialise in the kernel)
+        const int n_wr = std::max(1, std::min(8, getenv("FADE_BAM_WRITERS") ? atoi(getenv("FADE_BAM_WRITERS")) : 1));
         stages.th.emplace_back([&] {  // writer
             OutRef r;
             bool ok = true;
@@ -1379,7 +1407,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
             struct stat so;
             const int fl = fcntl(1, F_GETFL);
             if (fflush(stdout) == 0 && fstat(1, &so) == 0 && S_ISREG(so.st_mode) && fl >= 0 && !(fl & O_APPEND) &&
-                !(getenv("FADE_BAM_WRITERS") && atoi(getenv("FADE_BAM_WRITERS")) == 0)) {
+                getenv("FADE_BAM_WRITERS") && atoi(getenv("FADE_BAM_WRITERS")) > 1) {
                 const off_t b = lseek(1, 0, SEEK_CUR);
                 if (b >= 0) placed_base = (long long)b;
             }
@@ -1388,11 +1416,14 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         bool failed = false;
         while (!failed && !abort_all && q_full.pop(k)) {
             ck_front.start();
-            const int rc = host_inflate ? fadehip_bam_front_raw(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0)
-                                        : fadehip_bam_front(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0);
+            const int rc = (host_inflate && !bufs[k].compressed) ? fadehip_bam_front_raw(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0)
+                                                                 : fadehip_bam_front(st, bufs[k].p, bufs[k].n, bufs[k].last ? 1 : 0);
             ck_front.stop();
             if (rc) { set_err(std::string("device: ") + fadehip_last_error(ctx)); failed = true; break; }
-            if (bufs[k].cbuf >= 0) q_cfree.push(bufs[k].cbuf);  // (device mode: the compressed bytes have been copied up)
+            if (bufs[k].cbuf >= 0) {  // (the compressed bytes have been copied up)
+                if (!host_inflate) q_cfree.push(bufs[k].cbuf);
+                else if (--cbuf_refs[bufs[k].cbuf] == 0) q_cfree.push(bufs[k].cbuf);
+            }
             q_free.push(k);
             q_done.push(0);
         }

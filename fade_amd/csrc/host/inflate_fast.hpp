@@ -2,8 +2,10 @@
 //
 // A BGZF block is a complete <= 64 KiB DEFLATE stream whose uncompressed size is known up front (ISIZE), so the
 // decoder writes straight into the caller's buffer with exact bounds: 64-bit bit buffer refilled eight bytes at a
-// time, 10-bit primary / secondary tables for the literal-length code, 8-bit for the distance code, word-wise match
-// copies.  Every table index, back-reference and output position is checked: corrupt input returns false, it never
+// time, 11-bit primary / secondary tables for the literal-length code, 8-bit for the distance code, word-wise match
+// copies.  A primary entry whose index holds TWO whole literal codes yields both at once (BAM payload is literals mostly —
+// packed bases and qualities at 4-6 bits a code — so a look-up, the unit of the decoder's dependent chain, then moves two
+// bytes).  Every table index, back-reference and output position is checked: corrupt input returns false, it never
 // reads or writes outside [in, in + in_len) / [out, out + out_len) (the caller's BgzfIn also checks the CRC32).
 //
 // Not derived from zlib/libdeflate sources; follows RFC 1951 only.
@@ -103,14 +105,22 @@ private:
         }
     }
 
-    static constexpr int LIT_BITS = 10, DIST_BITS = 8;
+    static constexpr int LIT_BITS = 11, DIST_BITS = 8;
     // entry: bits 0-7 code length to consume (sub-table pointer: primary bits), 8-11 kind, 12-15 extra bits or
-    // sub-table index bits, 16-31 literal value / base / sub-table offset
+    // sub-table index bits (a literal entry: how many literals it holds, 1 or 2), 16-31 literal value(s, the first in the
+    // low byte) / base / sub-table offset
     static constexpr uint32_t K_LIT = 1u << 8, K_LEN = 2u << 8, K_EOB = 3u << 8, K_SUB = 4u << 8, K_DIST = 5u << 8, K_MASK = 15u << 8;
     static constexpr int DYN_LIT_SIZE = (1 << LIT_BITS) + 32 * 288, DYN_DIST_SIZE = (1 << DIST_BITS) + 128 * 32;
     static constexpr int FIX_LIT_SIZE = (1 << LIT_BITS) + 32, FIX_DIST_SIZE = (1 << DIST_BITS) + 32;
 
     static inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+    // the literal(s) of entry e: both bytes are stored (the second is scratch when the entry holds one; callers keep room
+    // for it), the pointer moves by the entry's count
+    static inline __attribute__((always_inline)) void put2(uint8_t *&op, uint32_t e) {
+        const uint16_t v = (uint16_t)(e >> 16);
+        memcpy(op, &v, 2);
+        op += (e >> 12) & 3u;
+    }
     inline void refill() {
         if (iend_ - ip_ >= 8) {
             bb_ |= load64(ip_) << bc_;
@@ -175,7 +185,7 @@ private:
                 if (l[sym] != len) continue;
                 uint32_t e;
                 if (litlen) {
-                    if (sym < 256) e = ((uint32_t)sym << 16) | K_LIT;
+                    if (sym < 256) e = ((uint32_t)sym << 16) | (1u << 12) | K_LIT;
                     else if (sym == 256) e = K_EOB;
                     else if (sym < 286) e = ((uint32_t)LBASE[sym - 257] << 16) | ((uint32_t)LX[sym - 257] << 12) | K_LEN;
                     else e = 0;  // 286, 287 never appear in valid data: decoding them fails
@@ -201,6 +211,22 @@ private:
                 code++;
             }
             code <<= 1;
+        }
+        if (litlen) {
+            // two literals per entry where the index holds both codes whole: entry i = literal of l1 bits, and the bits
+            // behind it (i >> l1, whose top l1 bits are not the stream's) select a literal of at most primary - l1 bits
+            uint32_t *const two = pair_tmp_;
+            for (int i = 0; i < psize; i++) {
+                const uint32_t e = tab[i];
+                two[i] = e;
+                if ((e & K_MASK) != K_LIT) continue;
+                const uint32_t l1 = e & 255u;
+                if (l1 >= (uint32_t)primary) continue;
+                const uint32_t f = tab[(uint32_t)i >> l1];
+                if ((f & K_MASK) != K_LIT || (f & 255u) + l1 > (uint32_t)primary) continue;
+                two[i] = (((f >> 16) & 255u) << 24) | (e & 0x00ff0000u) | (2u << 12) | K_LIT | (l1 + (f & 255u));
+            }
+            for (int i = 0; i < psize; i++) tab[i] = two[i];
         }
         return true;
     }
@@ -285,22 +311,22 @@ private:
         // Fast loop while a whole worst-case step fits on both sides: >= 8 input bytes for the word refill, room for
         // three literals and a 258-byte match with its 8-byte copy overshoot.  One refill (>= 56 bits) serves up to
         // three literals (<= 45 bits); a length / distance pair (<= 48 bits) refills first if fewer are left.
-        while (iend_ - ip_ >= 8 && oend - op >= 3 + 258 + 8) {
+        while (iend_ - ip_ >= 8 && oend - op >= 7 + 258 + 8) {
             bb_ |= load64(ip_) << bc_;
             ip_ += (63 - bc_) >> 3;
             bc_ |= 56;
             uint32_t e = lit[(uint32_t)bb_ & ((1u << LIT_BITS) - 1u)];
-            if ((e & K_MASK) == K_LIT) {
+            if ((e & K_MASK) == K_LIT) {  // (one or two literals: both bytes are stored, the pointer moves by the count)
                 drop((int)(e & 255u));
-                *op++ = (uint8_t)(e >> 16);
+                put2(op, e);
                 e = lit[(uint32_t)bb_ & ((1u << LIT_BITS) - 1u)];
                 if ((e & K_MASK) == K_LIT) {
                     drop((int)(e & 255u));
-                    *op++ = (uint8_t)(e >> 16);
+                    put2(op, e);
                     e = lit[(uint32_t)bb_ & ((1u << LIT_BITS) - 1u)];
                     if ((e & K_MASK) == K_LIT) {
                         drop((int)(e & 255u));
-                        *op++ = (uint8_t)(e >> 16);
+                        put2(op, e);
                         continue;
                     }
                 }
@@ -313,8 +339,8 @@ private:
             if (cl == 0) return false;
             drop(cl);
             const uint32_t kind = e & K_MASK;
-            if (kind == K_LIT) {
-                *op++ = (uint8_t)(e >> 16);
+            if (kind == K_LIT) {  // (a sub-table literal: always one)
+                put2(op, e);
                 continue;
             }
             if (kind == K_EOB) {
@@ -372,6 +398,10 @@ private:
             if (kind == K_LIT) {
                 if (op == oend) return false;
                 *op++ = (uint8_t)(e >> 16);
+                if (((e >> 12) & 3u) == 2u) {
+                    if (op == oend) return false;
+                    *op++ = (uint8_t)(e >> 24);
+                }
                 continue;
             }
             if (kind == K_EOB) break;
@@ -435,7 +465,7 @@ private:
         c.bc -= cl;
         const uint32_t kind = e & K_MASK;
         if (kind == K_LIT) {
-            *c.op++ = (uint8_t)(e >> 16);
+            put2(c.op, e);
             return 0;
         }
         if (kind == K_EOB) return 1;
@@ -498,8 +528,8 @@ private:
         constexpr uint32_t M = (1u << LIT_BITS) - 1u;
         int flags = 0;
         for (;;) {
-            if (!(A.iend_ - a.ip >= 8 && A.oend_ - a.op >= 3 + 258 + 8)) flags |= F_A_CAREFUL;
-            if (!(B.iend_ - b.ip >= 8 && B.oend_ - b.op >= 3 + 258 + 8)) flags |= F_B_CAREFUL;
+            if (!(A.iend_ - a.ip >= 8 && A.oend_ - a.op >= 7 + 258 + 8)) flags |= F_A_CAREFUL;
+            if (!(B.iend_ - b.ip >= 8 && B.oend_ - b.op >= 7 + 258 + 8)) flags |= F_B_CAREFUL;
             if (flags) break;
             a.bb |= load64(a.ip) << a.bc;
             a.ip += (63 - a.bc) >> 3;
@@ -508,20 +538,20 @@ private:
             b.ip += (63 - b.bc) >> 3;
             b.bc |= 56;
             uint32_t ea = la[(uint32_t)a.bb & M], eb = lb[(uint32_t)b.bb & M];
-            // up to three literals from each stream per refill (<= 45 of >= 56 bits), the two chains side by side
+            // up to three look-ups (six literals) from each stream per refill (<= 3 x 15 of >= 56 bits), the two chains side by side
             if (((ea & K_MASK) == K_LIT) & ((eb & K_MASK) == K_LIT)) {
-                a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); *a.op++ = (uint8_t)(ea >> 16);
-                b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); *b.op++ = (uint8_t)(eb >> 16);
+                a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); put2(a.op, ea);
+                b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); put2(b.op, eb);
                 ea = la[(uint32_t)a.bb & M];
                 eb = lb[(uint32_t)b.bb & M];
                 if (((ea & K_MASK) == K_LIT) & ((eb & K_MASK) == K_LIT)) {
-                    a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); *a.op++ = (uint8_t)(ea >> 16);
-                    b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); *b.op++ = (uint8_t)(eb >> 16);
+                    a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); put2(a.op, ea);
+                    b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); put2(b.op, eb);
                     ea = la[(uint32_t)a.bb & M];
                     eb = lb[(uint32_t)b.bb & M];
                     if (((ea & K_MASK) == K_LIT) & ((eb & K_MASK) == K_LIT)) {
-                        a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); *a.op++ = (uint8_t)(ea >> 16);
-                        b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); *b.op++ = (uint8_t)(eb >> 16);
+                        a.bb >>= (ea & 63u); a.bc -= (int)(ea & 255u); put2(a.op, ea);
+                        b.bb >>= (eb & 63u); b.bc -= (int)(eb & 255u); put2(b.op, eb);
                         continue;
                     }
                 }
@@ -546,6 +576,7 @@ private:
     int bc_ = 0;
     const uint32_t *lit_ = nullptr, *dist_ = nullptr;
     bool fixed_built_ = false;
+    uint32_t pair_tmp_[1 << LIT_BITS];
     uint32_t dyn_lit_[DYN_LIT_SIZE], dyn_dist_[DYN_DIST_SIZE];
     uint32_t fix_lit_[FIX_LIT_SIZE], fix_dist_[FIX_DIST_SIZE];
 };

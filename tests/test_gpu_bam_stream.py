@@ -168,6 +168,20 @@ def test_records_that_straddle_members_and_calls(big, chunk_mb, inflate):
     assert stats(dev.stderr) == stats(big["host"].stderr)
 
 
+@pytest.mark.parametrize("share,chunk_mb", [("2", "1"), ("3", "1"), ("2", "64")])
+def test_the_pool_and_the_device_share_the_inflating(big, share, chunk_mb):
+    """FADE_BAM_DEVICE_SHARE=n: the pool inflates, but every n-th call's members cross PCIe as they are and are inflated by the
+    kernel — calls of both kinds alternate on one stream (fadehip_bam_front / fadehip_bam_front_raw), records straddle them.
+    Same bytes as the host pipeline."""
+    dev = _run(["annotate", "--stats", "--timing", "-w", "100", "-b", str(big["bam"]), str(big["fa"])],
+               {"FADE_BAM_CHUNK_MB": chunk_mb, "FADE_BAM_INFLATE": "host", "FADE_BAM_DEVICE_SHARE": share})
+    assert dev.returncode == 0, dev.stderr.decode()[-2000:]
+    assert b"file path on the device" in dev.stderr
+    assert gzip.decompress(dev.stdout) == gzip.decompress(big["host"].stdout)
+    stats = lambda err: [l for l in err.decode().splitlines() if l.startswith(("read count", "Clipped", "% With", "Artifact"))]
+    assert stats(dev.stderr) == stats(big["host"].stderr)
+
+
 @pytest.mark.parametrize("inflate", ["device", "host"])
 def test_a_slow_reader_of_the_output_gets_the_same_bytes(big, inflate):
     """The output through a pipe that is drained slowly, in many small calls: the back half runs ahead of the writer, and

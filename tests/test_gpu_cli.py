@@ -352,7 +352,7 @@ def test_cli_out_shards_every_lane_a_complete_file(lanes_bam):
     d = lanes_bam["dir"]
     prefix = str(d / "shard")
     p = subprocess.run([FADE, "annotate", "--stats", "--timing", "--gpus", "6", "--out-shards", prefix, "-w", "100", "-b", lanes_bam["bam"], lanes_bam["fa"]],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, FADE_DEVICE_MAP="0,0,0,0,0,0"))
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, FADE_DEVICE_MAP="0,0,0,0,0,0", FADE_LANES_LIVE="3"))
     assert p.returncode == 0, p.stderr.decode()[-2500:]
     assert p.stdout == b"" and b"a complete file per lane, nothing merged" in p.stderr
     text1, recs1 = _bam_payload(lanes_bam["one"])
