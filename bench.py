@@ -461,7 +461,10 @@ def main():
 
     if rank == 0:
         R = fade_amd._lib.row_class(cfg["read_len"])
-        kernel = "sw_pk_kernel<%d,1> (score pass)" % R
+        # reads of up to 152 bases in the 160-row class run on eight-lane groups x 19 rows since round 4 (FADEHIP_SCORE_G8=0: sixteen x 10)
+        g8 = R == 10 and cfg["read_len"] <= 152 and os.environ.get("FADEHIP_SCORE_G8", "1") != "0"
+        kernel = "sw_pk_kernel<19,1,LG=8> (score pass: 8 lanes x 19 rows per alignment pair, 16 alignments per wavefront)" if g8 else "sw_pk_kernel<%d,1> (score pass)" % R
+        kpat = "sw_pk_kernel<19, 1" if g8 else "sw_pk_kernel<%d, 1" % R
         fwd_streamed = float(np.mean([p["forward_ms"] for p in profs]))  # every fourth launch of the timed region, slots sharing the device
         fwd = float(np.mean([p["forward_ms"] for p in solo]))            # launches that had the device to themselves
         units = float(np.mean([p["alignments"] for p in solo]))
@@ -475,7 +478,7 @@ def main():
         pk = None
         if pmc:
             for name, k in pmc["kernels"].items():
-                if "sw_pk_kernel<%d, 1>" % R in name:
+                if kpat in name:
                     pk = k
         out = {
             "metric": "annotate reads/sec at 1/2/4/8 MI355X; rs/am tag bit-exact vs ref",

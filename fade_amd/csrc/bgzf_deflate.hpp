@@ -1,40 +1,40 @@
 // bgzf_deflate.hpp — BGZF (SAM spec §4.1) compression on gfx950: one workgroup per BGZF block, the whole block resident in
-// LDS, in two geometries (below: 0xff00-byte blocks, 160 KB, one workgroup of 512 threads per CU; 0x7f00-byte blocks, 80 KB,
-// two workgroups of 384 threads per CU).  A block's time is set by the serial roles of phase A (one wave each), so what a
-// CU gains from a second block is a second pipeline.
+// LDS, in two geometries with a phase A of their own each (below).
 //
 // What it replaces: htslib's bgzf_write -> zlib deflate behind `SAMWriter(..., SAMWriterTypes.BAM)` (source/util.d:65-76),
 // i.e. the serialised write at source/anno.d:47-49 — 7 of the 12.7 core-seconds `fade annotate` spent per 10 M reads.
 //
-// Per block (host/selftest/gpu_deflate_model.cpp is the same algorithm on the CPU, checked with zlib's inflate):
-//   A  matches, as a pipeline of wave roles over pieces of 64 positions (bgzf_deflate_body.hpp): a hasher walks the pieces
-//      through the hash heads (4-way buckets of 16-bit positions: a piece's lookups see every earlier piece's inserts),
-//      extenders try those four candidates and the distances 1..8 side by side in LDS, a parser takes the pieces in order and
-//      parses greedily (a match yields to a longer one at the next position) on 64-bit lane masks in scalar registers:
-//      token bitmap, match bitmap, match records.
+// Per block (host/selftest/gpu_deflate_model.cpp is the algorithm of the smaller geometry on the CPU, checked with zlib's
+// inflate; it reproduces the device's output byte for byte):
+//   A  matches and the parse over pieces of 64 positions: token bitmap, match bitmap, match records.
+//        0x7f00-byte blocks (bgzf_deflate_body.hpp): the pieces in eight contiguous segments, a wave each — own hash table
+//        (384 buckets of four 16-bit positions, the KB in front of the segment entered first), candidates = the bucket's four
+//        and the nearest of the distances 1..8, extended side by side in LDS, greedy parse with one step of laziness on
+//        64-bit lane masks; a match cut at its segment's end is lengthened again at the seam.  No wave waits for another.
+//        0xff00-byte blocks (bgzf_deflate_roles.hpp): round 3's pipeline of wave roles — one hasher over ONE table for the
+//        whole block, six extenders, one parser, rings between them: every match of the block in reach, half the rate.
 //   B  symbol histograms (8 sub-histograms against same-address LDS atomics), minimum-redundancy code lengths (Moffat &
-//      Katajainen in place, the array spread over the lanes of a wave), 15-bit limit, canonical codes.
-//   C  the dynamic-block header, one wave (lane arrays again), while the others count their tokens' bits.
+//      Katajainen in place), 15-bit limit, canonical codes; the waves that have no part in the code lengths sum the CRC-32
+//      meanwhile (slicing-by-4 over a piece per thread, combined with the x^(8n) mod P arithmetic of bgzf_huff.hpp).
+//   C  the dynamic-block header, in parallel, while the others count their tokens' bits.
 //   D  the threads' position ranges emit their tokens at scanned bit offsets straight into the block's output slot; a word that
 //      two ranges share is OR-ed atomically.  A block that would not shrink is stored.
-//   CRC-32 of the input by slicing-by-4 over a piece per thread, combined with the x^(8n) mod P arithmetic of bgzf_huff.hpp.
 // A second kernel scans the block sizes and a third assembles the BGZF members (header, payload, CRC32, ISIZE) into one
-// contiguous byte stream: what goes to the file.
+// contiguous byte stream — in pinned host memory: what goes to the file.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "bgzf_huff.hpp"
 
-// Two geometries of the same kernels.  64: htslib's 0xff00-byte blocks, the block and its tables fill the CU's LDS, one
-// workgroup per CU — the smallest output (a block's dynamic-Huffman header and its cold start weigh half as much).  32:
-// 0x7f00-byte blocks, 80 KB of LDS, two workgroups per CU — a block's time is set by the serial roles of phase A, so a CU
-// gains a second pipeline (9.8 -> 14.6 GB/s, 18 GB/s in the kernel) and other kernels can share a CU with a compressor;
-// the output is 0.5 % larger on uniform-quality BAM payload and 1 % larger where qualities run (there a member shrinks
-// to 8 KB and its header shows).  fadehip.hip picks per call: 32 while the stream is mostly incompressible bases
-// (ratio above 0.45), 64 otherwise, so that the output stays below zlib -6's in both regimes.
+// Two geometries.  64: htslib's 0xff00-byte blocks, the block and its tables fill the CU's LDS, one workgroup per CU, the
+// role pipeline — the smallest output (9.8 GB/s of payload).  32: 0x7f00-byte blocks, 80 KB of LDS, two workgroups of eight
+// waves per CU, phase A on per-wave segments (19 GB/s); the output is 0.6 % larger on uniform-quality BAM payload than the
+// other geometry's and 1-2 % larger where qualities run.  fadehip.hip picks per call: 32 while the stream is mostly
+// incompressible bases (ratio above 0.45: there zlib -6 is 2 % behind either), 64 otherwise, so that the output stays
+// below zlib -6's in both regimes (tests/test_gpu_bgzf.py).
 #define FADEHIP_BGZF_GEOM 64
 #define FADEHIP_BGZF_NS bgzf64
-#include "bgzf_deflate_body.hpp"
+#include "bgzf_deflate_roles.hpp"
 #undef FADEHIP_BGZF_GEOM
 #undef FADEHIP_BGZF_NS
 #define FADEHIP_BGZF_GEOM 32

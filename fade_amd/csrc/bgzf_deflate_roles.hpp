@@ -1,29 +1,25 @@
-// bgzf_deflate_body.hpp — the compressor's kernels for one block geometry (FADEHIP_BGZF_GEOM = 64 or 32, namespace
-// FADEHIP_BGZF_NS): included twice by bgzf_deflate.hpp.  No include guard on purpose.
+// bgzf_deflate_roles.hpp — the compressor as a pipeline of wave roles (round 3's phase A: a hasher, extenders, ONE parser,
+// rings between them), kept for the 0xff00-byte geometry: one hash table over the whole block, i.e. every match the block
+// holds is in reach — the smallest output, at 9.8 GB/s.  The geometry is taken where the stream compresses well (bgzf_deflate.hpp);
+// where it hardly does, bgzf_deflate_body.hpp (phase A on per-wave segments, twice the rate) serves.  Included by
+// bgzf_deflate.hpp with FADEHIP_BGZF_GEOM / FADEHIP_BGZF_NS set.  No include guard on purpose.
 
 namespace fadehip {
 namespace FADEHIP_BGZF_NS {
 using namespace ::fadehip::bgzf;  // bgzf_huff.hpp's serial helpers
 
 #if FADEHIP_BGZF_GEOM == 64
-// htslib's block size; the block takes the CU's whole LDS: one workgroup of eight waves per CU
-constexpr int BLOCK = 0xff00, DATA_BYTES = 65536, WG = 512, MIN_WAVES_PER_SIMD = 2, N_BUCKETS = 512, MAX_MATCHES = 8192 + 2560;
+// htslib's block size; the block takes the CU's whole LDS: one workgroup of eight waves (hasher, six extenders, parser) per CU
+constexpr int BLOCK = 0xff00, DATA_BYTES = 65536, WG = 512, MIN_WAVES_PER_SIMD = 2, HASH_BITS = 12, MAX_MATCHES = 8192, R2 = 24;
 #else
-// half of it: 80 KB of LDS, TWO workgroups of eight waves per CU at 128 VGPRs: all of a SIMD's four wave slots.  (Six
-// waves per workgroup — a slot per SIMD left to the file path's other kernels, as round 3 had it — were measured too: the
-// compressor alone 18.1 instead of 19.7 GB/s, and the kernels that then run beside it crawl — pack_write 0.97 ms instead
-// of 0.03, rewrite 1.35 instead of 0.23 — so that a call's device time is the same either way; tools/r04/stream_timeline.py.)
-constexpr int BLOCK = 0x7f00, DATA_BYTES = 32768, WG = 512, MIN_WAVES_PER_SIMD = 4, N_BUCKETS = 384, MAX_MATCHES = 2560;
+// half of it: 80 KB of LDS, TWO workgroups of six waves (hasher, four extenders — six waited two thirds of the time —, parser)
+// per CU, which takes four waves per SIMD, i.e. 128 VGPRs (38 spilled, outside the roles' loops)
+constexpr int BLOCK = 0x7f00, DATA_BYTES = 32768, WG = 384, MIN_WAVES_PER_SIMD = 4, HASH_BITS = 11, MAX_MATCHES = 3072, R2 = 8;
 #endif
 constexpr int DIST_T0 = 320;  // threads DIST_T0 .. + 29 serve the distance alphabet where the first 286 serve literals / lengths
 constexpr int N_WAVES = WG / 64;
 constexpr int WAYS = 4;
-// phase A runs on segments, a wave each with a hash table of its own: N_BUCKETS buckets of WAYS 16-bit positions (what a
-// wave can reach back to: the last N_BUCKETS * WAYS positions on average)
-constexpr int HEAD_WAVE_BYTES = N_BUCKETS * WAYS * 2;
-constexpr int HEAD_BYTES = HEAD_WAVE_BYTES * N_WAVES;
-constexpr int SEG_CAP = MAX_MATCHES / N_WAVES;  // match records a segment may leave (more: literals from there on)
-constexpr int SEED_PIECES = 16;                 // pieces in front of a segment whose positions are hashed for it (1 KB of history)
+constexpr int HEAD_BYTES = (1 << HASH_BITS) * WAYS * 2;
 constexpr int MIN_MATCH = 4, MAX_MATCH = 258;
 constexpr int N_WORDS = (BLOCK + 31) / 32;   // words of a per-position bitmap
 constexpr int WPT = (N_WORDS + WG - 1) / WG;  // ... per thread in the per-range phases (a range = 64 positions)
@@ -31,18 +27,19 @@ constexpr int SLOT = 65536;                  // bytes of a block's output slot (
 constexpr int MAX_PAYLOAD = 65536 - 26;
 
 // LDS layout (bytes)
+constexpr int R1 = 8;  // (R2 above) slots of phase A's candidate ring (64 x 8 bytes each) and length ring (64 x 4)
 constexpr int BITMAP_BYTES = ((N_WORDS * 4 + 255) / 256) * 256;
 constexpr int L_DATA = 0, L_HEAD = DATA_BYTES, L_MATCH = L_HEAD + HEAD_BYTES, L_TOK = L_MATCH + MAX_MATCHES * 4, L_MAT = L_TOK + BITMAP_BYTES,
-              L_MISC = L_MAT + BITMAP_BYTES, LDS_BYTES = L_MISC + 6144;
+              L_MISC = L_MAT + BITMAP_BYTES, L_CRING = L_MISC + 6144, L_LRING = L_CRING + R1 * 512, LDS_BYTES = L_LRING + R2 * 256;
 static_assert(LDS_BYTES <= (FADEHIP_BGZF_GEOM == 64 ? 160 : 80) * 1024, "the workgroups of a CU must fit its LDS");
 static_assert(BLOCK % 16 == 0 && BLOCK + 256 <= DATA_BYTES && BLOCK < 65535, "block size");
 // ... of the head region once the matches are found; the CRC tables go where the match records were once they are emitted
 constexpr int H_H8 = 0, H_AL = H_H8 + 8 * 320 * 4, H_SL = H_AL + 320 * 4, H_AD = H_SL + 320 * 4, H_SD = H_AD + 64 * 4, H_END = H_SD + 64 * 4;
-static_assert(H_END + 4096 <= HEAD_BYTES, "phase B temporaries and the CRC tables must fit the hash region");
+static_assert(H_END <= HEAD_BYTES, "phase B temporaries must fit the hash region");
+static_assert(4096 <= MAX_MATCHES * 4, "the CRC tables must fit the match region");
 
 struct Misc {  // the small arrays of a block
     uint32_t abort, dbg[3], carry, mcount, full, blk, m_l, m_d, hdr_bits, total_bits, stored, pad[3];
-    uint32_t seg_mcount[N_WAVES], seg_prefix[N_WAVES + 1];  // match records per segment of phase A; ... of the segments in front
     uint32_t freq_l[320], freq_d[64];
     uint8_t ll[320], dl[64];
     uint16_t lc[320], dc[64];
@@ -52,6 +49,8 @@ struct Misc {  // the small arrays of a block
     uint32_t sortbuf[64];
     uint32_t wtmp[N_WAVES];
     uint32_t crc_part[N_WAVES];
+    // phase A's rings (see there): sequence / free numbers per slot, the extenders' ticket
+    uint32_t cand_seq[R1], cand_free[R1], lens_seq[R2], lens_free[R2], ext_ticket;
     // the header's run-length tokens (symbol | extra << 8) and the code-length alphabet
     uint16_t cltok[320];
     uint32_t cl_freq[NUM_CL + 1], cl_len[NUM_CL + 1], cl_code[NUM_CL + 1], cl_n, cl_hlit, cl_hdist, cl_hclen;
@@ -78,15 +77,44 @@ __device__ __forceinline__ uint64_t lds_load64u(const uint8_t *base, uint32_t p)
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
     return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, p & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, p & 3u) << 32);
 }
-__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (((v * 0x9E3779B1u) >> 16) * (uint32_t)N_BUCKETS) >> 16; }
+__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
 
-// the next ticket of a wave-shared counter, as a wave-uniform value (kept out of line: inlined into a loop the claim was
-// once hoisted around the loop's exec-mask bookkeeping and a back edge re-used a stale ticket)
+// Waits for *turn == v.  Every wait of the pipeline is bounded: a wait that outlasts SPIN_LIMIT polls (a hundred times
+// the longest legitimate one) raises the block's abort flag, which ends every other wait and every role's loop too, so
+// that the workgroup always drains; the block is then reported as failed (out_size = ~0) instead of hanging the device.
+constexpr uint32_t SPIN_LIMIT = 1u << 18;
+// (Every value the loop branches on goes through v_readfirstlane: the waits are wave-uniform by construction, and the
+// compiler must know it — with per-lane exit conditions it nests the roles' loops around exec masks, and a back edge of
+// that nest re-used a stale ticket: two extenders on one piece.)
+__device__ __forceinline__ bool spin_until(uint32_t *turn, uint32_t v, uint32_t *abort_flag, uint32_t who) {
+    uint32_t polls = 0;
+    for (;;) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (x == v) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 255u) == 0) {
+            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+            if (polls >= SPIN_LIMIT) {
+                abort_flag[1] = x;  // (dbg: what it saw ...
+                abort_flag[2] = v;  //  ... and wanted)
+                abort_flag[3] = (uint32_t)(threadIdx.x >> 6);
+                __hip_atomic_store(abort_flag, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return false;
+            }
+        }
+    }
+}
+// the next ticket of a wave-shared counter, as a wave-uniform value (kept out of line: inlined into the extenders' loop the
+// claim was hoisted around the loop's exec-mask bookkeeping and a back edge re-used a stale ticket)
 __device__ __noinline__ int claim_ticket(uint32_t *counter) {
     uint32_t tk = 0;
     if ((threadIdx.x & 63) == 0) tk = atomicAdd(counter, 1u);
     return __builtin_amdgcn_readlane((int)tk, 0);
 }
+__device__ __forceinline__ void publish(uint32_t *turn, uint32_t v) {
+    __hip_atomic_store(turn, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // exclusive scan of one value per thread over the workgroup (tmp: N_WAVES words of LDS); *total = the sum
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -177,62 +205,77 @@ __device__ __forceinline__ void token_bits(const uint8_t *data, uint32_t mw, uin
     }
 }
 
-// ---- phase A: matches and the parse of ONE SEGMENT of the block, by one wave that needs nobody else.
-// Round 3 ran phase A as a pipeline of wave roles (a hasher, extenders, ONE parser, rings with sequence numbers between
-// them): a block's time was the parser's, the other waves waited a third to two thirds of theirs, and a quarter of the
-// kernel's instructions were polls.  Now the block's pieces (64 positions each) are cut into N_WAVES contiguous segments
-// and every wave does all three steps for its own: it hashes a piece's positions into a table OF ITS OWN (the 512 bytes
-// in front of the segment first, so that the segment's first record finds the one before it), extends the candidates of
-// the positions no earlier match covers — it knows where its parse stands, the extenders of the pipeline could not —,
-// parses the piece on lane masks, and goes on.  No wait, no ring, no poll; the waves meet at the barrier behind phase A.
-// What it costs: a match cannot cross a segment's end (it is cut there, so that the next segment's parse starts at its
-// first position), and a segment's table sees only its own positions — in BAM payload matches reach one or two records
-// back, a few hundred bytes.
-struct SegArgs {
+// ---- phase A's three roles (inlined: out of line they measured a third slower)
+struct RoleArgs {
     uint8_t *data;
-    uint16_t *head;    // this wave's table
-    uint32_t *match;   // this wave's match records [SEG_CAP]
-    uint32_t *tokw, *matw;
-    int n, first_piece, end_piece, lane;
+    uint16_t *head;
+    uint32_t *match, *tokw, *matw;
+    Misc *ms;
+    uint2 *cand_ring;
+    uint32_t *lens_ring;
+    int n, n_pieces, lane;
+    unsigned long long *prof;  // optional: [60 + 2 role] clocks waited, [61 + 2 role] clocks in the role (summed over waves)
 };
-// what a segment's wave leaves for the seam behind it: the record of its last match if that match was cut at the segment's
-// end, and by how many bytes it would have gone on (phase_a_seam lengthens it again as far as the next segment's parse allows)
-struct SegOut {
-    uint32_t mcount, over_rec, over;
-};
-__device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
-    uint8_t *const data = r.data;
-    const int n = r.n, lane = r.lane;
-    const int seg_end = min(n, r.end_piece * 64);  // first position behind the segment
-    // history: the positions of the pieces just in front of the segment (another wave's) go into this wave's table
-    for (int piece = max(0, r.first_piece - SEED_PIECES); piece < r.first_piece; piece++) {
-        const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
-        if ((int)p + MIN_MATCH <= n) {
-            uint2 *bucket = reinterpret_cast<uint2 *>(r.head) + hash4(lds_load32u(data, p));
-            const uint2 bk = *bucket;
-            *bucket = make_uint2((p + 1u) | (bk.x << 16), (bk.x >> 16) | (bk.y << 16));
-        }
-    }
-    int carry = r.first_piece * 64;  // positions below it are covered by a match already taken
-    uint32_t mcount = 0, full = 0, over_rec = 0, over = 0;
-    for (int piece = r.first_piece; piece < r.end_piece; piece++) {
+__device__ __forceinline__ void role_hasher(const RoleArgs r) {
+    uint8_t *const data = r.data; uint16_t *const head = r.head; Misc *const ms = r.ms; uint2 *const cand_ring = r.cand_ring;
+    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
+        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+        const bool ok = spin_until(turn, v, ab, who);
+        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
+        return ok;
+    };
+    bool live = true;  // (wave-uniform; an aborted role runs its loop out without waiting or working)
+    for (int piece = 0; piece < n_pieces && live; piece++) {
         const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
         const bool valid = (int)p + MIN_MATCH <= n;
         const uint32_t v = valid ? lds_load32u(data, p) : 0u;
+        uint2 *bucket = reinterpret_cast<uint2 *>(head) + hash4(v);
+        const int slot = piece % R1;
+        live = timed_spin(&ms->cand_free[slot], (uint32_t)piece, &ms->abort, 0x10000000u | (uint32_t)piece);
         uint2 bk = make_uint2(0, 0);
         if (valid) {
-            uint2 *bucket = reinterpret_cast<uint2 *>(r.head) + hash4(v);
             bk = *bucket;
-            // (leaving the positions inside runs of one byte out of the table was modelled — host/selftest/gpu_deflate_model.cpp,
-            // MODEL_SKIP_RUNS — and made the output 0.3 % larger on run-heavy qualities, not smaller)
             *bucket = make_uint2((p + 1u) | (bk.x << 16), (bk.x >> 16) | (bk.y << 16));  // newest first; the oldest of the four leaves
         }
+        cand_ring[slot * 64 + lane] = bk;
+        if (lane == 0) publish(&ms->cand_seq[slot], (uint32_t)piece + 1u);
+    }
+    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 0], t_wait); atomicAdd(&r.prof[61 + 2 * 0], __builtin_readcyclecounter() - t_role0); }
+}
+__device__ __forceinline__ void role_extender(const RoleArgs r) {
+    uint8_t *const data = r.data; Misc *const ms = r.ms; uint2 *const cand_ring = r.cand_ring; uint32_t *const lens_ring = r.lens_ring;
+    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
+        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+        const bool ok = spin_until(turn, v, ab, who);
+        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
+        return ok;
+    };
+    bool live = true;
+    for (int piece = claim_ticket(&ms->ext_ticket); piece < n_pieces; piece = claim_ticket(&ms->ext_ticket)) {
+        if (!live) continue;  // (aborted: the tickets are drawn to the end, nothing else is done)
+        const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
+        const bool valid = (int)p + MIN_MATCH <= n;
+        const uint32_t v = valid ? lds_load32u(data, p) : 0u;
+        const int slot = piece % R1;
+        live = timed_spin(&ms->cand_seq[slot], (uint32_t)piece + 1u, &ms->abort, 0x20000000u | (uint32_t)piece);
+        if (!live) continue;
+        const uint2 bk = cand_ring[slot * 64 + lane];
+        if (lane == 0) publish(&ms->cand_free[slot], (uint32_t)(piece + R1));
         uint32_t len = 0, dist = 0;
-        if (valid && (int)p >= carry) {
+        // a position that an earlier match already covers can start no token: its matches are never looked at (the
+        // parse starts at `carry`, which only grows), so they need not be found either
+        const uint32_t covered_to = __hip_atomic_load(&ms->carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid && p >= covered_to) {
             const uint32_t maxlen = (uint32_t)min(MAX_MATCH, n - (int)p);
             // up to five candidates: the nearest of the distances 1 .. 8 whose four bytes agree, and the bucket's four
             // positions; their loads are issued together and they are extended side by side (one LDS round trip per
-            // eight bytes of the LONGEST match, not per candidate)
+            // four bytes of the LONGEST match, not per candidate)
             uint32_t cp[5];
             uint32_t alive = 0;
             {
@@ -278,23 +321,55 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
                 if (l > len) { len = l; dist = p - cp[k]; }
             }
         }
-        // a match ends with its segment (the next segment's parse starts at that segment's first position); what it would have
-        // had beyond is remembered for the seam
-        const uint32_t ulen = len;
-        len = min(len, (uint32_t)max(seg_end - (int)p, 0));
         if (len < (uint32_t)MIN_MATCH) len = 0;
-        // ---- the parse of this piece, on 64-bit lane masks: a match yields to a longer one at the next position
+        const int lslot = piece % R2;
+        live = timed_spin(&ms->lens_free[lslot], (uint32_t)piece, &ms->abort, 0x30000000u | (uint32_t)piece);
+        if (!live) continue;
+        lens_ring[lslot * 64 + lane] = len | (dist << 16);
+        if (lane == 0) publish(&ms->lens_seq[lslot], (uint32_t)piece + 1u);
+    }
+    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 1], t_wait); atomicAdd(&r.prof[61 + 2 * 1], __builtin_readcyclecounter() - t_role0); }
+}
+__device__ __forceinline__ void role_parser(const RoleArgs r) {
+    uint32_t *const match = r.match, *const tokw = r.tokw, *const matw = r.matw; Misc *const ms = r.ms; uint32_t *const lens_ring = r.lens_ring;
+    const int n = r.n, n_pieces = r.n_pieces, lane = r.lane;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_role0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+    auto timed_spin = [&](uint32_t *turn, uint32_t v, uint32_t *ab, uint32_t who) {
+        const unsigned long long t0 = r.prof ? __builtin_readcyclecounter() : 0ull;
+        const bool ok = spin_until(turn, v, ab, who);
+        if (r.prof) t_wait += __builtin_readcyclecounter() - t0;
+        return ok;
+    };
+    // The parser sets the block's pace (every piece passes through this one wave, carry in hand), so its round trips are
+    // taken off the chain: the next piece's (length, distance) words are fetched while this piece is parsed, the neighbour's
+    // length comes by DPP (wave_shl:1) instead of through the LDS crossbar, and a match's slot in the list is an mbcnt.
+    int carry = 0;
+    uint32_t mcount = 0, full = 0;
+    bool live = n_pieces > 0 && timed_spin(&ms->lens_seq[0], 1u, &ms->abort, 0x40000000u);
+    uint32_t lx = live ? lens_ring[lane] : 0u;
+    for (int piece = 0; piece < n_pieces && live; piece++) {
+        const int lslot = piece % R2;
+        const uint32_t len = lx & 0xffffu, dist = lx >> 16;
+        if (lane == 0) publish(&ms->lens_free[lslot], (uint32_t)(piece + R2));  // (this piece's words are in registers: its slot goes back)
+        // the next piece's words are fetched while this one is parsed
+        uint32_t lx_next = 0;
+        const int nslot = (piece + 1) % R2;
+        if (piece + 1 < n_pieces) {
+            live = timed_spin(&ms->lens_seq[nslot], (uint32_t)piece + 2u, &ms->abort, 0x40000000u | (uint32_t)(piece + 1));
+            if (live) lx_next = lens_ring[nslot * 64 + lane];
+        }
+        // a match yields to a longer one at the next position
         const uint32_t len_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
         const bool yield = len && lane < 63 && len_next > len;
         const int cb = piece * 64, nv = min(64, n - cb);
         uint64_t has = __ballot(len != 0 && !yield);
-        if (full || mcount + (uint32_t)__popcll(has) > (uint32_t)SEG_CAP) { full = 1; has = 0; }  // the segment's match list is full: literals from here on
+        if (full || mcount + (uint32_t)__popcll(has) > (uint32_t)MAX_MATCHES) { full = 1; has = 0; }  // the match list is full: literals from here on
         const uint64_t vmask = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
         // greedy: from `cur`, the next match start at or after it is taken and covers its length; what no match covers is a literal
         uint64_t matmask = 0, covered = 0;
         int cur = max(carry - cb, 0);
         const int cur0 = cur;
-        int j_last = -1;
         while (cur < nv) {
             const uint64_t rem = has & (~0ull << cur);
             if (!rem) break;
@@ -303,42 +378,24 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
             matmask |= 1ull << j;
             covered |= (e >= 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((j == 63) ? ~0ull : ((1ull << (j + 1)) - 1ull));
             cur = e;
-            j_last = j;
-        }
-        if (j_last >= 0 && cb + cur == seg_end) {  // the piece's last match reaches the segment's end: was it cut there?
-            const uint32_t cut = (uint32_t)__builtin_amdgcn_readlane((int)(ulen - len), j_last);
-            over = cut;
-            over_rec = mcount + (uint32_t)__popcll(matmask & ((1ull << j_last) - 1ull));
         }
         const uint64_t tokmask = vmask & ~covered & (cur0 >= 64 ? 0ull : (~0ull << cur0));
         if (cur < nv) cur = nv;
         if (cb + cur > carry) carry = cb + cur;
         if ((matmask >> lane) & 1ull) {
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(matmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matmask, 0u));
-            r.match[mcount + before] = dist | ((len - 3u) << 16);
+            match[mcount + before] = dist | ((len - 3u) << 16);
         }
         mcount += (uint32_t)__popcll(matmask);
         if (lane == 0) {
-            *reinterpret_cast<uint2 *>(r.tokw + 2 * piece) = make_uint2((uint32_t)tokmask, (uint32_t)(tokmask >> 32));
-            *reinterpret_cast<uint2 *>(r.matw + 2 * piece) = make_uint2((uint32_t)matmask, (uint32_t)(matmask >> 32));
+            *reinterpret_cast<uint2 *>(tokw + 2 * piece) = make_uint2((uint32_t)tokmask, (uint32_t)(tokmask >> 32));
+            *reinterpret_cast<uint2 *>(matw + 2 * piece) = make_uint2((uint32_t)matmask, (uint32_t)(matmask >> 32));
+            __hip_atomic_store(&ms->carry, (uint32_t)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        lx = lx_next;
     }
-    SegOut o;
-    o.mcount = mcount;
-    o.over_rec = over_rec;
-    o.over = over;
-    return o;
-}
-// The seam behind a segment whose last match was cut at its end by `over` bytes: the match is given back as many of them
-// as the next segment's parse allows — up to its first match start inside that stretch; the literals it then covers
-// leave the token bitmap.  One lane; runs between the barrier behind phase A and the histograms.
-__device__ __forceinline__ void phase_a_seam(uint32_t *match_rec, uint32_t over, int seg_end, int next_end, uint32_t *tokw, const uint32_t *matw) {
-    int give = min((int)over, next_end - seg_end);  // (within the next segment: its bitmap words are this seam's alone)
-    for (int q = seg_end; q < seg_end + give; q++)
-        if ((matw[q >> 5] >> (q & 31)) & 1u) { give = q - seg_end; break; }
-    if (give <= 0) return;
-    for (int q = seg_end; q < seg_end + give; q++) tokw[q >> 5] &= ~(1u << (q & 31));
-    *match_rec += (uint32_t)give << 16;
+    if (lane == 0) ms->mcount = mcount;
+    if (r.prof && lane == 0) { atomicAdd(&r.prof[60 + 2 * 2], t_wait); atomicAdd(&r.prof[61 + 2 * 2], __builtin_readcyclecounter() - t_role0); }
 }
 
 __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(DeflateArgs a) {
@@ -349,13 +406,12 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
     uint32_t *const tokw = reinterpret_cast<uint32_t *>(lds + L_TOK);
     uint32_t *const matw = reinterpret_cast<uint32_t *>(lds + L_MAT);
     Misc *const ms = reinterpret_cast<Misc *>(lds + L_MISC);
+    uint2 *const cand_ring = reinterpret_cast<uint2 *>(lds + L_CRING);
+    uint32_t *const lens_ring = reinterpret_cast<uint32_t *>(lds + L_LRING);
     uint32_t *const h8 = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_H8);
     uint32_t *const A_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AL), *const S_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SL);
     uint32_t *const A_d = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AD), *const S_d = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SD);
-    // the CRC tables (slicing by 4: 4 KB) live behind phase B's temporaries in what were the hash tables: they are built on
-    // the way through phase B, and the CRC itself is summed by the waves that would otherwise idle while one lane per
-    // alphabet makes the code lengths
-    uint32_t *const crct = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_END);
+    uint32_t *const crct = reinterpret_cast<uint32_t *>(lds + L_MATCH);  // (after phase D)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if (tid == 0) crc_x2n_table(ms->x2n);
@@ -391,39 +447,46 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             for (int k = tid; k < HEAD_BYTES / 16; k += WG) z[k] = make_uint4(0, 0, 0, 0);
             uint4 *zb = reinterpret_cast<uint4 *>(lds + L_TOK);
             for (int k = tid; k < 2 * BITMAP_BYTES / 16; k += WG) zb[k] = make_uint4(0, 0, 0, 0);
-            if (tid == 0) { ms->carry = 0; ms->mcount = 0; ms->stored = 0; ms->abort = 0; }
+            if (tid == 0) { ms->carry = 0; ms->mcount = 0; ms->stored = 0; ms->ext_ticket = 0; ms->abort = 0; }
+            if (tid < R1) { ms->cand_seq[tid] = 0; ms->cand_free[tid] = (uint32_t)tid; }
+            if (tid < R2) { ms->lens_seq[tid] = 0; ms->lens_free[tid] = (uint32_t)tid; }
         }
         __syncthreads();
         stamp(0);
 
-        // ---- A: matches and the parse: the block's pieces of 64 positions in N_WAVES contiguous segments, a wave each
-        // (phase_a_segment: no wave waits for another)
+        // ---- A: matches and the parse, as a pipeline of wave roles over pieces of 64 positions.  The two steps that must
+        // see the pieces in order never hand a turn from wave to wave (a hand-over costs ~900 clocks, 2,040 of them a block):
+        //   wave 0, the hasher, walks the pieces through the hash heads (a bucket's read, then its write, in LDS order) and
+        //           leaves each position's four candidates in a small ring;
+        //   waves 1 .. N_WAVES - 2, the extenders, claim pieces by ticket, take the candidates (the slot goes back at once), extend
+        //           them and leave (length, distance) in a second ring;
+        //   the last wave, the parser, takes the pieces in order, carry and match count in registers.
+        // Slots carry sequence numbers: a ring slot s is written for piece k only when `free` says k, read only when `seq`
+        // says k + 1.  Every wait is for a lower-numbered piece's step, so the waits cannot form a cycle.
         const int n_pieces = (n + 63) >> 6;
-        const int seg_pieces = (n_pieces + N_WAVES - 1) / N_WAVES;
         {
-            SegArgs sa;
-            sa.data = data;
-            sa.head = head + (size_t)wave * (HEAD_WAVE_BYTES / 2);
-            sa.match = match + (size_t)wave * SEG_CAP;
-            sa.tokw = tokw;
-            sa.matw = matw;
-            sa.n = n;
-            sa.first_piece = min(wave * seg_pieces, n_pieces);
-            sa.end_piece = min((wave + 1) * seg_pieces, n_pieces);
-            sa.lane = lane;
-            const SegOut so = phase_a_segment(sa);
-            if (lane == 0) ms->seg_mcount[wave] = so.mcount;
-            __syncthreads();
-            // the seams: a match cut at its segment's end goes on into the next segment as far as that one's parse lets it
-            if (lane == 0 && so.over && wave + 1 < N_WAVES && sa.end_piece < n_pieces)
-                phase_a_seam(sa.match + so.over_rec, so.over, sa.end_piece * 64, min(n, (sa.end_piece + seg_pieces) * 64), tokw, matw);
+            RoleArgs ra;
+            ra.data = data; ra.head = head; ra.match = match; ra.tokw = tokw; ra.matw = matw; ra.ms = ms;
+            ra.cand_ring = cand_ring; ra.lens_ring = lens_ring; ra.n = n; ra.n_pieces = n_pieces; ra.lane = lane; ra.prof = a.prof;
+            if (wave == 0) role_hasher(ra);
+            else if (wave < N_WAVES - 1) role_extender(ra);
+            else role_parser(ra);
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t run = 0;
-            for (int w = 0; w < N_WAVES; w++) { ms->seg_prefix[w] = run; run += ms->seg_mcount[w]; }
-            ms->seg_prefix[N_WAVES] = run;
-            ms->mcount = run;
+        if (ms->abort) {  // (uniform) a wait of the pipeline timed out: the block is reported, not compressed
+            if (tid == 0) {
+                a.out_size[blk] = 0xffffffffu;
+                a.out_crc[blk] = ms->abort;
+                if (a.prof) {  // the rings as they stand (FADEHIP_BGZF_PROF): [8..) of the profile words
+                    unsigned long long *d = a.prof + 8;
+                    int q = 0;
+                    d[q++] = ms->abort; d[q++] = ms->ext_ticket; d[q++] = ms->carry; d[q++] = (unsigned long long)n | ((unsigned long long)ms->dbg[0] << 32);
+                    d[70] = ms->dbg[1]; d[71] = ms->dbg[2];
+                    for (int k = 0; k < R1; k++) { d[q++] = ms->cand_seq[k]; d[q++] = ms->cand_free[k]; }
+                    for (int k = 0; k < R2; k++) { d[q++] = ms->lens_seq[k]; d[q++] = ms->lens_free[k]; }
+                }
+            }
+            continue;
         }
         stamp(1);
 
@@ -432,10 +495,8 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             uint32_t *z = reinterpret_cast<uint32_t *>(lds + L_HEAD);
             for (int k = tid; k < H_END / 4; k += WG) z[k] = 0;
             if (tid < 16) { ms->bl_l[tid] = 0; ms->bl_d[tid] = 0; }
-            if (tid < 256) crct[tid] = crc_table_entry((uint32_t)tid);
         }
         __syncthreads();
-        if (tid < 256) crct[256 + tid] = (crct[tid] >> 8) ^ crct[crct[tid] & 255u];  // (published by the barrier behind the histograms)
         const int w0 = WPT * tid, w1 = min(w0 + WPT, N_WORDS);
         uint32_t tw_r[WPT], mw_r[WPT], mb_r[WPT];  // this range's bitmap words and the match index each word starts at
         {
@@ -448,12 +509,10 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                 cnt += (uint32_t)__builtin_popcount(mw_r[k]);
             }
             uint32_t all;
-            uint32_t at = block_excl_scan(cnt, ms->wtmp, &all);  // (its barriers also publish seg_prefix)
-            // a word's matches lie in its segment's region of the match records: at the word's rank among the segment's matches
+            uint32_t at = block_excl_scan(cnt, ms->wtmp, &all);
 #pragma unroll
             for (int k = 0; k < WPT; k++) {
-                const int sg = min(((w0 + k) >> 1) / seg_pieces, N_WAVES - 1);
-                mb_r[k] = (uint32_t)sg * (uint32_t)SEG_CAP + (at - ms->seg_prefix[sg]);
+                mb_r[k] = at;
                 at += (uint32_t)__builtin_popcount(mw_r[k]);
             }
         }
@@ -475,7 +534,6 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
         }
         __syncthreads();
-        if (tid < 256) crct[512 + tid] = (crct[256 + tid] >> 8) ^ crct[crct[256 + tid] & 255u];
         for (int s = tid; s < 320; s += WG) {
             uint32_t f = 0;
 #pragma unroll
@@ -484,7 +542,6 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             else ms->freq_d[s - 288] = (s - 288 < NUM_DIST) ? f : 0u;
         }
         __syncthreads();
-        if (tid < 256) crct[768 + tid] = (crct[512 + tid] >> 8) ^ crct[crct[512 + tid] & 255u];
         stamp(2);
         if (tid == 0) {  // at least two distance codes (as zlib makes sure of, for old inflaters)
             int used = 0;
@@ -535,29 +592,6 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             const int m = (int)ms->m_d;
             mr_code_lengths(A_d, m);
             limit_code_lengths(A_d, m, MAX_LITLEN_BITS, ms->sortbuf + 32);
-        } else if (wave >= 2) {
-            // ---- CRC-32 of the input, by the waves that have nothing to do meanwhile: slicing-by-4 over a piece per thread,
-            // combined by x^(8n) mod P
-            constexpr int CT = WG - 128;                                // threads of waves 2 ..
-            constexpr int PIECE = ((DATA_BYTES / CT + 3) / 4 + 1) * 4;  // bytes per thread, a multiple of 4, CT * PIECE >= BLOCK
-            static_assert(PIECE * CT >= BLOCK, "CRC pieces must cover the block");
-            const int lo = PIECE * (tid - 128), hi = min(lo + PIECE, n);
-            uint32_t part = 0;
-            if (lo < hi) {
-                uint32_t c = 0xffffffffu;
-                int k = lo;
-                const uint32_t *dw = reinterpret_cast<const uint32_t *>(data);
-                for (; k + 4 <= hi; k += 4) {
-                    c ^= dw[k >> 2];
-                    c = crct[768 + (c & 255u)] ^ crct[512 + ((c >> 8) & 255u)] ^ crct[256 + ((c >> 16) & 255u)] ^ crct[c >> 24];
-                }
-                for (; k < hi; k++) c = crct[(c ^ data[k]) & 255u] ^ (c >> 8);
-                c = ~c;
-                part = crc_mulmod(crc_x8n((uint32_t)(n - hi), ms->x2n), c);  // crc(A || B) = x^(8 |B|) crc(A) ^ crc(B)
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) part ^= (uint32_t)__shfl_xor((int)part, m, 64);
-            if (lane == 0) ms->crc_part[wave] = part;
         }
         __syncthreads();
         if ((uint32_t)tid < ms->m_l) {
@@ -796,9 +830,38 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         __syncthreads();
         stamp(5);
 
-        if (tid == 0) {  // (the CRC was summed beside the code lengths)
+        // ---- CRC-32 of the input: slicing-by-4 over a piece per thread, combined
+        if (tid < 256) crct[tid] = crc_table_entry((uint32_t)tid);
+        __syncthreads();
+        for (int t = 1; t < 4; t++) {
+            if (tid < 256) crct[256 * t + tid] = (crct[256 * (t - 1) + tid] >> 8) ^ crct[crct[256 * (t - 1) + tid] & 255u];
+            __syncthreads();
+        }
+        uint32_t part = 0;
+        {
+            constexpr int PIECE = ((DATA_BYTES / WG + 3) / 4 + 1) * 4;  // bytes per thread, a multiple of 4, WG * PIECE >= BLOCK
+            static_assert(PIECE * WG >= BLOCK, "CRC pieces must cover the block");
+            const int lo = PIECE * tid, hi = min(lo + PIECE, n);
+            if (lo < hi) {
+                uint32_t c = 0xffffffffu;
+                int k = lo;
+                const uint32_t *dw = reinterpret_cast<const uint32_t *>(data);
+                for (; k + 4 <= hi; k += 4) {
+                    c ^= dw[k >> 2];
+                    c = crct[768 + (c & 255u)] ^ crct[512 + ((c >> 8) & 255u)] ^ crct[256 + ((c >> 16) & 255u)] ^ crct[c >> 24];
+                }
+                for (; k < hi; k++) c = crct[(c ^ data[k]) & 255u] ^ (c >> 8);
+                c = ~c;
+                part = crc_mulmod(crc_x8n((uint32_t)(n - hi), ms->x2n), c);  // crc(A || B) = x^(8 |B|) crc(A) ^ crc(B)
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) part ^= (uint32_t)__shfl_xor((int)part, m, 64);
+        if (lane == 0) ms->crc_part[wave] = part;
+        __syncthreads();
+        if (tid == 0) {
             uint32_t c = 0;
-            for (int w = 2; w < N_WAVES; w++) c ^= ms->crc_part[w];
+            for (int w = 0; w < N_WAVES; w++) c ^= ms->crc_part[w];
             a.out_crc[blk] = c;
         }
         stamp(6);

@@ -1,7 +1,7 @@
 // gpu_deflate_model.cpp — CPU model of the gfx950 BGZF compressor (bgzf_deflate.hpp), phase by phase with the same
-// data structures (hash heads updated per round of 256 positions, token / match bitmaps, the match list, 256 position
-// ranges that each emit their bits at a scanned offset, OR-ing the words they share) and the SAME serial helpers
-// (bgzf_huff.hpp).  It exists so that the format logic is checked against zlib's inflate where there is no GPU:
+// data structures (per-segment hash tables of 4-way buckets, pieces of 64 positions, token / match bitmaps, the match
+// list, seams; 256 position ranges that each emit their bits at a scanned offset, OR-ing the words they share) and the
+// SAME serial helpers (bgzf_huff.hpp).  It exists so that the format logic is checked against zlib's inflate where there is no GPU:
 //   every stream inflates to its input, on BAM-like, text, random, constant, tiny and empty-ish inputs;
 //   sizes are printed next to zlib -6 and -1.
 // Build + run: make -C fade_amd/csrc build/gpu_deflate_model && fade_amd/csrc/build/gpu_deflate_model
@@ -21,97 +21,105 @@ using namespace fadehip::bgzf;
 
 namespace {
 
-constexpr int BLOCK = 0xff00, WG = 256, MAX_MATCHES = 8192, MIN_MATCH = 4, MAX_MATCH = 258;
-int WAYS = 2, HASH_BITS = 13;  // WAYS candidates per hash bucket; WAYS << HASH_BITS = 16 Ki u16 entries (32 KB of LDS)
+constexpr int WG = 256, MIN_MATCH = 4, MAX_MATCH = 258, MAXW = 16;
+int WAYS = 4;
+// the two geometries of bgzf_deflate_body.hpp, and the knobs of phase A (model only: the device's are constants)
+int BLOCK = 0xff00, N_SEG = 8, N_BUCKETS = 512, SEG_CAP = (8192 + 2560) / 8, SEED_PIECES = 16;
+bool SKIP_RUNS = false, SEAM = true;
+int SHORT4 = 32768, SHORT5 = 32768, SHORT6 = 32768;
 
 inline uint32_t load32(const uint8_t *d, int p) {
     uint32_t v;
     memcpy(&v, d + p, 4);
     return v;
 }
-inline uint32_t hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - HASH_BITS); }
+inline uint32_t hash4(uint32_t v) { return (((v * 0x9E3779B1u) >> 16) * (uint32_t)N_BUCKETS) >> 16; }
 
 // returns the raw DEFLATE stream of src[0..n), n <= BLOCK
 std::vector<uint8_t> model_deflate(const uint8_t *src, int n, bool lazy) {
-    std::vector<uint8_t> data((size_t)BLOCK + 16, 0);
+    std::vector<uint8_t> data((size_t)BLOCK + 600, 0);
     memcpy(data.data(), src, (size_t)n);
-    std::vector<uint16_t> head((size_t)WAYS << HASH_BITS, 0);
     std::vector<uint32_t> match_rec;
     const int n_words = (BLOCK + 31) / 32;
-    std::vector<uint32_t> tok((size_t)n_words, 0), mat((size_t)n_words, 0);
-    // ---- phase A: match finding per round of 256 positions, greedy parse per 64
-    int carry = 0;  // first position not covered by a token yet
-    bool full = false;
-    for (int base = 0; base < n; base += WG) {
-        uint32_t lens[WG];
-        // Pieces of 64 positions take their turn at the hash heads: the lookups of a piece see every earlier piece's
-        // inserts (atomicMax of p + 1), not those of its own 64 positions.  What sits nearer than that is looked for
-        // directly: distances 1 .. 8 (runs and short periods), of which the shortest with 4 equal bytes is a candidate.
-        for (int k = 0; k < WG / 64; k++) {
-            uint16_t cand[64][8];
-            uint32_t val[64];
-            for (int l = 0; l < 64; l++) {
-                const int p = base + 64 * k + l;
-                for (int w = 0; w < WAYS; w++) cand[l][w] = 0;
+    std::vector<uint32_t> tok((size_t)n_words + 2, 0), mat((size_t)n_words + 2, 0);
+    // ---- phase A (bgzf_deflate_body.hpp phase_a_segment): the block's pieces of 64 positions in N_SEG segments, each with a
+    // hash table of its own (N_BUCKETS x 4 ways, newest first), seeded with the SEED_PIECES pieces in front of it; a
+    // position's candidates: the nearest of the distances 1..8 whose four bytes agree, and its bucket's four; greedy parse on
+    // 64-position masks with one step of laziness; a match ends with its segment, and the seam gives it back what the next
+    // segment's parse allows
+    const int n_pieces = (n + 63) / 64, seg_pieces = (n_pieces + N_SEG - 1) / N_SEG;
+    struct Seam { int rec, over, seg_end, next_end; };
+    std::vector<Seam> seams;
+    for (int w = 0; w < N_SEG; w++) {
+        const int first = std::min(w * seg_pieces, n_pieces), end = std::min((w + 1) * seg_pieces, n_pieces);
+        const int seg_end = std::min(n, end * 64);
+        std::vector<uint16_t> head((size_t)N_BUCKETS * WAYS, 0);
+        auto insert_piece = [&](int piece, uint16_t cand[64][MAXW], uint32_t val[64]) {
+            bool ins[64];
+            for (int l = 0; l < 64; l++) {  // every lane reads its bucket, then every lane writes (lockstep); of two lanes on one bucket the later stays
+                const int p = piece * 64 + l;
+                ins[l] = false;
                 val[l] = 0;
+                for (int k = 0; k < WAYS; k++) cand[l][k] = 0;
                 if (p + MIN_MATCH <= n) {
                     val[l] = load32(data.data(), p);
-                    for (int w = 0; w < WAYS; w++) cand[l][w] = head[(size_t)hash4(val[l]) * WAYS + w];
+                    for (int k = 0; k < WAYS; k++) cand[l][k] = head[(size_t)hash4(val[l]) * WAYS + k];
+                    ins[l] = !SKIP_RUNS || p == 0 || load32(data.data(), p - 1) != val[l];
                 }
             }
-            for (int l = 0; l < 64; l++) {  // (device: one store per lane of the whole bucket; among lanes of one bucket the last lane stays)
-                const int p = base + 64 * k + l;
-                if (p + MIN_MATCH <= n) {
-                    uint16_t *b = &head[(size_t)hash4(val[l]) * WAYS];
-                    b[0] = (uint16_t)(p + 1);
-                    for (int w = 1; w < WAYS; w++) b[w] = cand[l][w - 1];
+            for (int l = 0; l < 64; l++)
+                if (ins[l]) {
+                    uint16_t *bk = &head[(size_t)hash4(val[l]) * WAYS];
+                    bk[0] = (uint16_t)(piece * 64 + l + 1);
+                    for (int k = 1; k < WAYS; k++) bk[k] = cand[l][k - 1];
                 }
-            }
+        };
+        uint16_t cand[64][MAXW];
+        uint32_t val[64];
+        for (int piece = std::max(0, first - SEED_PIECES); piece < first; piece++) insert_piece(piece, cand, val);
+        int carry = first * 64, mcount = 0, over = 0, over_rec = -1;
+        bool full = false;
+        for (int piece = first; piece < end; piece++) {
+            insert_piece(piece, cand, val);
+            uint32_t len[64], ulen[64], dist[64];
             for (int l = 0; l < 64; l++) {
-                const int p = base + 64 * k + l;
-                uint32_t len = 0, dist = 0;
+                const int p = piece * 64 + l;
+                len[l] = ulen[l] = dist[l] = 0;
+                if (p + MIN_MATCH > n || p < carry) continue;
                 const int maxlen = std::min(MAX_MATCH, n - p);
-                if (p + MIN_MATCH <= n) {
-                    for (int d = 1; d <= 8 && d <= p; d++)
-                        if (load32(data.data(), p - d) == val[l]) {
-                            uint32_t ln = 4;
-                            while ((int)ln < maxlen && data[(size_t)(p - d) + ln] == data[(size_t)p + ln]) ln++;
-                            len = ln;
-                            dist = (uint32_t)d;
-                            break;
-                        }
-                    for (int w = 0; w < WAYS; w++)
-                        if (cand[l][w]) {
-                            const int c = (int)cand[l][w] - 1;
-                            const uint32_t d2 = (uint32_t)(p - c);
-                            if (d2 <= 32768 && load32(data.data(), c) == val[l]) {
-                                uint32_t ln = 4;
-                                while ((int)ln < maxlen && data[(size_t)c + ln] == data[(size_t)p + ln]) ln++;
-                                if (ln > len) { len = ln; dist = d2; }
-                            }
-                        }
+                int cp[MAXW + 1], nc = 0;
+                for (int d = 1; d <= 8 && d <= p; d++)
+                    if (load32(data.data(), p - d) == val[l]) { cp[nc++] = p - d; break; }
+                for (int k = 0; k < WAYS; k++)
+                    if (cand[l][k]) {
+                        const int c = (int)cand[l][k] - 1;
+                        if (p - c <= 32768 && c < p && load32(data.data(), c) == val[l]) cp[nc++] = c;
+                    }
+                for (int k = 0; k < nc; k++) {
+                    uint32_t ln = 4;
+                    while ((int)ln < maxlen && data[(size_t)cp[k] + ln] == data[(size_t)p + ln]) ln++;
+                    if (ln > len[l]) { len[l] = ln; dist[l] = (uint32_t)(p - cp[k]); }
                 }
-                lens[64 * k + l] = len | (dist << 16);
+                ulen[l] = len[l];
+                len[l] = std::min<uint32_t>(len[l], (uint32_t)std::max(seg_end - p, 0));
+                if (len[l] < (uint32_t)MIN_MATCH) len[l] = 0;
+                // short matches at a distance cost more bits than the literals they replace (MODEL_SHORT4 / 5 / 6: the
+                // greatest distance at which a match of 4 / 5 / 6 bytes is still taken)
+                if (len[l] == 4 && (int)dist[l] > SHORT4) len[l] = 0;
+                if (len[l] == 5 && (int)dist[l] > SHORT5) len[l] = 0;
+                if (len[l] == 6 && (int)dist[l] > SHORT6) len[l] = 0;
             }
-        }
-        for (int k = 0; k < WG / 64; k++) {  // wave 0: one 64-position piece at a time
-            const int cb = base + 64 * k;
-            if (cb >= n) break;
-            const int valid = std::min(64, n - cb);
+            const int cb = piece * 64, valid = std::min(64, n - cb);
             uint64_t has = 0;
-            for (int l = 0; l < valid; l++)
-                if (!full && (lens[64 * k + l] & 0xffffu) >= (uint32_t)MIN_MATCH) has |= 1ull << l;
-            // the match list holds MAX_MATCHES records: once a piece might overflow it, the rest of the block goes out as literals
-            if ((int)match_rec.size() + __builtin_popcountll(has) > MAX_MATCHES) { full = true; has = 0; }
-            if (lazy) {  // a match gives way when the next position has a longer one
-                uint64_t keep = has;
-                for (int l = 0; l + 1 < valid; l++)
-                    if (((has >> l) & 1) && ((has >> (l + 1)) & 1) && (lens[64 * k + l + 1] & 0xffffu) > (lens[64 * k + l] & 0xffffu)) keep &= ~(1ull << l);
-                has = keep;
+            for (int l = 0; l < valid; l++) {
+                const bool yield = lazy && len[l] && l < 63 && len[l + 1] > len[l];
+                if (len[l] && !yield) has |= 1ull << l;
             }
+            if (full || mcount + __builtin_popcountll(has) > SEG_CAP) { full = true; has = 0; }
             int cur = std::max(carry - cb, 0);
             uint64_t tokmask = 0, matmask = 0;
             const uint64_t vmask = valid == 64 ? ~0ull : ((1ull << valid) - 1);
+            int j_last = -1;
             while (cur < valid) {
                 const uint64_t rem = has & ~((cur >= 64) ? ~0ull : ((1ull << cur) - 1));
                 if (!rem) {
@@ -122,16 +130,31 @@ std::vector<uint8_t> model_deflate(const uint8_t *src, int n, bool lazy) {
                 const int j = __builtin_ctzll(rem);
                 tokmask |= (((j == 63) ? ~0ull : ((1ull << (j + 1)) - 1)) & ~((1ull << cur) - 1));
                 matmask |= 1ull << j;
-                cur = j + (int)(lens[64 * k + j] & 0xffffu);
+                cur = j + (int)len[j];
+                j_last = j;
             }
-            carry = cb + cur;
+            if (j_last >= 0 && cb + cur == seg_end) {
+                over = (int)(ulen[j_last] - len[j_last]);
+                over_rec = (int)match_rec.size() + __builtin_popcountll(matmask & ((1ull << j_last) - 1));
+            }
+            carry = std::max(carry, cb + cur);
             for (int l = 0; l < 64; l++)
-                if ((matmask >> l) & 1) match_rec.push_back((lens[64 * k + l] >> 16) | (((lens[64 * k + l] & 0xffffu) - 3) << 16));
+                if ((matmask >> l) & 1) match_rec.push_back(dist[l] | ((len[l] - 3) << 16));
+            mcount += __builtin_popcountll(matmask);
             tok[(size_t)(cb >> 5)] |= (uint32_t)tokmask;
             tok[(size_t)(cb >> 5) + 1] |= (uint32_t)(tokmask >> 32);
             mat[(size_t)(cb >> 5)] |= (uint32_t)matmask;
             mat[(size_t)(cb >> 5) + 1] |= (uint32_t)(matmask >> 32);
         }
+        if (SEAM && over > 0 && w + 1 < N_SEG && end < n_pieces) seams.push_back({over_rec, over, end * 64, std::min(n, (end + seg_pieces) * 64)});
+    }
+    for (const Seam &sm : seams) {  // phase_a_seam
+        int give = std::min(sm.over, sm.next_end - sm.seg_end);
+        for (int q = sm.seg_end; q < sm.seg_end + give; q++)
+            if ((mat[(size_t)(q >> 5)] >> (q & 31)) & 1u) { give = q - sm.seg_end; break; }
+        if (give <= 0) continue;
+        for (int q = sm.seg_end; q < sm.seg_end + give; q++) tok[(size_t)(q >> 5)] &= ~(1u << (q & 31));
+        match_rec[(size_t)sm.rec] += (uint32_t)give << 16;
     }
     // ---- phase B: histograms (match index = matches before the position)
     std::vector<uint32_t> mpre((size_t)n_words + 1, 0);
@@ -331,7 +354,7 @@ std::vector<uint8_t> bam_like(size_t bytes, uint32_t seed, bool run_quals) {
 
 }  // namespace
 
-int main() {
+int main(int argc, char **argv) {
     // the shared helpers first
     {
         uint32_t x2n[32];
@@ -397,26 +420,54 @@ int main() {
         cases.push_back({"tiny zeros 300", std::vector<uint8_t>(300, 0)});
     }
     int fails = 0;
-    for (int ways : {1, 2, 4})
+    struct Geom { const char *name; int block, buckets, cap; };
+    const Geom geoms[2] = {{"0xff00-byte blocks", 0xff00, 512, (8192 + 2560) / 8}, {"0x7f00-byte blocks", 0x7f00, 384, 2560 / 8}};
+    // extra payloads from files (experiments: python dumps of tests/test_gpu_bgzf.py's payloads)
+    for (int k = 1; k < argc; k++) {
+        FILE *f = fopen(argv[k], "rb");
+        if (!f) continue;
+        std::vector<uint8_t> d;
+        uint8_t buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + got);
+        fclose(f);
+        cases.push_back({std::string("file ") + argv[k], d});
+    }
+    for (const Geom &g : geoms)
     for (const Case &c : cases) {
-        WAYS = ways;
-        HASH_BITS = ways == 1 ? 14 : ways == 2 ? 13 : 12;
-        if (ways != 2 && c.data.size() < 60000) continue;
-        for (int lazy = 0; lazy < 2; lazy++) {
+        BLOCK = g.block;
+        N_BUCKETS = g.buckets;
+        SEG_CAP = g.cap;
+        N_SEG = 8;
+        // (experiments: MODEL_SEG, MODEL_BUCKETS, MODEL_SEED, MODEL_SKIP_RUNS, MODEL_SEAM, MODEL_CAP override the device's constants)
+        if (getenv("MODEL_SEG")) N_SEG = atoi(getenv("MODEL_SEG"));
+        if (getenv("MODEL_BUCKETS")) N_BUCKETS = atoi(getenv("MODEL_BUCKETS"));
+        if (getenv("MODEL_SEED")) SEED_PIECES = atoi(getenv("MODEL_SEED"));
+        if (getenv("MODEL_SKIP_RUNS")) SKIP_RUNS = atoi(getenv("MODEL_SKIP_RUNS")) != 0;
+        if (getenv("MODEL_SEAM")) SEAM = atoi(getenv("MODEL_SEAM")) != 0;
+        if (getenv("MODEL_CAP")) SEG_CAP = atoi(getenv("MODEL_CAP"));
+        if (getenv("MODEL_WAYS")) WAYS = atoi(getenv("MODEL_WAYS"));
+        if (getenv("MODEL_SHORT4")) SHORT4 = atoi(getenv("MODEL_SHORT4"));
+        if (getenv("MODEL_SHORT5")) SHORT5 = atoi(getenv("MODEL_SHORT5"));
+        if (getenv("MODEL_SHORT6")) SHORT6 = atoi(getenv("MODEL_SHORT6"));
+        for (int lazy = 1; lazy < 2; lazy++) {
             size_t total = 0, z6 = 0, z1 = 0;
             bool ok = true;
-            for (size_t o = 0; o < c.data.size(); o += BLOCK) {
-                const int n = (int)std::min<size_t>(BLOCK, c.data.size() - o);
+            for (size_t o = 0; o < c.data.size(); o += (size_t)BLOCK) {
+                const int n = (int)std::min<size_t>((size_t)BLOCK, c.data.size() - o);
                 const std::vector<uint8_t> z = model_deflate(c.data.data() + o, n, lazy != 0);
                 if (!inflate_ok(z, c.data.data() + o, n)) { ok = false; printf("FAIL %s block at %zu (n = %d)\n", c.name.c_str(), o, n); }
                 if (z.size() > 65510) { ok = false; printf("FAIL %s: %zu bytes do not fit a BGZF block\n", c.name.c_str(), z.size()); }
-                total += z.size();
-                z6 += zlib_size(c.data.data() + o, n, 6);
-                z1 += zlib_size(c.data.data() + o, n, 1);
+                total += z.size() + 26;
+            }
+            for (size_t o = 0; o < c.data.size(); o += 0xff00) {  // the comparator: zlib over htslib's blocks
+                const int n = (int)std::min<size_t>(0xff00, c.data.size() - o);
+                z6 += zlib_size(c.data.data() + o, n, 6) + 26;
+                z1 += zlib_size(c.data.data() + o, n, 1) + 26;
             }
             if (!ok) fails++;
             if (c.data.size() > 2000)
-                printf("%d-way %-32s %s  %9zu -> %9zu (%.4f)   zlib -6 %.4f  -1 %.4f %s\n", ways, c.name.c_str(), lazy ? "lazy  " : "greedy", c.data.size(), total,
+                printf("%s %-36s %9zu -> %9zu (%.4f)   zlib -6 %.4f  -1 %.4f %s\n", g.name, c.name.c_str(), c.data.size(), total,
                        (double)total / (double)c.data.size(), (double)z6 / (double)c.data.size(), (double)z1 / (double)c.data.size(), ok ? "" : "  <-- FAIL");
         }
     }

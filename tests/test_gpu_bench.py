@@ -31,7 +31,7 @@ def test_bench_spawns_its_ranks_and_reduces_over_them():
     assert one["stats"]["read_count"] == 2 * per_step and two["stats"]["read_count"] == 2 * 2 * per_step
     assert two["stats"]["art"] > one["stats"]["art"] > 0  # rank 1 annotates its own shard (other seeds)
     for r in (one, two):
-        assert r["roofline"]["kernel"].startswith("sw_pk_kernel<10,1>") and 0 < r["roofline"]["frac"] < 0.05
+        assert r["roofline"]["kernel"].startswith("sw_pk_kernel<19,1,LG=8>") and 0 < r["roofline"]["frac"] < 0.05
         assert abs(r["roofline"]["bytes_per_unit"] - 316) < 10  # 75 + 161 + 16 + 64
         assert r["value"] > 0 and r["value_resident"] > 0 and r["cpu_baseline"] is None
 
