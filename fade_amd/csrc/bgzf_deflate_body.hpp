@@ -749,14 +749,26 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         } else {
             const uint32_t b1 = b0 + my_bits;
             const uint32_t hdr_words = (ms->hdr_bits + 31u) >> 5;
-            // words that more than one writer touches are cleared first and OR-ed atomically; the others are stored whole
-            if (my_bits) {
-                out32[b0 >> 5] = 0;
-                out32[(b1 - 1u) >> 5] = 0;
+            // The bit stream is put together in LDS — in what were the hash tables, free by now — and leaves as ONE coalesced
+            // copy: ranges of two threads meet inside a word, and a thread's words lie hundreds of bytes from its neighbour's, so
+            // that straight to the slot every word was a partial-line write and every seam a global atomic (PMC, round 4: 2.8
+            // bytes written per payload byte for 0.58 of output).  A stream that does not fit there (hardly compressible bytes)
+            // goes the old way.
+            const uint32_t out_words = (total_bits + 31u) >> 5;
+            const bool in_lds = out_words * 4u <= (uint32_t)HEAD_BYTES;
+            uint32_t *const sink = in_lds ? reinterpret_cast<uint32_t *>(lds + L_HEAD) : out32;
+            if (in_lds) {
+                for (uint32_t k = tid; k < out_words; k += WG) sink[k] = 0;
+            } else {
+                // words that more than one writer touches are cleared first and OR-ed atomically; the others are stored whole
+                if (my_bits) {
+                    sink[b0 >> 5] = 0;
+                    sink[(b1 - 1u) >> 5] = 0;
+                }
+                for (uint32_t k = tid; k < hdr_words; k += WG) sink[k] = 0;
             }
-            for (uint32_t k = tid; k < hdr_words; k += WG) out32[k] = 0;
             __syncthreads();
-            for (uint32_t k = tid; k < hdr_words; k += WG) atomicOr(&out32[k], ms->hdr[k]);
+            for (uint32_t k = tid; k < hdr_words; k += WG) atomicOr(&sink[k], ms->hdr[k]);
             if (my_bits) {
                 uint64_t acc = 0;
                 int cnt = (int)(b0 & 31u);
@@ -766,8 +778,8 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                     acc |= v << cnt;
                     cnt += k;
                     if (cnt >= 32) {
-                        if (wi == w_first || wi == w_last) atomicOr(&out32[wi], (uint32_t)acc);
-                        else out32[wi] = (uint32_t)acc;
+                        if (wi == w_first || wi == w_last) atomicOr(&sink[wi], (uint32_t)acc);
+                        else sink[wi] = (uint32_t)acc;
                         wi++;
                         acc >>= 32;
                         cnt -= 32;
@@ -789,7 +801,11 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                     }
                 }
                 if (tid == WG - 1) put(ms->lc[256], ms->ll[256]);
-                if (cnt) atomicOr(&out32[wi], (uint32_t)acc);
+                if (cnt) atomicOr(&sink[wi], (uint32_t)acc);
+            }
+            if (in_lds) {
+                __syncthreads();
+                for (uint32_t k = tid; k < out_words; k += WG) out32[k] = sink[k];
             }
             if (tid == 0) a.out_size[blk] = (total_bits + 7u) >> 3;
         }

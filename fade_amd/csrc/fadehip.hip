@@ -564,12 +564,27 @@ int run_class_two_pass(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun
         }
         // the other A/B variant: eight-lane groups, 19 rows per lane (152 rows for reads of up to 152 bases in the 160-row class),
         // sixteen alignments per wavefront; no snapshots in this geometry (pass 2 re-computes from step 0)
-        const bool g8 = ctx->score_g8 && class_rows(cls) == 10 && s.max_lq <= 152 && !p.longw && n_ck == 0 && !a.ticket;
-        if (g8) {
+        // Eight-lane groups: a lane owns R8 rows of 8 R8 — rows in steps of 8 instead of 16 (36-base reads: 40 rows instead of
+        // 64; 50: 56 / 64; 76: 80 / 96; 100, 101: 104 / 128; 150, 151: 152 / 160), sixteen alignments per wavefront, a skew of 7
+        // steps.  Taken when every read of the batch fits the rows (the batch's longest read is known: s.max_lq) and they are
+        // fewer than the sixteen-lane class's; no snapshots in this geometry (pass 2 re-computes from step 0).
+        const void *g8_fn = nullptr;
+        if (ctx->score_g8 && !p.longw && n_ck == 0 && !a.ticket) {
+            const int rows16 = 16 * class_rows(cls), lq = std::min(s.max_lq, rows16);
+            if (lq <= 40 && rows16 > 40) g8_fn = (const void *)sw_pk_kernel<5, 1, false, 8>;
+            else if (lq <= 56 && rows16 > 56) g8_fn = (const void *)sw_pk_kernel<7, 1, false, 8>;
+            else if (lq <= 80 && rows16 > 80) g8_fn = (const void *)sw_pk_kernel<10, 1, false, 8>;
+            else if (lq <= 104 && rows16 > 104) g8_fn = (const void *)sw_pk_kernel<13, 1, false, 8>;
+            else if (lq <= 152 && rows16 > 152 && rows16 <= 160)
+                g8_fn = ctx->score_g8 == 2 ? (const void *)sw_pk_kernel<19, 1, false, 8, false, 2> : (const void *)sw_pk_kernel<19, 1, false, 8>;
+            // (a class below the batch's top class holds reads of ITS row range only, which the kernel chosen for min(max_lq, rows) covers)
+            if (g8_fn && s.max_lq > rows16) g8_fn = nullptr;  // (not the top class: its reads may be any length up to rows16)
+        }
+        if (g8_fn) {
+            if (ctx->debug && o0 == 0) fprintf(stderr, "[fadehip] class of %d rows: score pass on eight-lane groups (longest read of the batch: %d)\n", 16 * class_rows(cls), s.max_lq);
             SwArgs copy = a;
             void *args[] = {&copy};
-            const void *fn = ctx->score_g8 == 2 ? (const void *)sw_pk_kernel<19, 1, false, 8, false, 2> : (const void *)sw_pk_kernel<19, 1, false, 8>;
-            HIPCHK(ctx, hipLaunchKernel(fn, dim3((unsigned)((n + 15) / 16)), dim3(64), args, 2 * lds1, sst));
+            HIPCHK(ctx, hipLaunchKernel(g8_fn, dim3((unsigned)((n + 15) / 16)), dim3(64), args, 2 * lds1, sst));
         } else if (a.ticket) {
             SwArgs copy = a;
             void *args[] = {&copy};

@@ -1306,7 +1306,7 @@ constexpr int PK_SCALE = 8;  // must stay 8: the shifts below are log2(8) and lo
 // (168; R = 16 spills ~100 registers outside its sweep and is still 6 % faster than at 2 waves), 2 beyond (R = 20 / 24:
 // +27 % / +30 % over the unconstrained allocation, which took 256 VGPRs and one wave).  The traced pass is latency-bound:
 // 3 or 4 waves per SIMD (40 / 85 spilled registers) changed nothing measurable, it is left alone.
-__host__ __device__ constexpr int pk_min_waves(int R, int MODE, int LG = 16, int WV = 0) { return WV ? WV : MODE != 1 ? 1 : (LG == 8 ? 3 : (R <= 10 ? 4 : (R <= 16 ? 3 : 2))); }
+__host__ __device__ constexpr int pk_min_waves(int R, int MODE, int LG = 16, int WV = 0) { return WV ? WV : MODE != 1 ? 1 : (LG == 8 ? (R <= 13 ? 4 : 3) : (R <= 10 ? 4 : (R <= 16 ? 3 : 2))); }
 
 // LONGW: the launch may hold windows longer than one staged chunk (CH_COLS columns); the sweep then re-stages at chunk
 // boundaries.  A kernel of its own, so that the ordinary launch keeps its registers (the chunk loop cost the 150-base

@@ -8,7 +8,7 @@
 # plus the same two TCC passes over bench/store_calib (known byte counts in the kernel's access shapes).
 # Outputs land under gpurun_out/prof_$TAG; profiles/summarize_pmc.py $TAG $CONFIG copies the summaries into profiles/.
 # usage: profiles/collect.sh r02_C2 C2
-TAG=${1:-r03_C2}
+TAG=${1:-r04_C2}
 CFG=${2:-C2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG

@@ -360,3 +360,31 @@ def test_malformed_offsets_are_rejected_before_any_launch(ctx):
         ctx.annotate(bad, 5, 100)
     rs, aln, st = ctx.annotate(b, 5, 100)
     assert int(st[0]) == 2000
+
+
+@pytest.mark.parametrize("read_len", [36, 40, 41, 50, 56, 57, 76, 80, 81, 100, 101, 104, 105, 150, 151, 152, 153])
+def test_uniform_read_lengths_and_the_eight_lane_score_kernels(oracle, read_len, capfd):
+    """Libraries of one read length: the score pass of the batch's top row class runs on eight-lane groups when the reads fit
+    rows in steps of eight that the sixteen-lane class does not offer (40 / 56 / 80 / 104 / 152 rows: sw_pk_kernel<R8,1,LG=8>);
+    lengths on both sides of every boundary, rs and am against the oracle, and the library says (FADEHIP_DEBUG) which
+    geometry it took."""
+    import os
+    os.environ["FADEHIP_DEBUG"] = "1"
+    try:
+        c = fade_amd.Context(device=0)
+    finally:
+        del os.environ["FADEHIP_DEBUG"]
+    try:
+        cfg = synth.config("C5")
+        cfg.update(read_len=read_len, contig_len=60_000, insert_mu=max(cfg["insert_mu"], read_len + 150), clip_max=min(cfg["clip_max"], read_len // 2))
+        g = synth.Genome(2, cfg["contig_len"], 11)
+        b = synth.make_reads(g, 3000, 900 + read_len, **{k: v for k, v in cfg.items() if k in (
+            "read_len", "window", "p_sc", "clip_min", "clip_max", "insert_mu", "insert_sd")})
+        b.pop("_truth", None)
+        rs, aln, tags = _compare(c, oracle, g.names, [a.tobytes().decode() for a in g.ascii_contigs()], b, cfg["floor_len"], cfg["window"])
+        assert len(tags) > 20
+    finally:
+        c.close()
+    err = capfd.readouterr().err
+    eight = "eight-lane groups" in err
+    assert eight == (read_len in (36, 40, 41, 50, 56, 76, 80, 100, 101, 104, 150, 151, 152)), (read_len, err[-300:])
