@@ -2269,12 +2269,20 @@ int main(int argc, char **argv) {
             fprintf(stderr, "[E::fade-annotate] Please use only one of the b or u flags\n");
             return 1;
         }
+        if (!o.out_shards.empty() && o.gpus < 2) {
+            fprintf(stderr, "[E::fade-annotate] --out-shards PREFIX writes one file per device: it goes with --gpus N (N >= 2)\n");
+            return 1;
+        }
         // --gpus N on a BAM file: one process per GPU, each on its own share of the input (annotate_lanes_main); input that
         // cannot be cut (a pipe, SAM text, a small file) is read by one process that deals batches to the N devices
         if (o.gpus > 1 && !lane_env().on && !(getenv("FADE_LANES") && atoi(getenv("FADE_LANES")) == 0)) {
             bool fall_back = true;
             const int lrc = annotate_lanes_main(cl, o, &fall_back);
             if (lrc == 0 || !fall_back) return lrc;
+            if (!o.out_shards.empty()) {
+                fprintf(stderr, "[E::fade-annotate] --out-shards needs an input that can be cut into ranges: a BAM file (not a pipe, not SAM text) of at least %d BGZF blocks\n", 8 * o.gpus);
+                return 1;
+            }
         }
         // BAM file in, BAM or uBAM out: the file path on the device (FADE_BAM_DEVICE=0: the host pipeline)
         if ((o.bam || o.ubam) && (o.gpus <= 1 || lane_env().on) && !(getenv("FADE_BAM_DEVICE") && atoi(getenv("FADE_BAM_DEVICE")) == 0)) {

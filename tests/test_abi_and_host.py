@@ -112,6 +112,21 @@ def test_cli_file_path_fails_loudly_without_gpu(tmp_path):
         assert p.returncode == 1 and p.stdout == b"" and b"[E::fade annotate] cannot open the GPU path" in p.stderr, (env, p.stderr[-300:])
 
 
+def test_cli_out_shards_goes_with_gpus_and_with_an_input_that_can_be_cut(tmp_path):
+    """`--out-shards PREFIX` writes a file per device: without `--gpus N` it is refused before anything touches the GPU, and with
+    an input that cannot be cut into ranges (SAM text, a file of a few blocks) it says so instead of writing to stdout."""
+    import subprocess
+    gold = os.path.join(ROOT, "tests", "golden")
+    fade = os.path.join(ROOT, "fade_amd", "fade")
+    p = subprocess.run([fade, "annotate", "--out-shards", str(tmp_path / "s"), "-b", os.path.join(gold, "anno_c1.sam"), os.path.join(gold, "anno_c1.fa")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 1 and p.stdout == b"" and b"--out-shards PREFIX writes one file per device" in p.stderr
+    p = subprocess.run([fade, "annotate", "--gpus", "2", "--out-shards", str(tmp_path / "s"), "-b", os.path.join(gold, "anno_c1.sam"), os.path.join(gold, "anno_c1.fa")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 1 and p.stdout == b"" and b"--out-shards needs an input that can be cut into ranges" in p.stderr
+    assert not list(tmp_path.iterdir())
+
+
 def test_product_path_does_not_touch_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fade_amd")):
         for f in files:
