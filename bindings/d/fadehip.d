@@ -163,6 +163,8 @@ struct fadehip_bam_config {
     uint tail_trim;              /// payload bytes at the end of the last member that belong to the next reader
 }
 enum FADEHIP_BAM_CHUNKS = 3;
+enum FADEHIP_BAM_STORED = 1;     /// fadehip_bam_config.flags: uncompressed BGZF out (`fade annotate -u`)
+enum FADEHIP_BAM_NO_OUTPUT = 2;  /// ... back releases the annotated records without compressing them (measurement)
 int fadehip_bam_open(fadehip_ctx* ctx, const(fadehip_bam_config)* cfg, fadehip_bam_stream** out_);
 int fadehip_bam_front(fadehip_bam_stream* st, const(void)* members, size_t n_bytes, int last);
 int fadehip_bam_front_raw(fadehip_bam_stream* st, const(void)* payload, size_t n_bytes, int last);
