@@ -177,6 +177,84 @@ __device__ __forceinline__ void token_bits(const uint8_t *data, uint32_t mw, uin
     }
 }
 
+// Minimum-redundancy code lengths (Moffat & Katajainen) by a WHOLE WAVE: the same lengths as bgzf_huff.hpp's
+// mr_code_lengths, which is a chain of ~3 m dependent LDS accesses for one lane (the longest serial stretch of a block once
+// phase A stopped being one).  Only its first pass is a chain by nature — the merge of the sorted leaves with the internal
+// nodes it makes — and stays with lane 0; it leaves each internal node's parent in A[0 .. m-2).  Then: the internal nodes'
+// depths by pointer jumping (ceil(log2 m) rounds of dep[i] += dep[par[i]], par[i] = par[par[i]] over all nodes at once, instead of
+// m dependent double look-ups), a histogram of those depths, the number of leaves at each depth from it (a level holds twice the
+// internal nodes of the level above; what is not an internal node is a leaf), and every leaf reads its depth off the running
+// sums by its position.  A[0 .. m) = frequencies ascending on entry, lengths (descending) on return; scratch: 4 arrays of m + 2.
+__device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, uint32_t *dep, uint32_t *par, uint32_t *cnt, uint32_t *cum, const int lane) {
+    if (m == 1) {
+        if (lane == 0) A[0] = 1;
+        return;
+    }
+    if (lane == 0) {
+        A[0] += A[1];
+        int root = 0, leaf = 2;
+        for (int next = 1; next < m - 1; next++) {
+            uint32_t v;
+            if (leaf >= m || A[root] < A[leaf]) { v = A[root]; A[root++] = (uint32_t)next; }
+            else v = A[leaf++];
+            if (leaf >= m || (root < next && A[root] < A[leaf])) { v += A[root]; A[root++] = (uint32_t)next; }
+            else v += A[leaf++];
+            A[next] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int ni = m - 1;  // internal nodes 0 .. m-2, the root last
+    constexpr int PER = (NUM_LITLEN + 2 + 63) / 64;
+    for (int i = lane; i < ni; i += 64) {
+        par[i] = i == ni - 1 ? (uint32_t)i : A[i];
+        dep[i] = i == ni - 1 ? 0u : 1u;
+    }
+    for (int i = lane; i < m + 2; i += 64) cnt[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; (1 << r) < ni; r++) {
+        uint32_t nd[PER], np[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = lane + 64 * k;
+            nd[k] = np[k] = 0;
+            if (i < ni) {
+                const uint32_t q = par[i];
+                nd[k] = dep[i] + dep[q];
+                np[k] = par[q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (a wave's LDS accesses complete in order: every read of the round is ahead of its writes)
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = lane + 64 * k;
+            if (i < ni) { dep[i] = nd[k]; par[i] = np[k]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < ni; i += 64) atomicAdd(&cnt[dep[i]], 1u);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {  // leaves per depth, as running sums: cum[d] = leaves at depths 0 .. d
+        uint32_t avbl = 1, run = 0;
+        int d = 0;
+        while (avbl > 0 && d <= m) {
+            const uint32_t used = cnt[d];
+            run += avbl - used;
+            cum[d] = run;
+            avbl = 2u * used;
+            d++;
+        }
+        cum[m + 1] = (uint32_t)d;  // levels
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int levels = (int)cum[m + 1];
+    for (int q = lane; q < m; q += 64) {  // the q-th most frequent leaf sits at the first depth whose running sum exceeds q
+        int d = 0;
+        while (d < levels - 1 && cum[d] <= (uint32_t)q) d++;
+        A[m - 1 - q] = (uint32_t)d;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- phase A: matches and the parse of ONE SEGMENT of the block, by one wave that needs nobody else.
 // Round 3 ran phase A as a pipeline of wave roles (a hasher, extenders, ONE parser, rings with sequence numbers between
 // them): a block's time was the parser's, the other waves waited a third to two thirds of theirs, and a quarter of the
@@ -525,12 +603,13 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         if (tid < 320) ms->ll[tid] = 0;
         if (tid < 64) ms->dl[tid] = 0;
         __syncthreads();
-        // minimum-redundancy lengths: a lane per alphabet (a chain of ~3 m dependent LDS accesses: the one serial stretch of
-        // the block that no reformulation here made shorter — lane arrays read by v_readlane measured slower than LDS)
-        if (tid == 0) {
+        // minimum-redundancy lengths: wave 0 for the literal / length alphabet (mr_code_lengths_wave), a lane of wave 1 for the
+        // thirty distance codes, the other waves sum the CRC meanwhile
+        if (wave == 0) {
+            // (h8's histograms have been summed: its space serves the wave as scratch)
             const int m = (int)ms->m_l;
-            mr_code_lengths(A_l, m);
-            limit_code_lengths(A_l, m, MAX_LITLEN_BITS, ms->sortbuf);
+            mr_code_lengths_wave(A_l, m, h8, h8 + 320, h8 + 640, h8 + 960, lane);
+            if (lane == 0) limit_code_lengths(A_l, m, MAX_LITLEN_BITS, ms->sortbuf);
         } else if (tid == 64) {
             const int m = (int)ms->m_d;
             mr_code_lengths(A_d, m);

@@ -461,7 +461,7 @@ struct StageThreads {
 
 // Threads when -t is not given: the CPUs this process may actually use — its affinity mask and, in a container, the
 // cgroup's CPU quota (a 16-CPU share of a 256-thread host must not get 255 threads) — at most 64.
-static int default_threads() {
+static int default_threads(int cap = 64) {
     int n = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
@@ -485,7 +485,7 @@ static int default_threads() {
     double q = quota("/sys/fs/cgroup/cpu.max", nullptr);  // cgroup v2: "<quota|max> <period>"
     if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");  // v1
     if (q > 0) n = std::min(n, (int)(q + 0.999));
-    return std::max(1, std::min(n, 64));
+    return std::max(1, std::min(n, cap));
 }
 
 // seconds since the kernel started this process (/proc/self/stat field 22 against /proc/uptime), for -T only
@@ -681,7 +681,9 @@ static int annotate_lanes_main(const std::string &cl, const Opts &o, bool *fall_
             for (int b2 = a + 1; b2 < n_lanes; b2++)
                 if (devmap[(size_t)a] == devmap[(size_t)b2]) distinct = false;
     }
-    const int threads_each = std::max(1, (o.threads > 0 ? o.threads : default_threads()) / n_lanes);
+    // (a lane is a whole `fade annotate` of its own: its share of the cores, up to the 64 a single run takes — an 8-GPU node
+    // has them)
+    const int threads_each = std::max(1, std::min(64, (o.threads > 0 ? o.threads : default_threads(64 * n_lanes)) / n_lanes));
     const bool shards = !o.out_shards.empty();
     // Where the lanes write.  --out-shards: every lane a complete file of its own (header, its records, end-of-file block),
     // nothing is merged (BASELINE config 4: "sharded per GPU").  Otherwise ONE stream on stdout: lane 0 writes straight into
