@@ -23,6 +23,7 @@ constexpr int WAYS = 4;
 constexpr int HEAD_WAVE_BYTES = N_BUCKETS * WAYS * 2;
 constexpr int HEAD_BYTES = HEAD_WAVE_BYTES * N_WAVES;
 constexpr int SEG_CAP = MAX_MATCHES / N_WAVES;  // match records a segment may leave (more: literals from there on)
+constexpr int NEAR = 2;                         // distances tried directly (the table does not hold a piece's own positions yet)
 constexpr int SEED_PIECES = 16;                 // pieces in front of a segment whose positions are hashed for it (1 KB of history)
 constexpr int MIN_MATCH = 4, MAX_MATCH = 258;
 constexpr int N_WORDS = (BLOCK + 31) / 32;   // words of a per-position bitmap
@@ -308,18 +309,21 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
         uint32_t len = 0, dist = 0;
         if (valid && (int)p >= carry) {
             const uint32_t maxlen = (uint32_t)min(MAX_MATCH, n - (int)p);
-            // up to five candidates: the nearest of the distances 1 .. 8 whose four bytes agree, and the bucket's four
+            // up to five candidates: the nearer of the distances 1 and 2 whose four bytes agree (what a piece's own positions,
+            // not yet in the table, would offer: runs and 16-bit patterns; the distances 3 .. 8 of the role pipeline bring
+            // nothing on the payloads this geometry is taken for — gpu_deflate_model MODEL_NEAR — and cost twelve LDS reads a
+            // position), and the bucket's four
             // positions; their loads are issued together and they are extended side by side (one LDS round trip per
             // eight bytes of the LONGEST match, not per candidate)
             uint32_t cp[5];
             uint32_t alive = 0;
             {
-                uint32_t vd[8];
+                uint32_t vd[NEAR];
 #pragma unroll
-                for (uint32_t d = 1; d <= 8u; d++) vd[d - 1] = lds_load32u(data, p >= d ? p - d : p);
+                for (uint32_t d = 1; d <= (uint32_t)NEAR; d++) vd[d - 1] = lds_load32u(data, p >= d ? p - d : p);
                 uint32_t dsmall = 0;
 #pragma unroll
-                for (uint32_t d = 8; d >= 1u; d--)
+                for (uint32_t d = NEAR; d >= 1u; d--)
                     if (p >= d && vd[d - 1] == v) dsmall = d;
                 cp[0] = p - dsmall;
                 if (dsmall) alive |= 1u;

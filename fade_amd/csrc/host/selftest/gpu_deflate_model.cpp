@@ -26,7 +26,7 @@ int WAYS = 4;
 // the two geometries of bgzf_deflate_body.hpp, and the knobs of phase A (model only: the device's are constants)
 int BLOCK = 0xff00, N_SEG = 8, N_BUCKETS = 512, SEG_CAP = (8192 + 2560) / 8, SEED_PIECES = 16;
 bool SKIP_RUNS = false, SEAM = true;
-int SHORT4 = 32768, SHORT5 = 32768, SHORT6 = 32768;
+int SHORT4 = 32768, SHORT5 = 32768, SHORT6 = 32768, NEAR = 2;
 
 inline uint32_t load32(const uint8_t *d, int p) {
     uint32_t v;
@@ -88,7 +88,7 @@ std::vector<uint8_t> model_deflate(const uint8_t *src, int n, bool lazy) {
                 if (p + MIN_MATCH > n || p < carry) continue;
                 const int maxlen = std::min(MAX_MATCH, n - p);
                 int cp[MAXW + 1], nc = 0;
-                for (int d = 1; d <= 8 && d <= p; d++)
+                for (int d = 1; d <= NEAR && d <= p; d++)
                     if (load32(data.data(), p - d) == val[l]) { cp[nc++] = p - d; break; }
                 for (int k = 0; k < WAYS; k++)
                     if (cand[l][k]) {
@@ -447,6 +447,7 @@ int main(int argc, char **argv) {
         if (getenv("MODEL_SEAM")) SEAM = atoi(getenv("MODEL_SEAM")) != 0;
         if (getenv("MODEL_CAP")) SEG_CAP = atoi(getenv("MODEL_CAP"));
         if (getenv("MODEL_WAYS")) WAYS = atoi(getenv("MODEL_WAYS"));
+        if (getenv("MODEL_NEAR")) NEAR = atoi(getenv("MODEL_NEAR"));
         if (getenv("MODEL_SHORT4")) SHORT4 = atoi(getenv("MODEL_SHORT4"));
         if (getenv("MODEL_SHORT5")) SHORT5 = atoi(getenv("MODEL_SHORT5"));
         if (getenv("MODEL_SHORT6")) SHORT6 = atoi(getenv("MODEL_SHORT6"));
