@@ -126,6 +126,7 @@ void fadehip_destroy(fadehip_ctx* ctx);
 const(char)* fadehip_last_error(const(fadehip_ctx)* ctx);
 int fadehip_host_alloc(fadehip_ctx* ctx, size_t bytes, void** out_);
 int fadehip_host_free(fadehip_ctx* ctx, void* p);
+int fadehip_host_register(fadehip_ctx* ctx, void* p, size_t bytes);
 size_t fadehip_batch_bytes(int n_reads, long n_cigar_ops, long n_seq_bytes);
 int fadehip_batch_bind(void* base, int n_reads, long n_cigar_ops, long n_seq_bytes, fadehip_read_batch* b);
 int fadehip_sw_batch(fadehip_ctx* ctx, int n, const(ubyte)* q, const(long)* q_off,
@@ -166,6 +167,7 @@ enum FADEHIP_BAM_CHUNKS = 3;
 enum FADEHIP_BAM_STORED = 1;     /// fadehip_bam_config.flags: uncompressed BGZF out (`fade annotate -u`)
 enum FADEHIP_BAM_NO_OUTPUT = 2;  /// ... back releases the annotated records without compressing them (measurement)
 int fadehip_bam_open(fadehip_ctx* ctx, const(fadehip_bam_config)* cfg, fadehip_bam_stream** out_);
+int fadehip_bam_prepare(fadehip_bam_stream* st, size_t call_bytes);
 int fadehip_bam_front(fadehip_bam_stream* st, const(void)* members, size_t n_bytes, int last);
 int fadehip_bam_front_raw(fadehip_bam_stream* st, const(void)* payload, size_t n_bytes, int last);
 int fadehip_bam_back(fadehip_bam_stream* st, const(ubyte)** out_, size_t* out_bytes);

@@ -26,12 +26,13 @@ def row_class(l_seq):
 # every symbol include/fadehip.h declares
 EXPORTS = [
     "fadehip_params_default", "fadehip_abi_version", "fadehip_create", "fadehip_destroy", "fadehip_last_error",
-    "fadehip_host_alloc", "fadehip_host_free", "fadehip_batch_bytes", "fadehip_batch_bind", "fadehip_sw_batch",
+    "fadehip_host_alloc", "fadehip_host_free", "fadehip_host_register", "fadehip_batch_bytes", "fadehip_batch_bind", "fadehip_sw_batch",
     "fadehip_genome_upload", "fadehip_annotate_upload", "fadehip_annotate_run", "fadehip_annotate_submit",
     "fadehip_annotate_results", "fadehip_annotate_collect",
     "fadehip_sync", "fadehip_last_run_profile", "fadehip_stats_allreduce",
     "fadehip_bgzf_deflate_submit", "fadehip_bgzf_deflate_wait", "fadehip_stats_allreduce_rank", "fadehip_bgzf_inflate",
     "fadehip_bam_open", "fadehip_bam_front", "fadehip_bam_front_raw", "fadehip_bam_back", "fadehip_bam_totals", "fadehip_bam_close",
+    "fadehip_bam_prepare",
 ]
 BGZF_BLOCK = 0xff00
 BGZF_LANES = 2
@@ -113,6 +114,7 @@ def load():
     L.fadehip_last_error.restype = C.c_char_p
     L.fadehip_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.fadehip_host_free.argtypes = [vp, vp]
+    L.fadehip_host_register.argtypes = [vp, vp, C.c_size_t]
     L.fadehip_batch_bytes.argtypes = [i32, i64, i64]
     L.fadehip_batch_bytes.restype = C.c_size_t
     L.fadehip_batch_bind.argtypes = [vp, i32, i64, i64, C.POINTER(ReadBatch)]
@@ -131,6 +133,7 @@ def load():
     L.fadehip_bgzf_deflate_wait.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fadehip_bgzf_inflate.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fadehip_bam_open.argtypes = [vp, C.POINTER(BamConfig), C.POINTER(vp)]
+    L.fadehip_bam_prepare.argtypes = [vp, C.c_size_t]
     L.fadehip_bam_front.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.fadehip_bam_front_raw.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.fadehip_bam_back.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]

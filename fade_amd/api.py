@@ -429,6 +429,10 @@ class BamStream:
         self._h = h
         self._keep = None
 
+    def prepare(self, call_bytes):
+        """fadehip_bam_prepare: the streams and buffers of calls of call_bytes inflated bytes, made ahead of the first call."""
+        self._ctx._chk(self._L.fadehip_bam_prepare(self._h, int(call_bytes)))
+
     def front(self, members, last=False):
         arr = np.frombuffer(members, dtype=np.uint8) if isinstance(members, (bytes, bytearray, memoryview)) else np.ascontiguousarray(members, dtype=np.uint8)
         self._ctx._chk(self._L.fadehip_bam_front(self._h, arr.ctypes.data if arr.nbytes else None, arr.nbytes, 1 if last else 0))

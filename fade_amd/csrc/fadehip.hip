@@ -23,6 +23,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace fadehip;
@@ -36,7 +38,7 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
-struct PinBuf {  // hipHostMalloc
+struct PinBuf {  // staging memory (pin_alloc)
     uint8_t *p = nullptr;
     size_t cap = 0;
 };
@@ -197,6 +199,7 @@ struct fadehip_ctx {
     int tail_cus_per_xcd = 1;  // FADEHIP_TAIL_CUS: CUs per XCD the score pass leaves alone (0: no CU mask, one stream per slot)
     int score_g8 = 1;            // the score pass of reads of up to 152 bases in the 160-row class on eight-lane groups (FADEHIP_SCORE_G8=0: sixteen-lane groups; 2: at two waves per SIMD): the score pass of 150-base reads on eight-lane groups (A/B variant)
     bool blocking_sync = false;  // FADEHIP_BLOCKING_SYNC=1: waits for the device sleep
+    int split_cus = 0;  // FADEHIP_BAM_SPLIT=j: the file path's record kernels get j CUs of every XCD, the compressor the others
     bool score_persist = false;  // FADEHIP_SCORE_PERSIST=1: the score pass as a persistent launch (A/B variant)
     int p2_waves_fixed = 0;    // FADEHIP_P2_WAVES: waves of the persistent pass-2 launch (0: adaptive, see run_class_two_pass)
     int span_slack = 24;  // FADEHIP_SPAN_SLACK overrides (tests: -1 makes almost every path leave its range)
@@ -249,16 +252,70 @@ int reserve(fadehip_ctx *ctx, DevBuf &b, size_t bytes) {
     return 0;
 }
 
+// Staging memory the device reaches over PCIe.  Large blocks are ordinary 2 MB-aligned host memory handed to
+// hipHostRegister: measured on MI355X (bench/setup_costs.hip) 1.5 ms per 32 MB against 4-7 ms for hipHostMalloc, with the
+// same 56 GB/s up and down and the same 53 GB/s for a kernel that stores into it; small ones come from hipHostMalloc.
+// The registry says which way a pointer came.
+constexpr size_t PIN_REGISTER_MIN = (size_t)1 << 20;
+std::mutex g_pin_mu;
+std::unordered_map<void *, bool> g_pin_registered;  // pointer -> the library owns the memory (free() it)
+
+int pin_alloc(fadehip_ctx *ctx, size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes >= PIN_REGISTER_MIN && !getenv("FADEHIP_PIN_HOSTMALLOC")) {
+        const size_t al = (size_t)1 << 21, n = (bytes + al - 1) & ~(al - 1);
+        void *p = aligned_alloc(al, n);
+        if (!p) return set_err(ctx, FADEHIP_E_NOMEM, "out of host memory (%zu bytes of staging memory)", n);
+        void *dp = nullptr;
+        if (hipHostRegister(p, n, hipHostRegisterDefault) == hipSuccess && hipHostGetDevicePointer(&dp, p, 0) == hipSuccess && dp == p) {
+            std::lock_guard<std::mutex> l(g_pin_mu);
+            g_pin_registered[p] = true;
+            *out = p;
+            return 0;
+        }
+        // (a stack where registered memory has another address on the device: the kernels are given host pointers)
+        (void)hipGetLastError();
+        (void)hipHostUnregister(p);
+        (void)hipGetLastError();
+        free(p);
+    }
+    HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 1));
+    return 0;
+}
+
+int pin_free(fadehip_ctx *ctx, void *p) {
+    if (!p) return 0;
+    bool registered = false, owned = false;
+    {
+        std::lock_guard<std::mutex> l(g_pin_mu);
+        auto it = g_pin_registered.find(p);
+        if (it != g_pin_registered.end()) {
+            registered = true;
+            owned = it->second;
+            g_pin_registered.erase(it);
+        }
+    }
+    if (!registered) {
+        HIPCHK(ctx, hipHostFree(p));
+        return 0;
+    }
+    const hipError_t e = hipHostUnregister(p);
+    if (owned) free(p);
+    if (e != hipSuccess) return set_err(ctx, FADEHIP_E_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int reserve_pinned(fadehip_ctx *ctx, PinBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return 0;
+    int rc;
     if (b.p) {
-        HIPCHK(ctx, hipHostFree(b.p));
+        if ((rc = pin_free(ctx, b.p))) return rc;
         b.p = nullptr;
         b.cap = 0;
     }
     size_t want = std::max<size_t>(bytes + bytes / 8, 4096);  // some headroom: batches of a stream differ a little in size
     want = (want + 4095) & ~(size_t)4095;
-    HIPCHK(ctx, hipHostMalloc((void **)&b.p, want));
+    if ((rc = pin_alloc(ctx, want, (void **)&b.p))) return rc;
     b.cap = want;
     return 0;
 }
@@ -289,7 +346,7 @@ void release(DevBuf &b) {
     b.cap = 0;
 }
 void release(PinBuf &b) {
-    if (b.p) (void)hipHostFree(b.p);
+    if (b.p) (void)pin_free(nullptr, b.p);
     b.p = nullptr;
     b.cap = 0;
 }
@@ -845,6 +902,20 @@ int run_long(fadehip_ctx *ctx, Slot &s, hipStream_t st, const ClassRun &c, int m
     return 0;
 }
 
+// A stream on CUs [lo, hi) of every XCD (mask bit i is CU i / 8 of XCD i % 8 on MI355X); nullptr where the stack has no CU masks.
+hipStream_t xcd_slice_stream(fadehip_ctx *ctx, int lo, int hi) {
+    if (ctx->cu_count < 64 || ctx->cu_count % 32) return nullptr;
+    std::vector<uint32_t> mask((size_t)ctx->cu_count / 32, 0u);
+    for (int i = 0; i < ctx->cu_count; i++)
+        if (i / 8 >= lo && i / 8 < hi) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t q = nullptr;
+    if (hipExtStreamCreateWithCUMask(&q, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return q;
+}
+
 // streams, events and the pinned counter block of a slot, made when the slot is first used
 int ensure_slot(fadehip_ctx *ctx, Slot &s) {
     if (s.h_zb) return 0;
@@ -1313,6 +1384,7 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params) 
     }
     if (const char *kv = getenv("FADEHIP_SPAN_SLACK")) ctx->span_slack = atoi(kv);
     if (const char *kv = getenv("FADEHIP_TAIL_CUS")) ctx->tail_cus_per_xcd = std::max(0, std::min(atoi(kv), 8));
+    if (const char *kv = getenv("FADEHIP_BAM_SPLIT")) ctx->split_cus = std::max(0, std::min(atoi(kv), 31));
     if (const char *kv = getenv("FADEHIP_P2_WAVES")) ctx->p2_waves_fixed = std::max(0, atoi(kv));
     if (const char *kv = getenv("FADEHIP_SCORE_PERSIST")) ctx->score_persist = atoi(kv) != 0;
     if (const char *kv = getenv("FADEHIP_SCORE_G8")) ctx->score_g8 = atoi(kv);
@@ -1381,13 +1453,20 @@ void fadehip_destroy(fadehip_ctx *ctx) {
 int fadehip_host_alloc(fadehip_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 1));
-    return 0;
+    return pin_alloc(ctx, bytes, out);
 }
 
 int fadehip_host_free(fadehip_ctx *ctx, void *p) {
     if (!p) return 0;
-    HIPCHK(ctx, hipHostFree(p));
+    return pin_free(ctx, p);
+}
+
+int fadehip_host_register(fadehip_ctx *ctx, void *p, size_t bytes) {
+    if (!ctx || !p || !bytes) return set_err(ctx, FADEHIP_E_INVALID, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> l(g_pin_mu);
+    g_pin_registered[p] = false;  // (the caller's memory: fadehip_host_free only takes the registration back)
     return 0;
 }
 
@@ -1839,7 +1918,8 @@ static int bgzf_lane_ready(fadehip_ctx *ctx, int lane, bool one_stream = false) 
         // lets the lanes share one — their copies then no longer overlap each other's kernels; the file path's back half
         // uses the lanes one after the other anyway)
         if (lane > 0 && (one_stream || getenv("FADEHIP_BGZF_ONE_STREAM")) && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
-        else HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        else if (ctx->split_cus > 0) l.stream = xcd_slice_stream(ctx, ctx->split_cus, ctx->cu_count / 8);
+        if (!l.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
         HIPCHK(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
     }
@@ -2116,6 +2196,21 @@ int bam_fail(fadehip_bam_stream *st, int rc) {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// FADEHIP_BAM_TRACE=1: where the first calls of a stream spend their time (buffers, streams and staging memory are made in them)
+struct CallTrace {
+    bool on;
+    const char *who;
+    uint64_t k;
+    double t;
+    CallTrace(const char *w, uint64_t kk) : on(kk < 4 && getenv("FADEHIP_BAM_TRACE")), who(w), k(kk), t(on ? now_s() : 0) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const double n = now_s();
+        fprintf(stderr, "[fadehip trace] %s %llu: %-28s %8.3f ms\n", who, (unsigned long long)k, what, (n - t) * 1e3);
+        t = n;
+    }
+};
+
 // C of call k (see fadehip_bam_stream): waits for the call's run and tag sizes, sizes the output, enqueues the rewrite.
 // Idempotent; front and back may both arrive here for the same call.
 int bam_finish_call(fadehip_bam_stream *st, uint64_t k) {
@@ -2170,11 +2265,19 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     Slot &s = ctx->slots[k & 1];
     int rc;
     // the set's previous call must have been finished (back has usually done that long ago)
+    CallTrace tr("front", k);
+    if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
     if (k >= 2 && (rc = bam_finish_call(st, k - 2))) return rc;
+    tr.mark("finish call k - 2");
     // every stream is an HSA queue to set up and to give back (tens of ms each): slot 0 works on the ctx's copy stream, which
     // exists anyway and which the file path does not use otherwise; slot 1 gets a stream of its own when the second call comes
+    if (ctx->split_cus > 0 && !s.stream && !s.h_zb) {
+        ctx->tail_cus_per_xcd = 0;  // (no third set of CUs)
+        s.stream = xcd_slice_stream(ctx, 0, ctx->split_cus);
+    }
     if (!s.stream && !s.h_zb && (k & 1) == 0 && ctx->copy_stream) s.stream = ctx->copy_stream;
     if ((rc = ensure_slot(ctx, s))) return rc;
+    tr.mark("slot (stream, events)");
     hipStream_t q = s.stream;
     const double t0 = now_s();
     // ---- the members, and where their payloads go
@@ -2204,6 +2307,8 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     if (carry) HIPCHK(ctx, hipMemcpyAsync(u, (const uint8_t *)st->set[(k + 1) & 1].u.p + st->prev_consumed, carry, hipMemcpyDeviceToDevice, q));
     const uint32_t nb = (uint32_t)blocks.size();
     if (raw && n_bytes) HIPCHK(ctx, hipMemcpyAsync(u + carry, members, n_bytes, hipMemcpyHostToDevice, q));
+    const bool fine = tr.on && k == 0 && getenv("FADEHIP_BAM_TRACE_FINE");
+    if (fine) { tr.mark("  copy enqueued"); (void)hipStreamSynchronize(q); tr.mark("  copy waited for"); }
     if (nb) {
         for (auto &b : blocks) b.dst_off += carry;
         if ((rc = reserve_roomy(ctx, S.comp, n_bytes + 16)) || (rc = reserve_roomy(ctx, S.blocks, sizeof(bgzf::InflateBlock) * (size_t)nb)) ||
@@ -2253,8 +2358,10 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         hipLaunchKernelGGL(bam::bam_frame_walk_kernel, dim3((n_seg + bam::WALK_SEGS - 1) / bam::WALK_SEGS), dim3(64), 0, q, fa);
         HIPCHK(ctx, hipGetLastError());
     }
+    if (fine) { tr.mark("  memsets, walk enqueued"); (void)hipStreamSynchronize(q); tr.mark("  waited for"); }
     hipLaunchKernelGGL(bam::bam_frame_resolve_kernel, dim3(1), dim3(64), 0, q, fa);
     HIPCHK(ctx, hipGetLastError());
+    if (fine) { tr.mark("  resolve enqueued"); (void)hipStreamSynchronize(q); tr.mark("  waited for"); }
     hipLaunchKernelGGL(bam::bam_frame_compact_kernel, dim3(std::max(1u, (n_seg + 3) / 4)), dim3(256), 0, q, fa);
     HIPCHK(ctx, hipGetLastError());
     // which records go to the device's gate, their sizes: enqueued behind the framing for as many records as the bytes could
@@ -2279,15 +2386,19 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
     const uint32_t nblk_est = st->rec_bytes_avg > 0 ? (uint32_t)((double)u_len / st->rec_bytes_avg * 1.25 / bam::PACK_BLOCK) + 8u : nblk_cap;
     hipLaunchKernelGGL(bam::bam_pack_count_kernel, dim3(std::max(1u, std::min(nblk_cap, nblk_est))), dim3(bam::PACK_BLOCK), 0, q, pa);
     HIPCHK(ctx, hipGetLastError());
+    if (fine) { tr.mark("  compact, pack count enqueued"); (void)hipStreamSynchronize(q); tr.mark("  waited for"); }
     hipLaunchKernelGGL(bam::bam_pack_scan_kernel, dim3(1), dim3(1024), 0, q, pa, nblk_cap);
     HIPCHK(ctx, hipGetLastError());
+    if (fine) { tr.mark("  pack scan enqueued"); (void)hipStreamSynchronize(q); tr.mark("  waited for"); }
     HIPCHK(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, q));
     uint32_t *h_tick = (uint32_t *)(S.h_counts.p + sizeof(bam::ChunkCounts));
     h_tick[0] = h_tick[1] = 0;
     if (nb) HIPCHK(ctx, hipMemcpyAsync(h_tick, S.ticket.p, 8, hipMemcpyDeviceToHost, q));
     const double t1 = now_s();
+    tr.mark("A enqueued");
     HIPCHK(ctx, hipStreamSynchronize(q));  // (1) the records of this call and the sizes of their batch
     const double t2 = now_s();
+    tr.mark("A waited for");
     st->t_inflate += t1 - t0;
     st->t_frame += t2 - t1;
     if (nb && h_tick[1]) {
@@ -2313,6 +2424,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         st->cv.wait(l, [&] { return out->state == 0 || st->failed || st->closing; });
         if (st->failed || st->closing) return set_err(ctx, FADEHIP_E_STATE, "bam stream: stopped");
     }
+    tr.mark("place in the ring");
     out->bytes = 0;
     S.k = k;
     S.n_rec = n_rec;
@@ -2346,6 +2458,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         pa.seq = ib + s.L.off[A_SEQ];
         hipLaunchKernelGGL(bam::bam_pack_write_kernel, dim3(nblk), dim3(bam::PACK_BLOCK), 0, q, pa);
         HIPCHK(ctx, hipGetLastError());
+        tr.mark("pack enqueued");
         // ---- annotateTask on the device (level 2's kernels), results left there
         s.n_reads = (int)n_sent;
         s.n_skipped = (int)(n_rec - n_sent);
@@ -2373,6 +2486,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
             }
             s.state = 2;
         }
+        tr.mark("run planned and enqueued");
         // ---- what anno.d:94-107 adds: sizes, offsets
         if ((rc = reserve_roomy(ctx, S.art_of, 4 * (size_t)std::max(n_sent, 1u)))) return rc;
         if (n_sent) {
@@ -2412,6 +2526,7 @@ int bam_front_impl(fadehip_bam_stream *st, const uint8_t *members, size_t n_byte
         S.ntb = ntb;
     }
     S.pending = true;
+    tr.mark("tag sizes enqueued");
     st->t_run += now_s() - t2;
     // the inflated bytes of this call are read by the next call's carry copy and by this call's rewrite, which change nothing;
     // the set's buffers are written again by call k + 2, whose front finishes this call first.
@@ -2431,7 +2546,6 @@ int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_ba
     if (!ctx) return set_err(nullptr, FADEHIP_E_INVALID, "ctx is NULL");
     if (!cfg || !out || cfg->n_ref < 0 || (cfg->n_ref && !cfg->ref_names) || cfg->window < 0 || (cfg->flags & ~(FADEHIP_BAM_STORED | FADEHIP_BAM_NO_OUTPUT)))
         return set_err(ctx, FADEHIP_E_INVALID, "bam stream: bad configuration");
-    if (ctx->n_contigs == 0) return set_err(ctx, FADEHIP_E_STATE, "fadehip_genome_upload has not been called");
     if (!ctx->two_pass) return set_err(ctx, FADEHIP_E_UNSUPPORTED, "bam stream: needs the default kernels (FADEHIP_KERNEL unset)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     fadehip_bam_stream *st = new (std::nothrow) fadehip_bam_stream;
@@ -2462,6 +2576,88 @@ int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_ba
         return set_err(ctx, FADEHIP_E_HIP, "bam stream: copying the contig names failed");
     }
     *out = st;
+    return 0;
+}
+
+// What the first calls of a stream would otherwise make one after the other, each in its turn holding up the thread that
+// came to it — the second slot's stream and the compressor lanes' streams (HSA queues: 7-10 ms each, and a launch on
+// another thread waits meanwhile), the three staging buffers of the members, the inflated bytes' buffers — made here side by
+// side; then one copy up, one down and one wait per stream (the first of each costs milliseconds).  Optional, and meant
+// for a thread of its own beside the caller's own start-up (reading the FASTA, the input's first members).
+int fadehip_bam_prepare(fadehip_bam_stream *st, size_t call_bytes) {
+    if (!st) return set_err(nullptr, FADEHIP_E_INVALID, "stream is NULL");
+    fadehip_ctx *ctx = st->ctx;
+    if (call_bytes == 0 || call_bytes > (size_t)bam::MAX_U) return set_err(ctx, FADEHIP_E_INVALID, "bam stream: prepare takes the inflated bytes of a call (1 .. %u)", bam::MAX_U);
+    if (st->k_front) return set_err(ctx, FADEHIP_E_STATE, "bam stream: prepare comes before the first front call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double t0 = now_s();
+    static const bool one_stream = getenv("FADEHIP_BAM_BACK_STREAMS") && atoi(getenv("FADEHIP_BAM_BACK_STREAMS")) == 1;
+    int rcs[4] = {0, 0, 0, 0};
+    std::string errs[4];
+    const bool with_out = !st->no_output;
+    // lane 0 first on this thread when the lanes share a stream (lane 1 borrows it); the function attributes are set once, there
+    if (with_out && (rcs[0] = bgzf_lane_ready(ctx, 0, one_stream))) return rcs[0];
+    const double t_lane0 = now_s();
+    std::vector<std::thread> th;
+    auto side = [&](int slot_no, auto fn) {
+        th.emplace_back([&, slot_no, fn] {
+            if (hipSetDevice(ctx->device) != hipSuccess) { rcs[slot_no] = FADEHIP_E_HIP; errs[slot_no] = "hipSetDevice failed"; return; }
+            if ((rcs[slot_no] = fn())) errs[slot_no] = fadehip_last_error(ctx);
+        });
+    };
+    side(1, [&]() -> int {  // the second slot: a stream of its own
+        Slot &s = ctx->slots[1];
+        if (ctx->split_cus > 0 && !s.stream && !s.h_zb) s.stream = xcd_slice_stream(ctx, 0, ctx->split_cus);
+        return ensure_slot(ctx, s);
+    });
+    if (with_out) side(2, [&]() -> int { return bgzf_lane_ready(ctx, 1, one_stream); });
+    // this thread: the first slot (on the ctx's copy stream), the buffers
+    int rc = 0;
+    {
+        Slot &s = ctx->slots[0];
+        if (ctx->split_cus > 0 && !s.stream && !s.h_zb) {
+            ctx->tail_cus_per_xcd = 0;
+            s.stream = xcd_slice_stream(ctx, 0, ctx->split_cus);
+        }
+        if (!s.stream && !s.h_zb && ctx->copy_stream) s.stream = ctx->copy_stream;
+        rc = ensure_slot(ctx, s);
+    }
+    const size_t carry_room = 65536;
+    for (int q = 0; q < 2 && !rc; q++) {
+        fadehip_bam_stream::Set &S = st->set[q];
+        if (!(rc = reserve_roomy(ctx, S.u, call_bytes + carry_room + 256))) rc = reserve_pinned(ctx, S.h_counts, sizeof(bam::ChunkCounts) + 16);
+        if (!rc) rc = reserve_roomy(ctx, S.counts, sizeof(bam::ChunkCounts));
+    }
+    // (annotated records are a few per cent longer than the call's; the members' bound is the compressor's own)
+    const size_t out_est = call_bytes + call_bytes / 8;
+    for (int q = 0; q < FADEHIP_BAM_CHUNKS && !rc && with_out; q++)
+        rc = reserve_pinned(ctx, st->outbuf[q], st->stored ? (out_est / bgzf::STORE_BLOCK + 2) * bgzf::STORE_MEMBER : bgzf_out_cap(out_est, 32));
+    const double t_mine = now_s();
+    for (auto &t : th) t.join();
+    if (getenv("FADEHIP_BAM_TRACE")) fprintf(stderr, "[fadehip trace] prepare: lane 0 %.3f ms, own part (slot 0, buffers) %.3f ms, the side threads %.3f ms more\n", (t_lane0 - t0) * 1e3, (t_mine - t_lane0) * 1e3, (now_s() - t_mine) * 1e3);
+    if (rc) return rc;
+    for (int q = 1; q < 4; q++)
+        if (rcs[q]) return set_err(ctx, rcs[q], "bam stream: prepare: %s", errs[q].c_str());
+    // the first copy, the first wait of every stream
+    const double t1 = now_s();
+    if (with_out && st->outbuf[0].p) {
+        for (int q = 0; q < 2; q++) {
+            fadehip_bam_stream::Set &S = st->set[q];
+            hipStream_t sq = ctx->slots[q].stream;
+            const size_t n = std::min(call_bytes, st->outbuf[q].cap);
+            HIPCHK(ctx, hipMemcpyAsync(S.u.p, st->outbuf[q].p, n, hipMemcpyHostToDevice, sq));
+            HIPCHK(ctx, hipMemsetAsync(S.counts.p, 0, sizeof(bam::ChunkCounts), sq));
+            HIPCHK(ctx, hipMemcpyAsync(S.h_counts.p, S.counts.p, sizeof(bam::ChunkCounts), hipMemcpyDeviceToHost, sq));
+        }
+        for (int q = 0; q < 2; q++) HIPCHK(ctx, hipStreamSynchronize(ctx->slots[q].stream));
+        for (int q = 0; q < 2; q++) {
+            BgzfLane &l = ctx->bgzf[q];
+            HIPCHK(ctx, hipMemcpyAsync(l.h_total, st->set[0].counts.p, 8, hipMemcpyDeviceToHost, l.stream));
+            HIPCHK(ctx, hipEventRecord(l.done, l.stream));
+            HIPCHK(ctx, hipEventSynchronize(l.done));
+        }
+    }
+    if (getenv("FADEHIP_BAM_TRACE")) fprintf(stderr, "[fadehip trace] prepare: streams and buffers %.3f ms, first copies and waits %.3f ms\n", (t1 - t0) * 1e3, (now_s() - t1) * 1e3);
     return 0;
 }
 
@@ -2503,7 +2699,9 @@ static int bam_submit_back(fadehip_bam_stream *st, uint64_t k) {
     fadehip_ctx *ctx = st->ctx;
     fadehip_bam_stream::Out *o = &st->ring[k % FADEHIP_BAM_CHUNKS];
     int rc;
+    CallTrace tr("back", k);
     if ((rc = bam_finish_call(st, k))) return rc;
+    tr.mark("finish call");
     st->k_sub = k + 1;
     if (!o->bytes || st->no_output) return 0;
     const int lane = (int)(k & 1);
@@ -2511,6 +2709,7 @@ static int bam_submit_back(fadehip_bam_stream *st, uint64_t k) {
     // before call k + 1's compressor starts instead of beside it)
     static const bool one_stream = getenv("FADEHIP_BAM_BACK_STREAMS") && atoi(getenv("FADEHIP_BAM_BACK_STREAMS")) == 1;
     if ((rc = bgzf_lane_ready(ctx, lane, one_stream))) return rc;
+    tr.mark("lane (stream)");
     BgzfLane &l = ctx->bgzf[lane];
     if (hipStreamWaitEvent(l.stream, o->ready, 0) != hipSuccess) return set_err(ctx, FADEHIP_E_HIP, "bam stream: hipStreamWaitEvent failed");
     PinBuf &ob = st->outbuf[k % FADEHIP_BAM_CHUNKS];
@@ -2527,7 +2726,9 @@ static int bam_submit_back(fadehip_bam_stream *st, uint64_t k) {
         l.state = 1;
         return 0;
     }
-    return bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes, bgzf_pick_geom(ctx), &ob);
+    rc = bgzf_enqueue(ctx, lane, (const uint8_t *)o->o.p, o->bytes, bgzf_pick_geom(ctx), &ob);
+    tr.mark("compressor enqueued");
+    return rc;
 }
 
 int fadehip_bam_back(fadehip_bam_stream *st, const uint8_t **out, size_t *out_bytes) {

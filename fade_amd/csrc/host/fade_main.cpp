@@ -441,11 +441,36 @@ static void apply_tags(Chunk &c, const Header &h, Pool &pool) {
     }, CPU_TAGS);
 }
 
+// FADE_TRACE=1: every start / stop pair of a named stage clock as a line on stderr at the end (ms since the first one)
+struct StageTrace {
+    bool on = getenv("FADE_TRACE") != nullptr;
+    std::mutex m;
+    std::chrono::steady_clock::time_point origin = std::chrono::steady_clock::now();
+    struct Ev { const char *name; double t0, t1; };
+    std::vector<Ev> ev;
+    void add(const char *name, std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        std::lock_guard<std::mutex> l(m);
+        ev.push_back(Ev{name, std::chrono::duration<double>(a - origin).count(), std::chrono::duration<double>(b - origin).count()});
+    }
+    void dump() {
+        if (!on) return;
+        std::lock_guard<std::mutex> l(m);
+        std::sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &b) { return a.t0 < b.t0; });
+        for (auto &e : ev) fprintf(stderr, "[trace] %-8s %9.3f ms  +%8.3f ms\n", e.name, e.t0 * 1e3, (e.t1 - e.t0) * 1e3);
+    }
+};
+static StageTrace g_trace;
+
 struct StageClock {
     double t = 0;
+    const char *name = nullptr;
     std::chrono::steady_clock::time_point t0;
     void start() { t0 = std::chrono::steady_clock::now(); }
-    void stop() { t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    void stop() {
+        const auto t1 = std::chrono::steady_clock::now();
+        t += std::chrono::duration<double>(t1 - t0).count();
+        if (g_trace.on && name) g_trace.add(name, t0, t1);
+    }
 };
 
 // joins the stage threads on every way out of annotate_main (an exception past a joinable std::thread is std::terminate)
@@ -991,6 +1016,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     struct stat sb;
     if (!(o.bam || o.ubam) || path == "-" || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
     StageClock ck_total, ck_fasta, ck_upload, ck_front, ck_back, ck_fwrite, ck_fread, ck_inflate;
+    ck_fasta.name = "fasta"; ck_upload.name = "upload"; ck_front.name = "front"; ck_back.name = "back"; ck_fwrite.name = "fwrite"; ck_fread.name = "fread"; ck_inflate.name = "inflate";
     ck_total.start();
     const int nthreads = o.threads > 0 ? o.threads : default_threads();
     // Who inflates: the device (FADE_BAM_INFLATE=device: only compressed bytes cross PCIe, the host cores stay free) or this
@@ -1060,13 +1086,14 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
     struct Guard {
         fadehip_ctx *&c;
         fadehip_bam_stream *&s;
-        std::vector<void *> pinned;
+        std::vector<void *> pinned, owned;  // registered with the ctx; allocated here
         ~Guard() {
             if (s) fadehip_bam_close(s);
             for (void *p : pinned) fadehip_host_free(c, p);
             fadehip_destroy(c);
+            for (void *p : owned) free(p);
         }
-    } guard{ctx, st, {}};
+    } guard{ctx, st, {}, {}};
     try {
         fadehip_params prm;
         fadehip_params_default(&prm);
@@ -1075,49 +1102,52 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         int device = 0;
         if (lane.on) device = lane.device;
         else if (const char *dm = getenv("FADE_DEVICE_MAP")) device = atoi(dm);
+        if (hdr.names.empty()) { fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n"); return 1; }
+        // FADE_BAM_CHUNK_MB: bytes per front call — compressed when the device inflates (default 128), inflated when the
+        // host does (default 32: the first call starts earlier and the last one drains sooner; 64 and 128 measured slower).
+        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : host_inflate ? 32 : 128) << 20;
+        // The device is brought up on a thread of its own, beside everything the host can do without it (the FASTA, the input's
+        // first members read and inflated): the ctx (the HIP runtime's own start is most of it), then the stream and what its
+        // first calls would otherwise make one by one (fadehip_bam_prepare).  The genome goes up as soon as the ctx is there.
         std::string create_err;
+        std::promise<int> ctx_made;
+        std::future<int> ctx_ready = ctx_made.get_future();
         std::future<int> creating = std::async(std::launch::async, [&]() -> int {
-            if (fadehip_create(&ctx, device, &prm)) { create_err = fadehip_last_error(nullptr); return 1; }
+            if (fadehip_create(&ctx, device, &prm)) { create_err = fadehip_last_error(nullptr); ctx_made.set_value(1); return 1; }
+            ctx_made.set_value(0);
+            std::vector<const char *> names;
+            for (auto &n : hdr.names) names.push_back(n.c_str());
+            fadehip_bam_config cfg;
+            memset(&cfg, 0, sizeof cfg);
+            cfg.floor_len = o.floor_len;
+            cfg.window = o.window;
+            cfg.n_ref = (int32_t)names.size();
+            cfg.ref_names = names.data();
+            cfg.first_record = first_rec;
+            cfg.tail_trim = host_inflate ? 0 : tail_trim;
+            cfg.flags = o.ubam ? FADEHIP_BAM_STORED : 0;  // -u: uncompressed BGZF (util.d:65-76, SAMWriterTypes.UBAM)
+            if (fadehip_bam_open(ctx, &cfg, &st)) { create_err = fadehip_last_error(ctx); return 1; }
+            const size_t call_bytes = host_inflate ? chunk : std::min<size_t>(chunk * 3, (size_t)1 << 30);
+            if (!(getenv("FADE_BAM_PREPARE") && atoi(getenv("FADE_BAM_PREPARE")) == 0) && fadehip_bam_prepare(st, call_bytes)) { create_err = fadehip_last_error(ctx); return 1; }
             return 0;
         });
-        ck_fasta.start();
-        Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
-        ck_fasta.stop();
-        Header out_hdr = hdr;
-        out_hdr.add_pg("fade-annotate", "fade", FADE_VERSION, lane.on ? lane.cl : cl);  // anno.d:25-32
-        std::vector<int64_t> lens(hdr.names.size());
-        std::vector<const uint8_t *> ptrs(hdr.names.size());
-        for (size_t k = 0; k < hdr.names.size(); k++) {
-            size_t q = 0;
-            while (q < fa.names.size() && fa.names[q] != hdr.names[k]) q++;
-            if (q == fa.names.size()) { fprintf(stderr, "[E::fade annotate] reference %s of the BAM header is not in %s\n", hdr.names[k].c_str(), o.pos[2].c_str()); return 1; }
-            if ((int64_t)fa.seqs[q].size() < hdr.lens[k]) {
-                fprintf(stderr, "[E::fade annotate] %s is shorter in the FASTA (%zu) than in the header (%lld)\n", hdr.names[k].c_str(), fa.seqs[q].size(), (long long)hdr.lens[k]);
-                return 1;
-            }
-            lens[k] = hdr.lens[k];
-            ptrs[k] = (const uint8_t *)fa.seqs[q].data();
-        }
-        if (hdr.names.empty()) { fprintf(stderr, "[E::fade annotate] input has no @SQ lines\n"); return 1; }
-        ck_upload.start();
-        if (creating.get()) { fprintf(stderr, "[E::fade annotate] cannot open the GPU path: %s\n", create_err.c_str()); return 1; }
-        ck_upload.stop();
         // ---- the stages
-        // FADE_BAM_CHUNK_MB: bytes per front call — compressed when the device inflates (default 128), inflated when the
-        // host does (default 32: the first call starts earlier and the last one drains sooner; 64 and 128 measured slower).  Compressed bytes are read
-        // by a thread of their own, HEAD bytes into a buffer, so that a member cut by the end of one read is completed by
-        // copying its beginning in front of the next.
-        const size_t chunk = (size_t)std::max(1, getenv("FADE_BAM_CHUNK_MB") ? atoi(getenv("FADE_BAM_CHUNK_MB")) : host_inflate ? 32 : 128) << 20;
+        // Compressed bytes are read by a thread of their own, HEAD bytes into a buffer, so that a member cut by the end of one
+        // read is completed by copying its beginning in front of the next.
         const size_t ccap = host_inflate ? std::max<size_t>(chunk / 2, 1 << 20) : chunk, HEAD = 65536 + 64;
         constexpr int NBUF = 3;
         struct CBuf { uint8_t *p = nullptr; size_t n = 0; uint64_t off = 0; bool eof = false; std::vector<uint8_t> own; };
         struct In { uint8_t *p = nullptr, *pin = nullptr; size_t n = 0; bool last = false, compressed = false; int cbuf = -1; };
         CBuf cbufs[NBUF];
         In bufs[NBUF];
+        // (ordinary memory for now — the ctx is still being made; registered with it once it is there)
+        std::vector<std::pair<void *, size_t>> raw_bufs;
         auto pinned = [&](size_t bytes) -> uint8_t * {
-            void *q = nullptr;
-            if (fadehip_host_alloc(ctx, bytes, &q)) throw std::runtime_error(fadehip_last_error(ctx));
-            guard.pinned.push_back(q);
+            const size_t al = (size_t)1 << 21, n = (bytes + al - 1) & ~(al - 1);
+            void *q = aligned_alloc(al, n);
+            if (!q) throw std::runtime_error("out of memory");
+            guard.owned.push_back(q);
+            raw_bufs.emplace_back(q, n);
             return (uint8_t *)q;
         };
         // FADE_BAM_DEVICE_SHARE=n: with the pool inflating, every n-th call's members go to the device as they are (inflated by
@@ -1126,6 +1156,8 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
         const int dev_share = host_inflate ? std::max(0, getenv("FADE_BAM_DEVICE_SHARE") ? atoi(getenv("FADE_BAM_DEVICE_SHARE")) : 0) : 0;
         std::atomic<int> cbuf_refs[NBUF];
         for (auto &r : cbuf_refs) r = 0;
+        // (Reading the members where the page cache has them — the file mapped, its pages entered by MADV_POPULATE_READ —
+        // was measured and is slower than pread into a buffer: the pool inflates 20-30 % slower out of the mapping.)
         for (int k = 0; k < NBUF; k++) {
             if (host_inflate) {
                 if (dev_share) cbufs[k].p = pinned(HEAD + ccap + 64);  // (some of its members cross PCIe as they are)
@@ -1317,6 +1349,42 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
             }
             q_full.close();
         });
+        ck_fasta.start();
+        Fasta fa = load_fasta(o.pos[2]);  // anno.d:23
+        ck_fasta.stop();
+        Header out_hdr = hdr;
+        out_hdr.add_pg("fade-annotate", "fade", FADE_VERSION, lane.on ? lane.cl : cl);  // anno.d:25-32
+        std::vector<int64_t> lens(hdr.names.size());
+        std::vector<const uint8_t *> ptrs(hdr.names.size());
+        for (size_t k = 0; k < hdr.names.size(); k++) {
+            size_t q = 0;
+            while (q < fa.names.size() && fa.names[q] != hdr.names[k]) q++;
+            if (q == fa.names.size()) { fprintf(stderr, "[E::fade annotate] reference %s of the BAM header is not in %s\n", hdr.names[k].c_str(), o.pos[2].c_str()); return 1; }
+            if ((int64_t)fa.seqs[q].size() < hdr.lens[k]) {
+                fprintf(stderr, "[E::fade annotate] %s is shorter in the FASTA (%zu) than in the header (%lld)\n", hdr.names[k].c_str(), fa.seqs[q].size(), (long long)hdr.lens[k]);
+                return 1;
+            }
+            lens[k] = hdr.lens[k];
+            ptrs[k] = (const uint8_t *)fa.seqs[q].data();
+        }
+        ck_upload.start();
+        if (ctx_ready.get()) { fprintf(stderr, "[E::fade annotate] cannot open the GPU path: %s\n", create_err.c_str()); return 1; }
+        // the buffers the reader has been filling become staging memory now
+        for (auto &rb : raw_bufs) {
+            if (fadehip_host_register(ctx, rb.first, rb.second)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
+            guard.pinned.push_back(rb.first);
+        }
+        if (fadehip_genome_upload(ctx, (int)lens.size(), lens.data(), ptrs.data())) { fprintf(stderr, "[E::fade annotate] genome upload: %s\n", fadehip_last_error(ctx)); return 1; }
+        // the header goes out through the CPU writer (its members only: no end-of-file block yet; not a byte without a device)
+        {
+            Writer hw(stdout, o.ubam ? OutFmt::UBAM : OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0 || lane.shard, false);
+            hw.close();
+        }
+        if (creating.get()) { fprintf(stderr, "[E::fade annotate] cannot open the GPU path: %s\n", create_err.c_str()); return 1; }
+        ck_upload.stop();
+        // (the FASTA's text is on the device now; giving a genome's worth of pages back takes milliseconds, and the first call
+        // is waiting: on a thread of its own)
+        std::thread([seqs = std::move(fa.seqs)]() mutable { seqs.clear(); seqs.shrink_to_fit(); }).detach();
         stages.th.emplace_back([&] {  // back: compress, hand to the writer
             int tok;
             try {
@@ -1382,29 +1450,6 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                 q_credit.push(0);
             }
         });
-        // (the reader and the inflating pool are at work by now: the genome goes up beside them)
-        ck_upload.start();
-        if (fadehip_genome_upload(ctx, (int)lens.size(), lens.data(), ptrs.data())) { fprintf(stderr, "[E::fade annotate] genome upload: %s\n", fadehip_last_error(ctx)); return 1; }
-        std::vector<const char *> names;
-        for (auto &n : hdr.names) names.push_back(n.c_str());
-        fadehip_bam_config cfg;
-        memset(&cfg, 0, sizeof cfg);
-        cfg.floor_len = o.floor_len;
-        cfg.window = o.window;
-        cfg.n_ref = (int32_t)names.size();
-        cfg.ref_names = names.data();
-        cfg.first_record = first_rec;
-        cfg.tail_trim = host_inflate ? 0 : tail_trim;
-        cfg.flags = o.ubam ? FADEHIP_BAM_STORED : 0;  // -u: uncompressed BGZF (util.d:65-76, SAMWriterTypes.UBAM)
-        if (fadehip_bam_open(ctx, &cfg, &st)) { fprintf(stderr, "[E::fade annotate] %s\n", fadehip_last_error(ctx)); return 1; }
-        ck_upload.stop();
-        fa.seqs.clear();
-        fa.seqs.shrink_to_fit();
-        // the header goes out through the CPU writer (its members only: no end-of-file block yet)
-        {
-            Writer hw(stdout, o.ubam ? OutFmt::UBAM : OutFmt::BAM, out_hdr, &pool, nullptr, !lane.on || lane.k == 0 || lane.shard, false);
-            hw.close();
-        }
         {
             struct stat so;
             const int fl = fcntl(1, F_GETFL);
@@ -1480,6 +1525,7 @@ static int annotate_stream_main(const std::string &cl, const Opts &o, bool *fall
                             "back (deflate, copy out) %.3f | fwrite %.3f (stages overlap); %lld records\n",
                     ck_total.t, ck_fasta.t, ck_upload.t, ck_fread.t, host_inflate ? pool.size() : 0, ck_inflate.t, host_inflate ? "" : "inflate, ", ck_front.t, ck_back.t, ck_fwrite.t, (long long)n_rec);
         }
+        g_trace.dump();
         if (getenv("FADEHIP_BAM_PROF")) { fadehip_bam_close(st); st = nullptr; }  // (prints the library's own clocks)
         if (!(getenv("FADE_FAST_EXIT") && atoi(getenv("FADE_FAST_EXIT")) == 0)) {
             if (o.timing) fprintf(stderr, "[timing] since process start %.3f s (leaving by _exit)\n", since_process_start());

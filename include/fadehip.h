@@ -107,9 +107,12 @@ int fadehip_create(fadehip_ctx **out, int device, const fadehip_params *params);
 void fadehip_destroy(fadehip_ctx *ctx);
 const char *fadehip_last_error(const fadehip_ctx *ctx); /* never NULL; ctx may be NULL */
 
-/* Pinned host memory so that submit can use hipMemcpyAsync. */
+/* Pinned host memory so that submit can use hipMemcpyAsync.  fadehip_host_register pins memory the caller already has
+ * (and may have been filling before the ctx existed: a reader that starts while the device is still being brought up);
+ * fadehip_host_free takes the registration back and leaves the memory to the caller. */
 int fadehip_host_alloc(fadehip_ctx *ctx, size_t bytes, void **out);
 int fadehip_host_free(fadehip_ctx *ctx, void *p);
+int fadehip_host_register(fadehip_ctx *ctx, void *p, size_t bytes);
 
 /* ------------------------------------------------------------------ Level 1: the SW seam -- */
 /* What FADE reads from a parasail result (analysis.d:69-113): res.score, res.position
@@ -304,7 +307,13 @@ int fadehip_bgzf_inflate(fadehip_ctx *ctx, const void *members, size_t n_bytes, 
  * tag of the wrong kind — rs:Z, am:i — is left as it is, as htslib's EINVAL leaves it).  Errors (corrupt member, impossible
  * record, input ending inside a record when last != 0) fail the call and every later one; what the device finds in a
  * call's records after front has returned surfaces at the call's back.  fadehip_bam_totals counts the calls back has taken.
- * The genome must have been uploaded (fadehip_genome_upload); the stream uses the ctx's slots 0 and 1 and both BGZF lanes. */
+ * The genome must have been uploaded (fadehip_genome_upload) by the first front call; the stream uses the ctx's slots 0 and
+ * 1 and both BGZF lanes.
+ * fadehip_bam_prepare (optional, before the first front call, typically on a thread of its own beside the caller's start-up):
+ * makes what the first calls would otherwise make one after the other — the streams of the second slot and of the
+ * compressor, the staging buffers of the members, the buffers of call_bytes inflated bytes — side by side, and pays for
+ * the first copy and the first wait of every stream.  The genome may go up meanwhile (fadehip_genome_upload on another
+ * thread).  Results do not depend on it. */
 typedef struct fadehip_bam_stream fadehip_bam_stream;
 typedef struct fadehip_bam_config {
     int32_t floor_len;            /* --min-length (anno.d: artifact_floor_length) */
@@ -323,6 +332,7 @@ typedef struct fadehip_bam_config {
 #define FADEHIP_BAM_STORED 1
 #define FADEHIP_BAM_NO_OUTPUT 2
 int fadehip_bam_open(fadehip_ctx *ctx, const fadehip_bam_config *cfg, fadehip_bam_stream **out);
+int fadehip_bam_prepare(fadehip_bam_stream *st, size_t call_bytes);
 int fadehip_bam_front(fadehip_bam_stream *st, const void *members, size_t n_bytes, int last);
 /* front for a caller that inflates itself (host cores otherwise idle; the device then spends its time on the rest):
  * payload = the members' inflated bytes, any cut, pinned memory for PCIe speed.  Calls of both kinds may alternate. */

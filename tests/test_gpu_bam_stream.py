@@ -259,6 +259,71 @@ def test_stream_api_one_member_per_call(big):
     assert n_rec == 30000 and totals[0] == 30000 and n_over == 0
 
 
+def test_a_stream_opened_and_prepared_before_the_genome_is_there(big):
+    """fadehip_bam_open before fadehip_genome_upload, fadehip_bam_prepare on a thread of its own while the genome goes up (what
+    `fade annotate` does while the device is brought up): front before the genome is an error, prepare after the first front is
+    one, and the bytes are the ones of a stream that was never prepared."""
+    import threading
+    raw = big["bam"].read_bytes()
+    payload = gzip.decompress(raw)
+    l_text = struct.unpack_from("<i", payload, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", payload, at)[0]
+    at += 4
+    names = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", payload, at)[0]
+        names.append(payload[at + 4:at + 4 + ln - 1].decode())
+        at += 4 + ln + 4
+    hdr_bytes = at
+    ms = _members(raw)
+    cum, k = 0, 0
+    while cum + struct.unpack_from("<I", ms[k], len(ms[k]) - 4)[0] <= hdr_bytes:
+        cum += struct.unpack_from("<I", ms[k], len(ms[k]) - 4)[0]
+        k += 1
+    body = ms[k:]
+    calls = [b"".join(body[j:j + 40]) for j in range(0, len(body), 40)]
+    g = big["g"]
+    outs = []
+    for prepared in (True, False):
+        ctx = fade_amd.Context(device=0)
+        try:
+            if prepared:
+                st = ctx.bam_stream(names, floor_len=5, window=100, first_record=hdr_bytes - cum)
+                with pytest.raises(fade_amd.FadeHipError, match="genome"):
+                    st.front(calls[0], last=False)
+                st.close()
+                st = ctx.bam_stream(names, floor_len=5, window=100, first_record=hdr_bytes - cum)
+                err = []
+
+                def prep():
+                    try:
+                        st.prepare(40 * 65280)
+                    except Exception as e:  # noqa: BLE001 (reported on the test's thread)
+                        err.append(e)
+                t = threading.Thread(target=prep)
+                t.start()
+                ctx.genome_upload(g.names, g.ascii_contigs())
+                t.join()
+                assert not err, err
+            else:
+                ctx.genome_upload(g.names, g.ascii_contigs())
+                st = ctx.bam_stream(names, floor_len=5, window=100, first_record=hdr_bytes - cum)
+            out = []
+            for j, c in enumerate(calls):
+                st.front(c, last=(j == len(calls) - 1))
+                if j == 0:
+                    with pytest.raises(fade_amd.FadeHipError, match="before the first front"):
+                        st.prepare(1 << 20)
+                out.append(st.back())
+            totals, n_rec, _ = st.totals()
+            st.close()
+            outs.append((gzip.decompress(b"".join(out)), totals, n_rec))
+        finally:
+            ctx.close()
+    assert outs[0] == outs[1] and outs[0][2] == 30000
+
+
 def test_a_tiny_last_call_whose_last_member_is_mostly_another_readers(big):
     """tail_trim (a lane's last member belongs mostly to the next lane): the inflater still writes the member's whole
     ISIZE, so the call's buffer must be sized from the untrimmed length — here the last call inflates to 64 KB of which a

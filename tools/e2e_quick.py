@@ -45,7 +45,7 @@ for v in variants:
                                stderr=subprocess.PIPE, env=env)
         dt = time.perf_counter() - t0
         r = dict(seconds=dt, reads_per_s=n / dt, rc=p.returncode, out_bytes=os.path.getsize(out),
-                 timing=[l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith(("[timing]", "[fadehip"))])
+                 timing=[l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith(("[timing]", "[fadehip", "[trace]"))])
         if best is None or dt < best["seconds"]:
             best = r
     res[label] = best
