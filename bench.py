@@ -145,7 +145,7 @@ def e2e_run(exe, bam, fa, n_reads, cfg, threads, out, reps, env=None):
     return best
 
 
-def e2e_legs(bam, fa, n_reads, cfg, threads, tmp, which=("gpu", "gpu_device_inflate", "gpu_host_pipeline", "cpu")):
+def e2e_legs(bam, fa, n_reads, cfg, threads, tmp, which=("gpu", "gpu_device_inflate", "gpu_host_pipeline", "cpu", "cpu_zlib")):
     """The whole program on a BAM file, GPU driver and CPU comparator on the same threads: wall time of each process
     (start-up, FASTA load and genome upload, BGZF inflate, annotate, tags, BGZF deflate, exit), best of 2 runs for EVERY leg."""
     fade = os.path.join(ROOT, "fade_amd", "fade")
@@ -156,8 +156,10 @@ def e2e_legs(bam, fa, n_reads, cfg, threads, tmp, which=("gpu", "gpu_device_infl
         "gpu_device_inflate": (fade, {"FADE_BAM_INFLATE": "device"}),  # ... inflate on the device too
         "gpu_host_pipeline": (fade, {"FADE_BAM_DEVICE": "0"}),        # round 2's pipeline (+ device deflate)
         "cpu": (cpu, None),
+        # the comparator with the codec reference FADE links (htslib's defaults: zlib's inflate, zlib level 6): one run
+        "cpu_zlib": (cpu, {"FADE_BGZF_CODEC": "zlib"}),
     }
-    return {k: e2e_run(legs[k][0], bam, fa, n_reads, cfg, threads, os.path.join(tmp, "bench_e2e.%s.bam" % k), 2, legs[k][1]) for k in which}
+    return {k: e2e_run(legs[k][0], bam, fa, n_reads, cfg, threads, os.path.join(tmp, "bench_e2e.%s.bam" % k), 1 if k == "cpu_zlib" else 2, legs[k][1]) for k in which}
 
 
 def bgzf_chunks(path, chunk_payload):
@@ -633,12 +635,16 @@ def main():
                                   "FADE_BAM_DEVICE=0 (records handled by the host pool, level-2 batches to the device, deflate on the device); "
                                   "cpu = tools/cpu_annotate: the same reader / writer / codec around the CPU oracle — this build's own fast inflate / "
                                   "deflate / CRC (several times zlib's speed), so a STRONGER comparator than reference FADE's htslib + zlib -6 would be.  "
-                                  "Every leg is the best of 2 runs" % (e2e_written, usable_cpus()),
+                                  "cpu_zlib = the same comparator with FADE_BGZF_CODEC=zlib (zlib's inflate, zlib level-6 deflate: htslib's defaults, "
+                                  "what the reference program links), one run.  Every other leg is the best of 2 runs" % (e2e_written, usable_cpus()),
                           "gpu_reads_per_s": g.get("reads_per_s"), "cpu_reads_per_s": c.get("reads_per_s"),
                           "gpu_over_cpu": (g["reads_per_s"] / c["reads_per_s"]) if g.get("reads_per_s") and c.get("reads_per_s") else None,
                           "gpu_device_inflate_reads_per_s": (e.get("gpu_device_inflate") or {}).get("reads_per_s"),
                           "gpu_host_pipeline_reads_per_s": (e.get("gpu_host_pipeline") or {}).get("reads_per_s"),
-                          "gpu": g, "gpu_device_inflate": e.get("gpu_device_inflate"), "gpu_host_pipeline": e.get("gpu_host_pipeline"), "cpu": c}
+                          "cpu_zlib_reads_per_s": (e.get("cpu_zlib") or {}).get("reads_per_s"),
+                          "gpu_over_cpu_zlib": (g["reads_per_s"] / e["cpu_zlib"]["reads_per_s"]) if g.get("reads_per_s") and (e.get("cpu_zlib") or {}).get("reads_per_s") else None,
+                          "gpu": g, "gpu_device_inflate": e.get("gpu_device_inflate"), "gpu_host_pipeline": e.get("gpu_host_pipeline"), "cpu": c,
+                          "cpu_zlib": e.get("cpu_zlib")}
             if e.get("big"):
                 bg, bc = e["big"].get("gpu") or {}, e["big"].get("cpu") or {}
                 out["e2e"]["big"] = {"reads": big_reads, "what": "the same two legs (gpu default, cpu) on a %d-read file: the workload's batches %d times over under new read names"

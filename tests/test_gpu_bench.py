@@ -65,6 +65,7 @@ def test_bench_line_carries_the_record_path_and_the_end_to_end_legs():
     assert c["value"] > 0 and c["kind"] == "port" and c["cores"] >= 1 and c["gpu_over_cpu"] > 0
     e = r["e2e"]
     assert e["gpu_reads_per_s"] > 0 and e["cpu_reads_per_s"] > 0 and e["gpu"]["best_of"] == 2 and e["cpu"]["best_of"] == 2
+    assert 0 < e["cpu_zlib_reads_per_s"] < e["cpu_reads_per_s"] and e["gpu_over_cpu_zlib"] > e["gpu_over_cpu"]  # (zlib -6 is the slower codec)
     assert e["big"]["reads"] == 800000 and e["big"]["gpu_reads_per_s"] > 0 and e["big"]["cpu_reads_per_s"] > 0
     assert "kernel_ms_is" in r["roofline"] and r["cpu_baseline"]["value"] > 0
 
