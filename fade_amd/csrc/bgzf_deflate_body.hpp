@@ -39,12 +39,13 @@ static_assert(LDS_BYTES <= (FADEHIP_BGZF_GEOM == 64 ? 160 : 80) * 1024, "the wor
 static_assert(BLOCK % 16 == 0 && BLOCK + 256 <= DATA_BYTES && BLOCK < 65535, "block size");
 // ... of the head region once the matches are found; the CRC tables go where the match records were once they are emitted
 constexpr int H_H8 = 0, H_AL = H_H8 + 8 * 320 * 4, H_SL = H_AL + 320 * 4, H_AD = H_SL + 320 * 4, H_SD = H_AD + 64 * 4, H_END = H_SD + 64 * 4;
-static_assert(H_END + 4096 <= HEAD_BYTES, "phase B temporaries and the CRC tables must fit the hash region");
+static_assert(H_END <= HEAD_BYTES, "phase B temporaries must fit the hash region");
 
 struct Misc {  // the small arrays of a block
     uint32_t abort, dbg[3], carry, mcount, full, blk, m_l, m_d, hdr_bits, total_bits, stored, pad[3];
     uint32_t seg_mcount[N_WAVES], seg_prefix[N_WAVES + 1];  // match records per segment of phase A; ... of the segments in front
-    uint32_t freq_l[320], freq_d[64];
+    alignas(8) uint32_t freq_l[320];  // (read two at a time where the symbols are ranked)
+    uint32_t freq_d[64];
     uint8_t ll[320], dl[64];
     uint16_t lc[320], dc[64];
     uint32_t hdr[160];
@@ -178,6 +179,34 @@ __device__ __forceinline__ void token_bits(const uint8_t *data, uint32_t mw, uin
     }
 }
 
+// CRC-32 (reflected, P = 0xEDB88320) advanced by one 32-bit word WITHOUT a table: bit k of (state ^ word) alone becomes the
+// constant K[k] after 32 shifts, so the new state is the XOR of the K[k] of the set bits — 32 x (bit-field extract, and,
+// xor) in registers.  The tables of slicing-by-4 cost four LDS look-ups a word, and the CRC is summed while one lane makes
+// the code lengths out of the same LDS: its chain of dependent accesses waited behind them.
+struct CrcBitK {
+    uint32_t k[32];
+    constexpr CrcBitK() : k() {
+        for (int b = 0; b < 32; b++) {
+            uint32_t c = 1u << b;
+            for (int i = 0; i < 32; i++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            k[b] = c;
+        }
+    }
+};
+__device__ __forceinline__ uint32_t crc_word(uint32_t c) {
+    constexpr CrcBitK K;
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) r ^= K.k[b] & (uint32_t)__builtin_amdgcn_sbfe((int)c, (uint32_t)b, 1u);
+    return r;
+}
+__device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint32_t byte) {
+    c ^= byte;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c = (c >> 1) ^ (0xEDB88320u & (uint32_t)__builtin_amdgcn_sbfe((int)c, 0u, 1u));
+    return c;
+}
+
 // Minimum-redundancy code lengths (Moffat & Katajainen) by a WHOLE WAVE: the same lengths as bgzf_huff.hpp's
 // mr_code_lengths, which is a chain of ~3 m dependent LDS accesses for one lane (the longest serial stretch of a block once
 // phase A stopped being one).  Only its first pass is a chain by nature — the merge of the sorted leaves with the internal
@@ -186,12 +215,23 @@ __device__ __forceinline__ void token_bits(const uint8_t *data, uint32_t mw, uin
 // m dependent double look-ups), a histogram of those depths, the number of leaves at each depth from it (a level holds twice the
 // internal nodes of the level above; what is not an internal node is a leaf), and every leaf reads its depth off the running
 // sums by its position.  A[0 .. m) = frequencies ascending on entry, lengths (descending) on return; scratch: 4 arrays of m + 2.
-__device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, uint32_t *dep, uint32_t *par, uint32_t *cnt, uint32_t *cum, const int lane) {
+__device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, uint32_t *dep, uint32_t *par, uint32_t *cnt, uint32_t *cum, const int lane,
+                                                     unsigned long long *prof = nullptr) {
+    unsigned long long tp = prof ? __builtin_readcyclecounter() : 0ull;
+    auto sub = [&](int k) {
+        if (prof && lane == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            atomicAdd(&prof[k], t - tp);
+            tp = t;
+        }
+    };
     if (m == 1) {
         if (lane == 0) A[0] = 1;
         return;
     }
     if (lane == 0) {
+        // (Holding the next four nodes and leaves in registers, loaded three picks ahead, was measured: 485 clocks a node
+        // against 390 — one lane's chain is bound by the instructions it issues as much as by the LDS round trips.)
         A[0] += A[1];
         int root = 0, leaf = 2;
         for (int next = 1; next < m - 1; next++) {
@@ -204,6 +244,7 @@ __device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, u
         }
     }
     __builtin_amdgcn_wave_barrier();
+    sub(41);
     const int ni = m - 1;  // internal nodes 0 .. m-2, the root last
     constexpr int PER = (NUM_LITLEN + 2 + 63) / 64;
     for (int i = lane; i < ni; i += 64) {
@@ -232,6 +273,7 @@ __device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, u
         }
         __builtin_amdgcn_wave_barrier();
     }
+    sub(42);
     for (int i = lane; i < ni; i += 64) atomicAdd(&cnt[dep[i]], 1u);
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {  // leaves per depth, as running sums: cum[d] = leaves at depths 0 .. d
@@ -247,6 +289,7 @@ __device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, u
         cum[m + 1] = (uint32_t)d;  // levels
     }
     __builtin_amdgcn_wave_barrier();
+    sub(43);
     const int levels = (int)cum[m + 1];
     for (int q = lane; q < m; q += 64) {  // the q-th most frequent leaf sits at the first depth whose running sum exceeds q
         int d = 0;
@@ -254,6 +297,7 @@ __device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, u
         A[m - 1 - q] = (uint32_t)d;
     }
     __builtin_amdgcn_wave_barrier();
+    sub(44);
 }
 
 // ---- phase A: matches and the parse of ONE SEGMENT of the block, by one wave that needs nobody else.
@@ -434,10 +478,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
     uint32_t *const h8 = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_H8);
     uint32_t *const A_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AL), *const S_l = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SL);
     uint32_t *const A_d = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_AD), *const S_d = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_SD);
-    // the CRC tables (slicing by 4: 4 KB) live behind phase B's temporaries in what were the hash tables: they are built on
-    // the way through phase B, and the CRC itself is summed by the waves that would otherwise idle while one lane per
-    // alphabet makes the code lengths
-    uint32_t *const crct = reinterpret_cast<uint32_t *>(lds + L_HEAD + H_END);
+    // (the CRC is summed without tables — crc_word — by the waves that would otherwise idle while the code lengths are made)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if (tid == 0) crc_x2n_table(ms->x2n);
@@ -514,10 +555,8 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             uint32_t *z = reinterpret_cast<uint32_t *>(lds + L_HEAD);
             for (int k = tid; k < H_END / 4; k += WG) z[k] = 0;
             if (tid < 16) { ms->bl_l[tid] = 0; ms->bl_d[tid] = 0; }
-            if (tid < 256) crct[tid] = crc_table_entry((uint32_t)tid);
         }
         __syncthreads();
-        if (tid < 256) crct[256 + tid] = (crct[tid] >> 8) ^ crct[crct[tid] & 255u];  // (published by the barrier behind the histograms)
         const int w0 = WPT * tid, w1 = min(w0 + WPT, N_WORDS);
         uint32_t tw_r[WPT], mw_r[WPT], mb_r[WPT];  // this range's bitmap words and the match index each word starts at
         {
@@ -557,7 +596,6 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
         }
         __syncthreads();
-        if (tid < 256) crct[512 + tid] = (crct[256 + tid] >> 8) ^ crct[crct[256 + tid] & 255u];
         for (int s = tid; s < 320; s += WG) {
             uint32_t f = 0;
 #pragma unroll
@@ -566,7 +604,6 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             else ms->freq_d[s - 288] = (s - 288 < NUM_DIST) ? f : 0u;
         }
         __syncthreads();
-        if (tid < 256) crct[768 + tid] = (crct[512 + tid] >> 8) ^ crct[crct[512 + tid] & 255u];
         stamp(2);
         if (tid == 0) {  // at least two distance codes (as zlib makes sure of, for old inflaters)
             int used = 0;
@@ -577,15 +614,22 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             ms->m_d = 0;
         }
         __syncthreads();
-        // rank the used symbols by (frequency, symbol)
+        // rank the used symbols by (frequency, symbol): the two in one key, (frequency - 1) << 9 | symbol (a block's tokens
+        // are far fewer than 2^23; an unused symbol's key wraps to the top and is smaller than nobody's), so that a
+        // symbol's rank is the number of smaller keys: two symbols a load, four operations a symbol
         if (tid < NUM_LITLEN) {
             const uint32_t f = ms->freq_l[tid];
             if (f) {
-                uint32_t r = 0;
-                for (int j = 0; j < NUM_LITLEN; j++) {
-                    const uint32_t g = ms->freq_l[j];
-                    r += g && (g < f || (g == f && j < tid));
+                const uint32_t key = ((f - 1u) << 9) | (uint32_t)tid;
+                uint32_t less = 0;
+                static_assert(NUM_LITLEN % 2 == 0 && (offsetof(Misc, freq_l) % 8) == 0, "freq_l is read two at a time");
+                const uint2 *f2 = reinterpret_cast<const uint2 *>(ms->freq_l);
+#pragma unroll 4
+                for (int j = 0; j < NUM_LITLEN / 2; j++) {
+                    const uint2 g = f2[j];
+                    less += ((((g.x - 1u) << 9) | (uint32_t)(2 * j)) < key) + ((((g.y - 1u) << 9) | (uint32_t)(2 * j + 1)) < key);
                 }
+                const uint32_t r = less;
                 A_l[r] = f;
                 S_l[r] = (uint32_t)tid;
                 atomicAdd(&ms->m_l, 1u);
@@ -607,13 +651,26 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         if (tid < 320) ms->ll[tid] = 0;
         if (tid < 64) ms->dl[tid] = 0;
         __syncthreads();
+        unsigned long long t_sub = a.prof ? __builtin_readcyclecounter() : 0ull;
+        auto sub = [&](int k) {
+            if (a.prof && tid == 0) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                atomicAdd(&a.prof[k], t - t_sub);
+                t_sub = t;
+            }
+        };
+        if (a.prof && tid == 0) atomicAdd(&a.prof[40], t_sub - t_prev);  // (ranks)
         // minimum-redundancy lengths: wave 0 for the literal / length alphabet (mr_code_lengths_wave), a lane of wave 1 for the
         // thirty distance codes, the other waves sum the CRC meanwhile
         if (wave == 0) {
             // (h8's histograms have been summed: its space serves the wave as scratch)
             const int m = (int)ms->m_l;
-            mr_code_lengths_wave(A_l, m, h8, h8 + 320, h8 + 640, h8 + 960, lane);
+            __builtin_amdgcn_s_setprio(3);  // the block's longest serial stretch: ahead of the CRC's waves at issue
+            mr_code_lengths_wave(A_l, m, h8, h8 + 320, h8 + 640, h8 + 960, lane, a.prof);
+            __builtin_amdgcn_s_setprio(0);
+            t_sub = a.prof ? __builtin_readcyclecounter() : 0ull;
             if (lane == 0) limit_code_lengths(A_l, m, MAX_LITLEN_BITS, ms->sortbuf);
+            sub(45);
         } else if (tid == 64) {
             const int m = (int)ms->m_d;
             mr_code_lengths(A_d, m);
@@ -630,11 +687,8 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                 uint32_t c = 0xffffffffu;
                 int k = lo;
                 const uint32_t *dw = reinterpret_cast<const uint32_t *>(data);
-                for (; k + 4 <= hi; k += 4) {
-                    c ^= dw[k >> 2];
-                    c = crct[768 + (c & 255u)] ^ crct[512 + ((c >> 8) & 255u)] ^ crct[256 + ((c >> 16) & 255u)] ^ crct[c >> 24];
-                }
-                for (; k < hi; k++) c = crct[(c ^ data[k]) & 255u] ^ (c >> 8);
+                for (; k + 4 <= hi; k += 4) c = crc_word(c ^ dw[k >> 2]);
+                for (; k < hi; k++) c = crc_byte(c, data[k]);
                 c = ~c;
                 part = crc_mulmod(crc_x8n((uint32_t)(n - hi), ms->x2n), c);  // crc(A || B) = x^(8 |B|) crc(A) ^ crc(B)
             }
@@ -643,6 +697,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             if (lane == 0) ms->crc_part[wave] = part;
         }
         __syncthreads();
+        sub(46);
         if ((uint32_t)tid < ms->m_l) {
             ms->ll[S_l[tid]] = (uint8_t)A_l[tid];
             atomicAdd(&ms->bl_l[A_l[tid]], 1u);
@@ -675,6 +730,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
         }
         __syncthreads();
+        sub(47);
         stamp(3);
 
         // ---- C: the dynamic-block header (RFC 1951 §3.2.7), in parallel: the hlit + hdist code lengths are cut into runs,

@@ -2067,6 +2067,9 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
             fprintf(stderr, "[fadehip bgzf] %u blocks, shader clocks per block:", l.n_blocks);
             for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.0f (%.0f%%)", nm[k], (double)pr[k] / l.n_blocks, 100.0 * (double)pr[k] / (double)std::max<unsigned long long>(sum, 1));
             fprintf(stderr, "\n");
+            if (pr[41])
+                fprintf(stderr, "[fadehip bgzf] B codes, clocks per block: ranks %.0f | merge (one lane) %.0f, depths %.0f, histogram + sums %.0f, leaves %.0f | limit %.0f | the others waited for %.0f | lengths, first codes, codes %.0f\n",
+                        (double)pr[40] / l.n_blocks, (double)pr[41] / l.n_blocks, (double)pr[42] / l.n_blocks, (double)pr[43] / l.n_blocks, (double)pr[44] / l.n_blocks, (double)pr[45] / l.n_blocks, (double)pr[46] / l.n_blocks, (double)pr[47] / l.n_blocks);
             fprintf(stderr, "[fadehip bgzf] phase A roles, clocks per block waited / in role: hasher %.0f / %.0f, extenders (sum) %.0f / %.0f, parser %.0f / %.0f\n",
                     (double)pr[60] / l.n_blocks, (double)pr[61] / l.n_blocks, (double)pr[62] / l.n_blocks, (double)pr[63] / l.n_blocks, (double)pr[64] / l.n_blocks, (double)pr[65] / l.n_blocks);
         }
