@@ -207,6 +207,17 @@ __device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint32_t byte) {
     return c;
 }
 
+// An array of up to 64 words held by a wave in ONE VGPR: element k is lane k's, read and written with a uniform index
+// (v_readlane; a write is a compare of the lane number and a select — this compiler has no builtin for v_writelane: a few
+// clocks, no LDS).  For bgzf_huff.hpp's templates over small alphabets; every lane of the wave must run the code (uniform
+// control flow).
+struct LaneArr {
+    uint32_t v;
+    int lane;
+    __device__ __forceinline__ uint32_t get(int i) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+    __device__ __forceinline__ void set(int i, uint32_t x) { v = lane == i ? x : v; }
+};
+
 // Minimum-redundancy code lengths (Moffat & Katajainen) by a WHOLE WAVE: the same lengths as bgzf_huff.hpp's
 // mr_code_lengths, which is a chain of ~3 m dependent LDS accesses for one lane (the longest serial stretch of a block once
 // phase A stopped being one).  Only its first pass is a chain by nature — the merge of the sorted leaves with the internal
@@ -291,10 +302,30 @@ __device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, u
     __builtin_amdgcn_wave_barrier();
     sub(43);
     const int levels = (int)cum[m + 1];
-    for (int q = lane; q < m; q += 64) {  // the q-th most frequent leaf sits at the first depth whose running sum exceeds q
-        int d = 0;
-        while (d < levels - 1 && cum[d] <= (uint32_t)q) d++;
-        A[m - 1 - q] = (uint32_t)d;
+    // the q-th most frequent leaf sits at the first depth whose running sum exceeds q: the sums do not decrease, so that depth is
+    // the number of sums <= q among the first levels - 1 — counted against the sums held in a register (a lane each, read with a
+    // uniform index) instead of walked in LDS by every lane for itself (12.7 k -> 3 k clocks a block)
+    if (levels <= 64) {
+        const uint32_t cumreg = lane < levels ? cum[lane] : 0u;
+        uint32_t dq[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) dq[k] = 0;
+        for (int d = 0; d < levels - 1; d++) {
+            const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)cumreg, d);
+#pragma unroll
+            for (int k = 0; k < PER; k++) dq[k] += cd <= (uint32_t)(lane + 64 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int q = lane + 64 * k;
+            if (q < m) A[m - 1 - q] = dq[k];
+        }
+    } else {
+        for (int q = lane; q < m; q += 64) {
+            int d = 0;
+            while (d < levels - 1 && cum[d] <= (uint32_t)q) d++;
+            A[m - 1 - q] = (uint32_t)d;
+        }
     }
     __builtin_amdgcn_wave_barrier();
     sub(44);
@@ -706,8 +737,25 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             atomicAdd(&ms->bl_d[A_d[tid - DIST_T0]], 1u);
         }
         __syncthreads();
-        if (tid == 0 || tid == 64) {  // first code of each length (RFC 1951 §3.2.2)
-            uint32_t *bl = tid ? ms->bl_d : ms->bl_l, *nc = tid ? ms->nc_d : ms->nc_l;
+        // Canonical codes (RFC 1951 §3.2.2), a symbol a lane: waves 0..4 hold the literal / length alphabet, wave 5 the
+        // distances.  A symbol's code is the first code of its length plus the symbols of the same length in front of it:
+        // those of its own wave from a ballot, those of the waves in front from the waves' counts (cw) — instead of every
+        // lane walking the lengths in front of it in LDS.  The first codes are made by two lanes meanwhile.
+        uint32_t *const cw = h8 + 1600;  // [6 waves][16 lengths] (h8 is free again: the code lengths are done)
+        uint32_t my_len = 0, my_within = 0;
+        const bool is_d = wave == 5;
+        const int sym = is_d ? lane : tid;
+        if (wave < 6) {
+            if (is_d ? sym < NUM_DIST : sym < NUM_LITLEN) my_len = is_d ? ms->dl[sym] : ms->ll[sym];
+#pragma unroll
+            for (int bb = 1; bb <= MAX_LITLEN_BITS; bb++) {
+                const unsigned long long mk = __ballot(my_len == (uint32_t)bb);
+                if (my_len == (uint32_t)bb) my_within = (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
+                if (lane == bb) cw[wave * 16 + bb] = (uint32_t)__builtin_popcountll(mk);
+            }
+        }
+        if (tid == 6 * 64 || tid == 7 * 64) {  // first code of each length
+            uint32_t *bl = tid == 7 * 64 ? ms->bl_d : ms->bl_l, *nc = tid == 7 * 64 ? ms->nc_d : ms->nc_l;
             uint32_t c = 0;
             bl[0] = 0;
             nc[0] = 0;
@@ -717,17 +765,12 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
         }
         __syncthreads();
-        if (tid < NUM_LITLEN + NUM_DIST) {
-            const bool is_d = tid >= NUM_LITLEN;
-            const int sym = is_d ? tid - NUM_LITLEN : tid;
-            const uint8_t *lens = is_d ? ms->dl : ms->ll;
-            const uint32_t l = lens[sym];
-            if (l) {
-                uint32_t before = 0;
-                for (int j = 0; j < sym; j++) before += lens[j] == l;
-                const uint32_t code = (is_d ? ms->nc_d : ms->nc_l)[l] + before;
-                (is_d ? ms->dc : ms->lc)[sym] = (uint16_t)(__builtin_bitreverse32(code) >> (32u - l));
-            }
+        if (my_len) {
+            uint32_t before = my_within;
+            if (!is_d)
+                for (int w = 0; w < wave; w++) before += cw[w * 16 + (int)my_len];
+            const uint32_t code = (is_d ? ms->nc_d : ms->nc_l)[my_len] + before;
+            (is_d ? ms->dc : ms->lc)[sym] = (uint16_t)(__builtin_bitreverse32(code) >> (32u - my_len));
         }
         __syncthreads();
         sub(47);
@@ -741,6 +784,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         if (tid < NUM_CL + 1) { ms->cl_freq[tid] = 0; ms->cl_len[tid] = 0; ms->cl_code[tid] = 0; }
         for (int k = tid; k < 160; k += WG) ms->hdr[k] = 0;
         __syncthreads();
+        t_sub = a.prof ? __builtin_readcyclecounter() : 0ull;
         if (tid < NUM_LITLEN && ms->ll[tid]) atomicMax(&ms->cl_hlit, (uint32_t)tid + 1u);
         if (tid >= DIST_T0 && tid < DIST_T0 + NUM_DIST && ms->dl[tid - DIST_T0]) atomicMax(&ms->cl_hdist, (uint32_t)(tid - DIST_T0) + 1u);
         __syncthreads();
@@ -785,52 +829,76 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             if (tid == 0) ms->cl_n = nt_all;
         }
         __syncthreads();
-        if (tid == 0) {  // the code-length code: 19 symbols, 7 bits at most
-            uint32_t *sf = ms->sortbuf, *ss = ms->sortbuf + 20, *bl = ms->sortbuf + 40;
-            int m = 0;
-            for (int sy = 0; sy < NUM_CL; sy++) {
-                const uint32_t f = ms->cl_freq[sy];
-                if (f) {
-                    int j = m++;
-                    while (j > 0 && sf[j - 1] > f) { sf[j] = sf[j - 1]; ss[j] = ss[j - 1]; j--; }
-                    sf[j] = f;
-                    ss[j] = (uint32_t)sy;
-                }
-            }
-            if (m == 1) ms->cl_len[ss[0]] = 1;
-            else {
-                mr_code_lengths(sf, m);
-                limit_code_lengths(sf, m, MAX_CL_BITS, bl);
-                for (int k = 0; k < m; k++) ms->cl_len[ss[k]] = sf[k];
-            }
-            for (int bb = 0; bb <= MAX_CL_BITS; bb++) bl[bb] = 0;
-            for (int sy = 0; sy < NUM_CL; sy++)
-                if (ms->cl_len[sy]) bl[ms->cl_len[sy]]++;
-            uint32_t c = 0;
-            sf[0] = 0;
+        sub(48);
+        // The code-length code — 19 symbols, 7 bits at most — by the LAST WAVE with its arrays in registers: element k of an
+        // array is lane k of a VGPR, read by v_readlane with a uniform index and written by a select on the lane number, so that Moffat–
+        // Katajainen's chain of a few hundred dependent accesses costs a few clocks each instead of an LDS round trip (one
+        // lane with its arrays in LDS: 88 k clocks a block, most of this phase).  The other waves count their ranges' bits
+        // meanwhile; this wave counts its own afterwards.
+        if (wave == N_WAVES - 1) {
+            const uint32_t f = lane < NUM_CL ? ms->cl_freq[lane] : 0u;
+            // rank among the used symbols by (frequency, symbol), as the insertion sort of build_header orders them
+            const uint32_t key = ((f - 1u) << 5) | (uint32_t)lane;  // (unused: wraps to the top)
+            uint32_t less = 0;
+#pragma unroll
+            for (int j = 0; j < NUM_CL; j++) less += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key;
+            const int m = __builtin_popcountll(__ballot(f != 0u));
+            uint32_t *sf = ms->sortbuf, *ss = ms->sortbuf + 20;
+            if (f) { sf[less] = f; ss[less] = (uint32_t)lane; }
+            __builtin_amdgcn_wave_barrier();
+            LaneArr A{lane < m ? sf[lane] : 0u, lane}, bl{0u, lane};
+            const uint32_t sym_r = lane < m ? ss[lane] : 0u;  // the symbol whose length lane r will hold
+            mr_code_lengths_t(A, m);
+            limit_code_lengths_t(A, m, MAX_CL_BITS, bl);
+            if (lane < m) ms->cl_len[sym_r] = A.v;  // (cl_len was cleared with the phase's other arrays)
+            __builtin_amdgcn_wave_barrier();
+            // canonical codes, a symbol a lane: the first code of each length from the counts (ballots), plus the symbols of
+            // the same length in front
+            const uint32_t len = lane < NUM_CL ? ms->cl_len[lane] : 0u;
+            uint32_t c = 0, prev = 0, code = 0;
+#pragma unroll
             for (int bb = 1; bb <= MAX_CL_BITS; bb++) {
-                c = (c + (bb > 1 ? bl[bb - 1] : 0u)) << 1;
-                sf[bb] = c;
+                c = (c + prev) << 1;
+                const unsigned long long mk = __ballot(len == (uint32_t)bb);
+                prev = (uint32_t)__builtin_popcountll(mk);
+                if (len == (uint32_t)bb) code = c + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
             }
-            for (int sy = 0; sy < NUM_CL; sy++) {
-                const uint32_t l = ms->cl_len[sy];
-                if (l) ms->cl_code[sy] = __builtin_bitreverse32(sf[l]++) >> (32u - l);
-            }
+            if (len) ms->cl_code[lane] = __builtin_bitreverse32(code) >> (32u - len);
+            // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then 3 bits per code-length code length in cl_order
             int hclen = NUM_CL;
-            while (hclen > 4 && ms->cl_len[cl_order(hclen - 1)] == 0) hclen--;
-            ms->cl_hclen = (uint32_t)hclen;
-            // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then 3 bits per code-length code length
-            WordSink sink;
-            sink.w = ms->hdr;
-            sink.put(1, 1);
-            sink.put(2, 2);
-            sink.put(ms->cl_hlit - 257u, 5);
-            sink.put(ms->cl_hdist - 1u, 5);
-            sink.put((uint32_t)(hclen - 4), 4);
-            for (int k = 0; k < hclen; k++) sink.put(ms->cl_len[cl_order(k)], 3);
-            sink.finish();
+            while (hclen > 4 && __builtin_amdgcn_readlane((int)len, cl_order(hclen - 1)) == 0) hclen--;
+            uint64_t w0 = 1ull | (2ull << 1) | ((uint64_t)(ms->cl_hlit - 257u) << 3) | ((uint64_t)(ms->cl_hdist - 1u) << 8) | ((uint64_t)(hclen - 4) << 13), w1 = 0;
+            int at = 17;
+            for (int k = 0; k < hclen; k++, at += 3) {
+                const uint64_t l3 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)len, cl_order(k));
+                if (at < 64) w0 |= l3 << at;
+                if (at + 3 > 64) w1 |= at >= 64 ? l3 << (at - 64) : l3 >> (64 - at);
+            }
+            if (lane == 0) {
+                ms->cl_hclen = (uint32_t)hclen;
+                ms->hdr[0] = (uint32_t)w0;
+                ms->hdr[1] = (uint32_t)(w0 >> 32);
+                ms->hdr[2] = (uint32_t)w1;
+            }
         }
+        // ---- D (first part): the bit counts of the threads' position ranges (WPT bitmap words each)
+        uint32_t my_bits = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; k++) {
+            uint32_t tw = tw_r[k];
+            while (tw) {
+                const int b = __builtin_ctz(tw);
+                tw &= tw - 1u;
+                uint64_t v;
+                int nb;
+                token_bits(data, mw_r[k], mb_r[k], match, ms, w0 + k, b, v, nb);
+                my_bits += (uint32_t)nb;
+            }
+        }
+        if (tid == WG - 1) my_bits += ms->ll[256];  // end of block
+        sub(49);
         __syncthreads();
+        sub(50);
         {
             const uint32_t nt_all = ms->cl_n, fixed_bits = 17u + 3u * ms->cl_hclen;
             uint32_t bits = 0, val = 0;
@@ -848,22 +916,8 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
             if (tid == 0) ms->hdr_bits = fixed_bits + cl_bits_all;
         }
-        // ---- D: the bit counts of the threads' position ranges (WPT bitmap words each)
-        uint32_t my_bits = 0;
-#pragma unroll
-        for (int k = 0; k < WPT; k++) {
-            uint32_t tw = tw_r[k];
-            while (tw) {
-                const int b = __builtin_ctz(tw);
-                tw &= tw - 1u;
-                uint64_t v;
-                int nb;
-                token_bits(data, mw_r[k], mb_r[k], match, ms, w0 + k, b, v, nb);
-                my_bits += (uint32_t)nb;
-            }
-        }
-        if (tid == WG - 1) my_bits += ms->ll[256];  // end of block
         __syncthreads();  // hdr_bits is there
+        sub(51);
         stamp(4);
         uint32_t tok_bits_all;
         const uint32_t b0 = ms->hdr_bits + block_excl_scan(my_bits, ms->wtmp, &tok_bits_all);

@@ -2070,6 +2070,9 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
             if (pr[41])
                 fprintf(stderr, "[fadehip bgzf] B codes, clocks per block: ranks %.0f | merge (one lane) %.0f, depths %.0f, histogram + sums %.0f, leaves %.0f | limit %.0f | the others waited for %.0f | lengths, first codes, codes %.0f\n",
                         (double)pr[40] / l.n_blocks, (double)pr[41] / l.n_blocks, (double)pr[42] / l.n_blocks, (double)pr[43] / l.n_blocks, (double)pr[44] / l.n_blocks, (double)pr[45] / l.n_blocks, (double)pr[46] / l.n_blocks, (double)pr[47] / l.n_blocks);
+            if (pr[48])
+                fprintf(stderr, "[fadehip bgzf] C header + count, clocks per block: runs of lengths into tokens %.0f | thread 0's bit counts %.0f, then waited for the code-length code %.0f | tokens' bits into the header %.0f\n",
+                        (double)pr[48] / l.n_blocks, (double)pr[49] / l.n_blocks, (double)pr[50] / l.n_blocks, (double)pr[51] / l.n_blocks);
             fprintf(stderr, "[fadehip bgzf] phase A roles, clocks per block waited / in role: hasher %.0f / %.0f, extenders (sum) %.0f / %.0f, parser %.0f / %.0f\n",
                     (double)pr[60] / l.n_blocks, (double)pr[61] / l.n_blocks, (double)pr[62] / l.n_blocks, (double)pr[63] / l.n_blocks, (double)pr[64] / l.n_blocks, (double)pr[65] / l.n_blocks);
         }
