@@ -1919,6 +1919,7 @@ static int bgzf_lane_ready(fadehip_ctx *ctx, int lane, bool one_stream = false) 
         // uses the lanes one after the other anyway)
         if (lane > 0 && (one_stream || getenv("FADEHIP_BGZF_ONE_STREAM")) && ctx->bgzf[0].stream) l.stream = ctx->bgzf[0].stream;
         else if (ctx->split_cus > 0) l.stream = xcd_slice_stream(ctx, ctx->split_cus, ctx->cu_count / 8);
+        else if (const char *kv = getenv("FADEHIP_BGZF_CUS")) l.stream = xcd_slice_stream(ctx, 0, std::max(1, std::min(atoi(kv), ctx->cu_count / 8)));  // the compressor alone on fewer CUs
         if (!l.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipHostMalloc((void **)&l.h_total, 64));
         HIPCHK(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
