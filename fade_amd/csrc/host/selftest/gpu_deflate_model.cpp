@@ -457,6 +457,17 @@ int main(int argc, char **argv) {
             for (size_t o = 0; o < c.data.size(); o += (size_t)BLOCK) {
                 const int n = (int)std::min<size_t>((size_t)BLOCK, c.data.size() - o);
                 const std::vector<uint8_t> z = model_deflate(c.data.data() + o, n, lazy != 0);
+                // MODEL_DUMP=path: the 0x7f00 geometry's raw DEFLATE streams of the payload files, each behind its length
+                // (u32): what tests/test_gpu_bgzf.py holds the device's members to, byte for byte
+                if (getenv("MODEL_DUMP") && g.block == 0x7f00 && c.name.rfind("file ", 0) == 0) {
+                    FILE *df = fopen(getenv("MODEL_DUMP"), "ab");
+                    if (df) {
+                        const uint32_t zl = (uint32_t)z.size();
+                        fwrite(&zl, 4, 1, df);
+                        fwrite(z.data(), 1, z.size(), df);
+                        fclose(df);
+                    }
+                }
                 if (!inflate_ok(z, c.data.data() + o, n)) { ok = false; printf("FAIL %s block at %zu (n = %d)\n", c.name.c_str(), o, n); }
                 if (z.size() > 65510) { ok = false; printf("FAIL %s: %zu bytes do not fit a BGZF block\n", c.name.c_str(), z.size()); }
                 total += z.size() + 26;

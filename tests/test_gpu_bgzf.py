@@ -176,3 +176,34 @@ def test_round_trips_of_many_shapes_in_both_geometries(monkeypatch, geom):
             assert len(members(out)) == (len(data) + cut - 1) // cut
     finally:
         c.close()
+
+
+def test_the_small_geometry_is_the_cpu_model_byte_for_byte(monkeypatch, tmp_path, payloads):
+    """host/selftest/gpu_deflate_model.cpp restates the 0x7f00-byte-block compressor on the CPU (segments, seams, the table's
+    ways and buckets, the parse, bgzf_huff.hpp's code lengths and header): every member the device writes must hold exactly the
+    model's bytes — whatever the kernel does in registers, ballots or lanes instead of the model's loops."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fade_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-s", "build/gpu_deflate_model"])
+    monkeypatch.setenv("FADEHIP_BGZF_GEOM", "32")
+    c = fade_amd.Context(device=0)
+    try:
+        for k, name in enumerate(("bam, uniform qualities", "bam, run-heavy qualities", "text", "one block and a byte")):
+            data = payloads[name]
+            src, dump = tmp_path / ("p%d.bin" % k), tmp_path / ("p%d.model" % k)
+            src.write_bytes(data)
+            subprocess.run([os.path.join(csrc, "build", "gpu_deflate_model"), str(src)], check=True, stdout=subprocess.DEVNULL,
+                           env=dict(os.environ, MODEL_DUMP=str(dump), ASAN_OPTIONS="detect_leaks=0"))
+            raw, want, at = dump.read_bytes(), [], 0
+            while at < len(raw):
+                n = struct.unpack_from("<I", raw, at)[0]
+                want.append(raw[at + 4:at + 4 + n])
+                at += 4 + n
+            got = [m[0] for m in members(bytes(c.bgzf_deflate(data)))]
+            assert len(got) == len(want) == (len(data) + SMALL - 1) // SMALL, name
+            for j, (g, w) in enumerate(zip(got, want)):
+                assert g == w, "%s: member %d differs from the model (%d / %d bytes)" % (name, j, len(g), len(w))
+    finally:
+        c.close()
