@@ -881,11 +881,26 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                 ms->hdr[2] = (uint32_t)w1;
             }
         }
-        // ---- D (first part): the bit counts of the threads' position ranges (WPT bitmap words each)
+        // ---- D (first part): the bit counts of the threads' position ranges (WPT bitmap words each).  The literals of a word
+        // without a chain: its 32 bytes come as two 16-byte loads, the 32 code lengths are looked up side by side (a token at a
+        // time was two dependent LDS round trips each: 33 k clocks a block) and summed where the bitmap says a literal starts;
+        // the few matches keep their own loop.
         uint32_t my_bits = 0;
 #pragma unroll
         for (int k = 0; k < WPT; k++) {
-            uint32_t tw = tw_r[k];
+            const uint32_t lit = tw_r[k] & ~mw_r[k];
+            if (lit) {
+                const uint4 *d4 = reinterpret_cast<const uint4 *>(data + 32 * (w0 + k));
+                const uint4 lo = d4[0], hi = d4[1];
+                const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int b = 0; b < 32; b++) {
+                    const uint32_t c = (dw[b >> 2] >> (8 * (b & 3))) & 255u;
+                    const uint32_t l = ms->ll[c];
+                    my_bits += ((lit >> b) & 1u) ? l : 0u;
+                }
+            }
+            uint32_t tw = tw_r[k] & mw_r[k];
             while (tw) {
                 const int b = __builtin_ctz(tw);
                 tw &= tw - 1u;
@@ -919,6 +934,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         __syncthreads();  // hdr_bits is there
         sub(51);
         stamp(4);
+        t_sub = a.prof ? __builtin_readcyclecounter() : 0ull;
         uint32_t tok_bits_all;
         const uint32_t b0 = ms->hdr_bits + block_excl_scan(my_bits, ms->wtmp, &tok_bits_all);
         if (tid == 0) {
@@ -961,6 +977,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                 for (uint32_t k = tid; k < hdr_words; k += WG) sink[k] = 0;
             }
             __syncthreads();
+            sub(52);
             for (uint32_t k = tid; k < hdr_words; k += WG) atomicOr(&sink[k], ms->hdr[k]);
             if (my_bits) {
                 uint64_t acc = 0;
@@ -978,15 +995,50 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                         cnt -= 32;
                     }
                 };
+                // The chain that places a thread's tokens took 58 k clocks for 64 tokens: a literal is two look-ups, a match a
+                // chain of five and sixty instructions — and some lane of the wave has a match in nearly every turn, so every
+                // turn paid for one.  The first MPRE matches of a word are therefore resolved AHEAD of the chain (a turn per
+                // match of the busiest lane, not per token), bits | length << 58 in a register pair; the chain picks them by
+                // rank.  A word's further matches take the long way.
+                constexpr int MPRE = 3;
+                uint64_t pre[WPT][MPRE];
+#pragma unroll
+                for (int k = 0; k < WPT; k++) {
+                    uint32_t mm = tw_r[k] & mw_r[k];
+#pragma unroll
+                    for (int q = 0; q < MPRE; q++) {
+                        pre[k][q] = 0;
+                        if (mm) {
+                            const int b = __builtin_ctz(mm);
+                            mm &= mm - 1u;
+                            uint64_t v;
+                            int nb;
+                            token_bits(data, mw_r[k], mb_r[k], match, ms, w0 + k, b, v, nb);
+                            pre[k][q] = v | ((uint64_t)nb << 58);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < WPT; k++) {
                     uint32_t tw = tw_r[k];
+                    const uint32_t mw = mw_r[k];
                     while (tw) {
                         const int b = __builtin_ctz(tw);
                         tw &= tw - 1u;
                         uint64_t v;
                         int nb;
-                        token_bits(data, mw_r[k], mb_r[k], match, ms, w0 + k, b, v, nb);
+                        if ((mw >> b) & 1u) {
+                            const int r = __builtin_popcount(mw & tw_r[k] & ((1u << b) - 1u));
+                            if (r < MPRE) {
+                                const uint64_t pv = r == 0 ? pre[k][0] : (r == 1 ? pre[k][1] : pre[k][2]);
+                                v = pv & ((1ull << 58) - 1ull);
+                                nb = (int)(pv >> 58);
+                            } else token_bits(data, mw, mb_r[k], match, ms, w0 + k, b, v, nb);
+                        } else {
+                            const uint32_t c = data[32 * (w0 + k) + b];
+                            v = ms->lc[c];
+                            nb = ms->ll[c];
+                        }
                         if (nb > 24) {  // (a token has up to 48 bits and the accumulator up to 31 pending)
                             put(v & 0xffffffull, 24);
                             put(v >> 24, nb - 24);
@@ -996,10 +1048,13 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                 if (tid == WG - 1) put(ms->lc[256], ms->ll[256]);
                 if (cnt) atomicOr(&sink[wi], (uint32_t)acc);
             }
+            sub(53);
             if (in_lds) {
                 __syncthreads();
+                sub(54);
                 for (uint32_t k = tid; k < out_words; k += WG) out32[k] = sink[k];
             }
+            sub(55);
             if (tid == 0) a.out_size[blk] = (total_bits + 7u) >> 3;
         }
         __syncthreads();

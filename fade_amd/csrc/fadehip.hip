@@ -2074,6 +2074,9 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
             if (pr[48])
                 fprintf(stderr, "[fadehip bgzf] C header + count, clocks per block: runs of lengths into tokens %.0f | thread 0's bit counts %.0f, then waited for the code-length code %.0f | tokens' bits into the header %.0f\n",
                         (double)pr[48] / l.n_blocks, (double)pr[49] / l.n_blocks, (double)pr[50] / l.n_blocks, (double)pr[51] / l.n_blocks);
+            if (pr[52])
+                fprintf(stderr, "[fadehip bgzf] D emit, clocks per block: scan of the bit counts, the stream's words cleared %.0f | thread 0's tokens placed %.0f, then waited for the others %.0f | copied out %.0f\n",
+                        (double)pr[52] / l.n_blocks, (double)pr[53] / l.n_blocks, (double)pr[54] / l.n_blocks, (double)pr[55] / l.n_blocks);
             fprintf(stderr, "[fadehip bgzf] phase A roles, clocks per block waited / in role: hasher %.0f / %.0f, extenders (sum) %.0f / %.0f, parser %.0f / %.0f\n",
                     (double)pr[60] / l.n_blocks, (double)pr[61] / l.n_blocks, (double)pr[62] / l.n_blocks, (double)pr[63] / l.n_blocks, (double)pr[64] / l.n_blocks, (double)pr[65] / l.n_blocks);
         }
