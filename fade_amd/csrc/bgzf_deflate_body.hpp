@@ -348,6 +348,7 @@ struct SegArgs {
     uint32_t *match;   // this wave's match records [SEG_CAP]
     uint32_t *tokw, *matw;
     int n, first_piece, end_piece, lane;
+    unsigned long long *prof;  // FADEHIP_BGZF_PROF: the first wave's clocks by part of a piece (nullptr otherwise)
 };
 // what a segment's wave leaves for the seam behind it: the record of its last match if that match was cut at the segment's
 // end, and by how many bytes it would have gone on (phase_a_seam lengthens it again as far as the next segment's parse allows)
@@ -369,6 +370,19 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
     }
     int carry = r.first_piece * 64;  // positions below it are covered by a match already taken
     uint32_t mcount = 0, full = 0, over_rec = 0, over = 0;
+    // (the parts of a piece, clocked: compiled in with -DFADEHIP_BGZF_PROF_A=1 only — seven more branches a piece are scalar
+    // instructions, and the CU's one scalar unit is what sixteen waves of this phase queue for)
+#ifndef FADEHIP_BGZF_PROF_A
+#define FADEHIP_BGZF_PROF_A 0
+#endif
+    unsigned long long tq = (FADEHIP_BGZF_PROF_A && r.prof) ? __builtin_readcyclecounter() : 0ull, tpart[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto part = [&](int k) {
+        if (FADEHIP_BGZF_PROF_A && r.prof) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            tpart[k - 56] += t - tq;
+            tq = t;
+        }
+    };
     for (int piece = r.first_piece; piece < r.end_piece; piece++) {
         const uint32_t p = (uint32_t)piece * 64u + (uint32_t)lane;
         const bool valid = (int)p + MIN_MATCH <= n;
@@ -382,6 +396,7 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
             *bucket = make_uint2((p + 1u) | (bk.x << 16), (bk.x >> 16) | (bk.y << 16));  // newest first; the oldest of the four leaves
         }
         uint32_t len = 0, dist = 0;
+        part(56);
         if (valid && (int)p >= carry) {
             const uint32_t maxlen = (uint32_t)min(MAX_MATCH, n - (int)p);
             // up to five candidates: the nearer of the distances 1 and 2 whose four bytes agree (what a piece's own positions,
@@ -415,6 +430,7 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
                 if (c4[w] && p - cp[1 + w] <= 32768u && cv[w] == v) alive |= 2u << w;
             uint32_t cl[5] = {0, 0, 0, 0, 0};
             uint32_t off = 4;
+            part(57);
             while (alive && off < maxlen) {  // eight bytes per round trip
                 const uint64_t pw = lds_load64u(data, p + off);
                 uint64_t x[5];
@@ -428,6 +444,7 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
                     }
                 off += 8;
             }
+            part(58);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 uint32_t l = ((alive >> k) & 1u) ? maxlen : cl[k];  // still equal where the limit was reached
@@ -445,29 +462,36 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
         const bool yield = len && lane < 63 && len_next > len;
         const int cb = piece * 64, nv = min(64, n - cb);
         uint64_t has = __ballot(len != 0 && !yield);
-        if (full || mcount + (uint32_t)__popcll(has) > (uint32_t)SEG_CAP) { full = 1; has = 0; }  // the segment's match list is full: literals from here on
+        // the segment's match list is full: literals from here on (a piece adds 64 at most: counted only near the end)
+        if (full || (mcount > (uint32_t)(SEG_CAP - 64) && mcount + (uint32_t)__popcll(has) > (uint32_t)SEG_CAP)) { full = 1; has = 0; }
         const uint64_t vmask = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
         // greedy: from `cur`, the next match start at or after it is taken and covers its length; what no match covers is a literal
+        part(60);
+        // (every operation here is the scalar unit's, which the CU's sixteen waves share: as few as the greedy walk needs)
         uint64_t matmask = 0, covered = 0;
         int cur = max(carry - cb, 0);
         const int cur0 = cur;
         int j_last = -1;
-        while (cur < nv) {
-            const uint64_t rem = has & (~0ull << cur);
-            if (!rem) break;
+        const uint64_t from0 = cur0 >= 64 ? 0ull : (~0ull << cur0);  // positions at or behind cur0
+        uint64_t rem = has & from0;  // match starts still ahead of the walk (has holds none beyond the block's end)
+        while (rem) {
             const int j = (int)__builtin_ctzll(rem);
             const int e = j + (int)__builtin_amdgcn_readlane((int)len, j);  // first position after the match
+            const uint64_t above_j = 2ull << j;                            // (0 for j = 63: no position inside the match)
+            const uint64_t at_e = e >= 64 ? 0ull : (1ull << e);
             matmask |= 1ull << j;
-            covered |= (e >= 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((j == 63) ? ~0ull : ((1ull << (j + 1)) - 1ull));
+            covered |= at_e - above_j;  // positions j + 1 .. e - 1 (e >= 64: everything above j)
+            rem &= ~(at_e - 1ull);      // the starts the match covers are gone (e >= 64: all of them)
             cur = e;
             j_last = j;
         }
+        part(61);
         if (j_last >= 0 && cb + cur == seg_end) {  // the piece's last match reaches the segment's end: was it cut there?
             const uint32_t cut = (uint32_t)__builtin_amdgcn_readlane((int)(ulen - len), j_last);
             over = cut;
             over_rec = mcount + (uint32_t)__popcll(matmask & ((1ull << j_last) - 1ull));
         }
-        const uint64_t tokmask = vmask & ~covered & (cur0 >= 64 ? 0ull : (~0ull << cur0));
+        const uint64_t tokmask = vmask & ~covered & from0;
         if (cur < nv) cur = nv;
         if (cb + cur > carry) carry = cb + cur;
         if ((matmask >> lane) & 1ull) {
@@ -479,7 +503,10 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
             *reinterpret_cast<uint2 *>(r.tokw + 2 * piece) = make_uint2((uint32_t)tokmask, (uint32_t)(tokmask >> 32));
             *reinterpret_cast<uint2 *>(r.matw + 2 * piece) = make_uint2((uint32_t)matmask, (uint32_t)(matmask >> 32));
         }
+        part(62);
     }
+    if (FADEHIP_BGZF_PROF_A && r.prof && lane == 0)
+        for (int k = 0; k < 7; k++) atomicAdd(&r.prof[56 + k], tpart[k]);
     SegOut o;
     o.mcount = mcount;
     o.over_rec = over_rec;
@@ -565,6 +592,7 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             sa.first_piece = min(wave * seg_pieces, n_pieces);
             sa.end_piece = min((wave + 1) * seg_pieces, n_pieces);
             sa.lane = lane;
+            sa.prof = (a.prof && wave == 0) ? a.prof : nullptr;
             const SegOut so = phase_a_segment(sa);
             if (lane == 0) ms->seg_mcount[wave] = so.mcount;
             __syncthreads();

@@ -2074,6 +2074,9 @@ int fadehip_bgzf_deflate_wait(fadehip_ctx *ctx, int lane, const uint8_t **out, s
             if (pr[48])
                 fprintf(stderr, "[fadehip bgzf] C header + count, clocks per block: runs of lengths into tokens %.0f | thread 0's bit counts %.0f, then waited for the code-length code %.0f | tokens' bits into the header %.0f\n",
                         (double)pr[48] / l.n_blocks, (double)pr[49] / l.n_blocks, (double)pr[50] / l.n_blocks, (double)pr[51] / l.n_blocks);
+            if (pr[56])
+                fprintf(stderr, "[fadehip bgzf] A (the first wave's segment), clocks per block: position's bytes, bucket read and written %.0f | candidates' four bytes %.0f | extended %.0f | best picked, who yields, ballot %.0f | the piece's matches taken in turn %.0f | bitmaps, records stored %.0f\n",
+                        (double)pr[56] / l.n_blocks, (double)pr[57] / l.n_blocks, (double)pr[58] / l.n_blocks, (double)pr[60] / l.n_blocks, (double)pr[61] / l.n_blocks, (double)pr[62] / l.n_blocks);
             if (pr[52])
                 fprintf(stderr, "[fadehip bgzf] D emit, clocks per block: scan of the bit counts, the stream's words cleared %.0f | thread 0's tokens placed %.0f, then waited for the others %.0f | copied out %.0f\n",
                         (double)pr[52] / l.n_blocks, (double)pr[53] / l.n_blocks, (double)pr[54] / l.n_blocks, (double)pr[55] / l.n_blocks);
