@@ -240,18 +240,48 @@ __device__ __forceinline__ void mr_code_lengths_wave(uint32_t *A, const int m, u
         if (lane == 0) A[0] = 1;
         return;
     }
-    if (lane == 0) {
-        // (Holding the next four nodes and leaves in registers, loaded three picks ahead, was measured: 485 clocks a node
-        // against 390 — one lane's chain is bound by the instructions it issues as much as by the LDS round trips.)
-        A[0] += A[1];
+    {
+        // (One lane with its values in vector registers took 390 clocks a node; holding the next four nodes and leaves in
+        // registers, loaded three picks ahead, 485: the chain is bound by the instructions it issues as much as by the LDS.)
+        // the merge, run by the whole wave on UNIFORM values (read through v_readfirstlane): its compares, selects and counters
+        // are then the scalar unit's, whose dependent operations follow each other faster than one lane's vector operations
+        // The fronts of the two queues (ar, al) are scalars; the places behind them (A[root + 1], A[leaf + 1]) are loads in flight,
+        // in vector registers, turned into scalars only when their turn comes — a pick then does not wait for the LDS.  A
+        // node is written after the place behind root may have been read ahead: its value is put into that register too.
+        auto rfl = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+        constexpr uint32_t INF = 0xffffffffu;
+        const uint32_t a01 = rfl(A[0]) + rfl(A[1]);
+        A[0] = a01;
         int root = 0, leaf = 2;
+        uint32_t ar = a01, al = leaf < m ? rfl(A[2]) : INF;
+        uint32_t pr = A[1], pl = A[3];  // (in flight)
         for (int next = 1; next < m - 1; next++) {
             uint32_t v;
-            if (leaf >= m || A[root] < A[leaf]) { v = A[root]; A[root++] = (uint32_t)next; }
-            else v = A[leaf++];
-            if (leaf >= m || (root < next && A[root] < A[leaf])) { v += A[root]; A[root++] = (uint32_t)next; }
-            else v += A[leaf++];
+            if (ar < al) {  // (leaf >= m: al is the maximum)
+                v = ar;
+                A[root++] = (uint32_t)next;
+                ar = rfl(pr);
+                pr = A[root + 1];
+            } else {
+                v = al;
+                leaf++;
+                al = leaf < m ? rfl(pl) : INF;
+                pl = A[leaf + 1];
+            }
+            if (leaf >= m || (root < next && ar < al)) {
+                v += ar;
+                A[root++] = (uint32_t)next;
+                ar = rfl(pr);
+                pr = A[root + 1];
+            } else {
+                v += al;
+                leaf++;
+                al = leaf < m ? rfl(pl) : INF;
+                pl = A[leaf + 1];
+            }
             A[next] = v;
+            if (root == next) ar = v;           // the node just made is the internal queue's front,
+            else if (root + 1 == next) pr = v;  // or the place behind it
         }
     }
     __builtin_amdgcn_wave_barrier();
