@@ -668,19 +668,28 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             }
         }
         {
+            // The literals of a word without a loop over its tokens: the word's 32 bytes come as two 16-byte loads and every
+            // position adds its bit of the literal bitmap (0 or 1) to its byte's counter — a token at a time, the wave took the
+            // match's path (its symbols are sixty instructions) in nearly every turn because SOME lane had a match.  The few
+            // matches keep a loop of their own.
             uint32_t *hl = h8 + (lane & 7) * 320;
 #pragma unroll
             for (int k = 0; k < WPT; k++) {
-                uint32_t tw = tw_r[k];
-                const uint32_t mw = mw_r[k];
+                const uint32_t mw = mw_r[k], lit = tw_r[k] & ~mw;
+                if (lit) {
+                    const uint4 *d4 = reinterpret_cast<const uint4 *>(data + 32 * (w0 + k));
+                    const uint4 lo = d4[0], hi = d4[1];
+                    const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int b = 0; b < 32; b++) atomicAdd(&hl[(dw[b >> 2] >> (8 * (b & 3))) & 255u], (lit >> b) & 1u);
+                }
+                uint32_t tw = tw_r[k] & mw;
                 while (tw) {
                     const int b = __builtin_ctz(tw);
                     tw &= tw - 1u;
-                    if ((mw >> b) & 1u) {
-                        const uint32_t rec = match[mb_r[k] + (uint32_t)__builtin_popcount(mw & ((1u << b) - 1u))];
-                        atomicAdd(&hl[length_symbol((rec >> 16) + 3u).sym], 1u);
-                        atomicAdd(&hl[288 + dist_symbol(rec & 0xffffu).sym], 1u);
-                    } else atomicAdd(&hl[data[32 * (w0 + k) + b]], 1u);
+                    const uint32_t rec = match[mb_r[k] + (uint32_t)__builtin_popcount(mw & ((1u << b) - 1u))];
+                    atomicAdd(&hl[length_symbol((rec >> 16) + 3u).sym], 1u);
+                    atomicAdd(&hl[288 + dist_symbol(rec & 0xffffu).sym], 1u);
                 }
             }
         }
