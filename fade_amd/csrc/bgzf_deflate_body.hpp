@@ -475,12 +475,14 @@ __device__ __forceinline__ SegOut phase_a_segment(const SegArgs r) {
                 off += 8;
             }
             part(58);
+            uint32_t best_cp = p;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                uint32_t l = ((alive >> k) & 1u) ? maxlen : cl[k];  // still equal where the limit was reached
-                if (l > maxlen) l = maxlen;
-                if (l > len) { len = l; dist = p - cp[k]; }
+                // (still equal where the limit was reached: the longest there is; a compare may have read past the limit)
+                const uint32_t l = min(((alive >> k) & 1u) ? maxlen : cl[k], maxlen);
+                if (l > len) { len = l; best_cp = cp[k]; }
             }
+            dist = p - best_cp;
         }
         // a match ends with its segment (the next segment's parse starts at that segment's first position); what it would have
         // had beyond is remembered for the seam
