@@ -700,8 +700,12 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
             uint32_t f = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) f += h8[k * 320 + s];
-            if (s < 288) ms->freq_l[s] = s == 256 ? 1u : (s < NUM_LITLEN ? f : 0u);
-            else ms->freq_d[s - 288] = (s - 288 < NUM_DIST) ? f : 0u;
+            if (s < 288) {
+                const uint32_t fl = s == 256 ? 1u : (s < NUM_LITLEN ? f : 0u);
+                ms->freq_l[s] = fl;
+                // the symbol's rank key (below), in what was the token bitmap: every thread has its words of it in registers by now
+                tokw[s] = ((fl - 1u) << 9) | (uint32_t)s;
+            } else ms->freq_d[s - 288] = (s - 288 < NUM_DIST) ? f : 0u;
         }
         __syncthreads();
         stamp(2);
@@ -716,18 +720,18 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
         __syncthreads();
         // rank the used symbols by (frequency, symbol): the two in one key, (frequency - 1) << 9 | symbol (a block's tokens
         // are far fewer than 2^23; an unused symbol's key wraps to the top and is smaller than nobody's), so that a
-        // symbol's rank is the number of smaller keys: two symbols a load, four operations a symbol
+        // symbol's rank is the number of smaller keys: the keys are made once (where the frequencies are summed), four come
+        // with a load, and a symbol is a compare and an add
         if (tid < NUM_LITLEN) {
             const uint32_t f = ms->freq_l[tid];
             if (f) {
                 const uint32_t key = ((f - 1u) << 9) | (uint32_t)tid;
                 uint32_t less = 0;
-                static_assert(NUM_LITLEN % 2 == 0 && (offsetof(Misc, freq_l) % 8) == 0, "freq_l is read two at a time");
-                const uint2 *f2 = reinterpret_cast<const uint2 *>(ms->freq_l);
+                const uint4 *k4 = reinterpret_cast<const uint4 *>(tokw);  // the 288 keys (the two behind the alphabet: unused, at the top)
 #pragma unroll 4
-                for (int j = 0; j < NUM_LITLEN / 2; j++) {
-                    const uint2 g = f2[j];
-                    less += ((((g.x - 1u) << 9) | (uint32_t)(2 * j)) < key) + ((((g.y - 1u) << 9) | (uint32_t)(2 * j + 1)) < key);
+                for (int j = 0; j < 288 / 4; j++) {
+                    const uint4 g = k4[j];
+                    less += (g.x < key) + (g.y < key) + (g.z < key) + (g.w < key);
                 }
                 const uint32_t r = less;
                 A_l[r] = f;
