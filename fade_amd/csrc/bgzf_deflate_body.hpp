@@ -937,21 +937,23 @@ __global__ __launch_bounds__(WG, MIN_WAVES_PER_SIMD) void bgzf_deflate_kernel(De
                 if (len == (uint32_t)bb) code = c + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
             }
             if (len) ms->cl_code[lane] = __builtin_bitreverse32(code) >> (32u - len);
-            // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then 3 bits per code-length code length in cl_order
-            int hclen = NUM_CL;
-            while (hclen > 4 && __builtin_amdgcn_readlane((int)len, cl_order(hclen - 1)) == 0) hclen--;
-            uint64_t w0 = 1ull | (2ull << 1) | ((uint64_t)(ms->cl_hlit - 257u) << 3) | ((uint64_t)(ms->cl_hdist - 1u) << 8) | ((uint64_t)(hclen - 4) << 13), w1 = 0;
-            int at = 17;
-            for (int k = 0; k < hclen; k++, at += 3) {
-                const uint64_t l3 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)len, cl_order(k));
-                if (at < 64) w0 |= l3 << at;
-                if (at + 3 > 64) w1 |= at >= 64 ? l3 << (at - 64) : l3 >> (64 - at);
+            // BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN, then 3 bits per code-length code length in cl_order: lane k holds the
+            // k-th of them (the length of symbol cl_order(k), fetched from that symbol's lane), the last one used is the highest
+            // set bit of a ballot, and every lane ORs its three bits into the (cleared) header words
+            // (cl_order as two packed constants, five bits an entry: a table indexed by the lane would be a load from memory)
+            constexpr uint64_t ORD0 = 0x22caa324e804a30ull, ORD1 = 0x3c2e1346cull;
+            const int ord = lane < 12 ? (int)((ORD0 >> (5 * lane)) & 31u) : (int)((ORD1 >> (5 * ((lane < NUM_CL ? lane : 12) - 12))) & 31u);
+            const uint32_t in_order = lane < NUM_CL ? (uint32_t)__shfl((int)len, ord, 64) : 0u;
+            const unsigned long long used = __ballot(in_order != 0u);
+            const int hclen = max(4, used ? 64 - (int)__builtin_clzll(used) : 0);
+            if (lane < hclen) {
+                const uint32_t pos = 17u + 3u * (uint32_t)lane;
+                atomicOr(&ms->hdr[pos >> 5], in_order << (pos & 31u));
+                if ((pos & 31u) > 29u) atomicOr(&ms->hdr[(pos >> 5) + 1u], in_order >> (32u - (pos & 31u)));
             }
             if (lane == 0) {
                 ms->cl_hclen = (uint32_t)hclen;
-                ms->hdr[0] = (uint32_t)w0;
-                ms->hdr[1] = (uint32_t)(w0 >> 32);
-                ms->hdr[2] = (uint32_t)w1;
+                atomicOr(&ms->hdr[0], 1u | (2u << 1) | ((ms->cl_hlit - 257u) << 3) | ((ms->cl_hdist - 1u) << 8) | ((uint32_t)(hclen - 4) << 13));
             }
         }
         // ---- D (first part): the bit counts of the threads' position ranges (WPT bitmap words each).  The literals of a word
