@@ -28,7 +28,10 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return *reinterpret
 __device__ __forceinline__ int32_t ld32s(const uint8_t *p) { return *reinterpret_cast<const i32u *>(p); }
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return *reinterpret_cast<const u16u *>(p); }
 
-constexpr uint32_t SEG = 65536;                 // framing segment (the resolving wave takes ~250 ns per segment: 0.5 ms per 128 MB)
+// framing segment: a walk is a chain of one dependent load per record, so the segment sets the framing's latency (64 KB: ~200
+// records, 185 us per call; 16 KB: a quarter of that).  The resolving wave no longer pays per segment (bam_frame_resolve_kernel
+// takes the linked segments of a group at once), which is what kept the segments large.
+constexpr uint32_t SEG = 16384;
 constexpr uint32_t SEG_SLOTS = SEG / 36 + 2;    // record starts a segment can hold (a record takes at least 36 bytes)
 constexpr uint32_t EXIT_INCOMPLETE = 0x80000000u, EXIT_BAD = 0x40000000u, EXIT_MASK = 0x3fffffffu;
 constexpr uint32_t MAX_U = 0x3fffff00u;         // inflated bytes per chunk (offsets are 30 bits + two flags)
@@ -102,7 +105,7 @@ struct FrameArgs {
 
 // one wave per WALK_SEGS segments: the lanes look for each segment's first plausible record together, then WALK_SEGS lanes walk
 // one segment each (a walk is a chain of ~200 dependent loads: the more waves share the segments, the sooner it is over)
-constexpr uint32_t WALK_SEGS = 16;
+constexpr uint32_t WALK_SEGS = 8;
 __global__ __launch_bounds__(64) void bam_frame_walk_kernel(FrameArgs a) {
     const uint32_t u_len = a.u_len;
     const uint32_t n_seg = (u_len + SEG - 1) / SEG;
@@ -149,7 +152,38 @@ __global__ __launch_bounds__(64) void bam_frame_resolve_kernel(FrameArgs a) {
         uint32_t c = 0xffffffffu, e = 0, n = 0;
         if (s < n_seg) { c = a.cand[s]; e = a.exit_[s]; n = a.cnt[s]; }
         uint32_t my_base = 0, my_n = 0;
-        for (uint32_t j = 0; j < 64u && s0 + j < n_seg; j++) {
+        // The group's head without a chain: a segment's walk is the true one when it started where the chain enters it — its
+        // candidate is the exit of the segment in front (for the group's first: the entry carried here), inside the segment.
+        // That holds for all but a handful of a call's segments (where a look-alike precedes the first record, or one record
+        // covers a whole segment); for the lanes up to the first that is different, or the first whose walk ended early, the
+        // record counts are a prefix sum and the entry is the last one's exit.  The rest of the group takes the chain below.
+        uint32_t j_from = 0;
+        if (!stop) {
+            uint32_t prev_e = (uint32_t)__shfl_up((int)e, 1, 64);
+            if (lane == 0) prev_e = entry;
+            const bool clean = !(e & (EXIT_BAD | EXIT_INCOMPLETE));
+            const bool link = s < n_seg && c != 0xffffffffu && prev_e == c && c < (s + 1u) * SEG;  // (a flagged exit in front never equals a candidate: the flags are high bits)
+            const unsigned long long links = __ballot(link), cleans = __ballot(clean || s >= n_seg);
+            uint32_t k = ~links ? (uint32_t)__builtin_ctzll(~links) : 64u;          // lanes [0, k) are linked
+            if (~cleans) k = min(k, (uint32_t)__builtin_ctzll(~cleans) + 1u);         // ... up to and with the first walk that ended early
+            if (k) {
+                // exclusive prefix sum of the counts over lanes [0, k)
+                uint32_t inc = (uint32_t)lane < k ? n : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+                    if (lane >= d) inc += up;
+                }
+                if ((uint32_t)lane < k) { my_base = total + inc - n; my_n = n; }
+                total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                const uint32_t ex = (uint32_t)__shfl((int)e, (int)k - 1, 64);
+                if (ex & EXIT_BAD) { stop = true; err = 1; err_at = ex & EXIT_MASK; entry = ex & EXIT_MASK; }
+                else if (ex & EXIT_INCOMPLETE) { stop = true; entry = ex & EXIT_MASK; }
+                else entry = ex;
+                j_from = k;
+            }
+        }
+        for (uint32_t j = j_from; j < 64u && s0 + j < n_seg; j++) {
             const uint32_t sj = s0 + j;
             const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)j), ej = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)j),
                            nj = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)j);
